@@ -1,0 +1,194 @@
+/*
+ * primalcr.h -- C ABI of libprimalcr.so: the MI355X-native PrimalCR / PrimalCR++
+ * training path (hand-written HIP for gfx950) behind the reference's solver API.
+ *
+ * Drop-in boundary.  The reference's solver entry points are
+ *     extern "C" void pcrpp(smat_t&, mat_t&, mat_t&, testset_t&, parameter&)  pmf.h:52-56, pcrpp.cpp:841
+ *     extern "C" void pcr  (smat_t&, mat_t&, mat_t&, testset_t&, parameter&)  pmf.h:54,    pcr.cpp:616
+ * whose arguments are C++ references to STL classes -- not a real C ABI.  This
+ * header is the genuine C ABI for the same step: plain pointers and sizes, caller
+ * owned factor buffers (fp64, row-major, exactly the reference's mat_t payload),
+ * integer status codes (the reference returns void and never reports errors).
+ * INTEGRATION.md shows the few lines a maintainer adds to pmf-train.cpp to call it.
+ *
+ * Every entry point cites the reference interface it replaces (file:line relative
+ * to the reference checkout).
+ *
+ * Conventions
+ *   - all matrices row-major, 0-based; U is d1 x k (users), V is d2 x k (items)
+ *   - ratings: user-major CSR in the reference's SparseMat layout (util.h:390-413):
+ *     index[d1+1], item[nnz] (SparseMat::rows), val[nnz] (SparseMat::vals)
+ *   - return value 0 = success, negative = error; pcr_last_error() has the text
+ *   - functions marked [host] never touch the GPU
+ *   - functions marked [device] need a gfx950 GPU and FAIL (never fall back to a
+ *     CPU path) when none is usable
+ */
+#ifndef PRIMALCR_H
+#define PRIMALCR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCR_OK               0
+#define PCR_ERR_ARG         -1
+#define PCR_ERR_IO          -2
+#define PCR_ERR_NOMEM       -3
+#define PCR_ERR_DEVICE      -4   /* no usable GPU / HIP runtime error            */
+#define PCR_ERR_COMM        -5   /* RCCL error                                    */
+#define PCR_ERR_STATE       -6   /* call order (e.g. obtain_g before comp_m)      */
+#define PCR_ERR_UNSUPPORTED -7
+
+/* solver ids: pmf.h:6  enum {CCDR1, PCR, PCRPP} */
+#define PCR_SOLVER_PCR    1
+#define PCR_SOLVER_PCRPP  2
+
+/* storage type of U, V, m and the CG vectors on the device.  Prefix sums,
+ * objectives, dot products and sweep coefficients are ALWAYS accumulated in fp64. */
+#define PCR_F32 0
+#define PCR_F64 1
+
+/* mirrors class parameter (pmf.h:9-49) for the fields the PCR/PCR++ path reads,
+ * plus device-side extensions */
+typedef struct pcr_params {
+    int solver_type;   /* pmf.h:32  default PCRPP (2)                             */
+    int k;             /* pmf.h:33  rank, default 10                              */
+    int threads;       /* pmf.h:38  default 4; host threads of loaders only       */
+    int maxiter;       /* pmf.h:35  default 10                                    */
+    double lambda;     /* pmf.h:37  default 5000                                  */
+    int do_predict;    /* pmf.h:45  default 1                                     */
+    int verbose;       /* pmf.h:46                                                */
+    double stepsize;   /* pmf.h:28  default 1.0 (reset every step, pcrpp.cpp:877) */
+    int ndcg_k;        /* pmf.h:29  default 10                                    */
+    /* extensions */
+    int precision;     /* PCR_F32 (default) | PCR_F64                             */
+    int device;        /* HIP device ordinal, default 0                           */
+} pcr_params;
+
+/* pmf.h:27-48 parameter::parameter() */
+void pcr_params_default(pcr_params *p);                                   /* [host] */
+
+const char *pcr_last_error(void);                                         /* [host] */
+const char *pcr_version(void);                                            /* [host] */
+
+/* ------------------------------------------------------------------------- */
+/* host data path                                                            */
+/* ------------------------------------------------------------------------- */
+
+/* util.cpp:80-93 initial(): N(0,1) from a default-seeded std::default_random_engine
+ * through std::normal_distribution<double>; a fresh engine per call. */
+int pcr_initial(double *X, int64_t n, int64_t k);                         /* [host] */
+
+typedef struct pcr_dataset pcr_dataset;   /* training CSR + test CSR, host memory */
+
+/* util.cpp:6-25 load() + util.h:197-271 smat_t::load + util.h:360-371
+ * testset_t::load + util.cpp:219-274 convert(): reads <dir>/meta and the rating
+ * files it names. */
+int pcr_dataset_load(const char *dir, pcr_dataset **out);                 /* [host] */
+/* same conversion from in-memory 0-based triplets (train in any order; test must
+ * be user-sorted, util.cpp:259-261).  tnnz may be 0. */
+int pcr_dataset_from_triplets(int64_t d1, int64_t d2,
+                              int64_t nnz, const int32_t *user, const int32_t *item, const double *val,
+                              int64_t tnnz, const int32_t *tuser, const int32_t *titem, const double *tval,
+                              pcr_dataset **out);                          /* [host] */
+void pcr_dataset_free(pcr_dataset *ds);                                    /* [host] */
+/* sizes: d1, d2, nnz (train), tnnz (test entries assigned by convert()) */
+int pcr_dataset_dims(const pcr_dataset *ds, int64_t *d1, int64_t *d2, int64_t *nnz, int64_t *tnnz);
+/* copy the CSR out (which: 0 = train, 1 = test); any pointer may be NULL */
+int pcr_dataset_csr(const pcr_dataset *ds, int which, int64_t *index, int64_t *item, double *val);
+/* #Omega = #{(i,j,k): R_ij > R_ik} after the solver's level bucketing (lround for
+ * PrimalCR++, pcrpp.cpp:41; raw doubles for PrimalCR, pcr.cpp:23) */
+int64_t pcr_dataset_count_pairs(const pcr_dataset *ds, int solver_type);   /* [host] */
+
+/* pmf-train.cpp:297-310 + util.cpp:30-51 save_mat_t(U^T,false); save_mat_t(V^T,false):
+ * "long d1, long k, d1*k doubles, long d2, long k, d2*k doubles" */
+int pcr_model_save(const char *path, const double *U, int64_t d1, const double *V, int64_t d2, int64_t k);
+/* pmf-predict.cpp:49-50 + util.cpp:56-79 load_mat_t(fp,true) twice.
+ * Call with U = V = NULL to query the sizes first. */
+int pcr_model_load(const char *path, int64_t *d1, int64_t *d2, int64_t *k, double *U, double *V);
+
+/* nnz-balanced contiguous user ranges for nparts GPUs: bounds[nparts+1] */
+int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *bounds);   /* [host] */
+
+/* ------------------------------------------------------------------------- */
+/* device solver                                                             */
+/* ------------------------------------------------------------------------- */
+
+typedef struct pcr_solver pcr_solver;
+
+/* Upload this rank's user shard (rank 0 of 1 = everything) and allocate the
+ * device state.  Replaces convert(R), convert(T) at pcrpp.cpp:850-851. */
+int pcr_solver_create(const pcr_dataset *ds, const pcr_params *p, int rank, int nranks,
+                      pcr_solver **out);                                   /* [device] */
+void pcr_solver_destroy(pcr_solver *s);
+
+/* RCCL bootstrap for nranks > 1 (one process per GPU): rank 0 obtains an id
+ * (128 bytes), the host application broadcasts it, every rank calls comm_init. */
+int pcr_comm_unique_id(void *id128);                                       /* [device] */
+int pcr_solver_comm_init(pcr_solver *s, const void *id128);                /* [device] */
+
+/* first local user and number of local users of this rank's shard */
+int pcr_solver_shard(const pcr_solver *s, int64_t *first_user, int64_t *n_users, int64_t *nnz_local);
+
+/* factors: host fp64 <-> device.  U is the FULL d1 x k matrix; each rank reads /
+ * writes only its own rows [first_user, first_user+n_users). V is d2 x k. */
+int pcr_solver_set_factors(pcr_solver *s, const double *U, const double *V);
+int pcr_solver_get_factors(pcr_solver *s, double *U, double *V);
+
+/* pcrpp.cpp:17-35 comp_m_new (pcr.cpp:47 comp_m): m = u_i . v_j for every rating,
+ * from the current device U, V; also builds the per-user (level, m)-sorted state
+ * the sweeps use.  m_out (local nnz, CSR order) may be NULL. */
+int pcr_comp_m(pcr_solver *s, double *m_out);
+/* pcrpp.cpp:361-412 objective_new (pcr.cpp:5 objective) at the state of the last
+ * pcr_comp_m: all-rank sum incl. lambda/2 (|U|^2 + |V|^2). */
+int pcr_objective(pcr_solver *s, double *obj);
+/* pcrpp.cpp:140-249 obtain_g_new (pcr.cpp:102 obtain_g): g (d2 x k) */
+int pcr_obtain_g(pcr_solver *s, double *g);
+/* pcrpp.cpp:252-332 compute_Ha_new (pcr.cpp:167 compute_Ha): a, Ha are d2 x k */
+int pcr_compute_Ha(pcr_solver *s, const double *a, double *Ha);
+/* pcrpp.cpp:335-358 solve_delta_new (pcr.cpp:248): CG on H delta = g */
+int pcr_solve_delta(pcr_solver *s, const double *g, double *delta, int *cg_iters);
+/* pcrpp.cpp:415-444 update_V_new (pcr.cpp:279): one Newton step on V.
+ * info[0] = CG iterations, info[1] = line-search evaluations, info[2] = accepted */
+int pcr_update_V(pcr_solver *s, double *now_obj, int *info);
+/* pcrpp.cpp:818-838 update_U_new (pcr.cpp:587): one Newton step per user.
+ * info[0] = total CG iterations, info[1] = total line-search evaluations */
+int pcr_update_U(pcr_solver *s, double *now_obj, int64_t *info);
+/* util.cpp:434-542 compute_pairwise_error_ndcg on the train (which=0) or test
+ * (which=1) ratings with the current device factors */
+int pcr_evaluate(pcr_solver *s, int which, int ndcg_k, double *pairwise_err, double *ndcg);
+
+/* what the reference prints per iteration (pcrpp.cpp:859-890) */
+typedef struct pcr_iter_stats {
+    double obj;
+    double train_err, train_ndcg, test_err, test_ndcg;
+    double seconds;                 /* cumulative, clock scope of pcrpp.cpp:874-881 */
+    int64_t cg_v, ls_v, cg_u, ls_u; /* executed inner-iteration counts              */
+} pcr_iter_stats;
+
+typedef void (*pcr_log_fn)(void *ctx, const char *line);
+
+/* pcrpp.cpp:841-901 pcrpp() / pcr.cpp:616-704 pcr(): the whole training loop
+ * from the current device factors.  Emits the reference's log lines through
+ * `log` (NULL = stdout).  hist may be NULL, else holds maxiter+1 records. */
+int pcr_train(pcr_solver *s, pcr_log_fn log, void *log_ctx, pcr_iter_stats *hist);
+
+/* pmf-predict.cpp:56-64: pred[z] = U[user[z]] . V[item[z]] for n (0-based) pairs */
+int pcr_predict(const double *U, int64_t d1, const double *V, int64_t d2, int64_t k,
+                int64_t n, const int32_t *user, const int32_t *item, double *pred,
+                int device);                                               /* [device] */
+
+/* per-kernel-class device timing (HIP events on the solver's stream).
+ * names: "prepare", "vgrad", "vhv", "spmm", "cg", "ustep", "eval", "allreduce" */
+int pcr_profile_enable(pcr_solver *s, int on);
+int pcr_profile_get(pcr_solver *s, const char *name, double *total_ms, int64_t *launches);
+int pcr_profile_reset(pcr_solver *s);
+/* blocks until the solver's stream is idle */
+int pcr_solver_sync(pcr_solver *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRIMALCR_H */

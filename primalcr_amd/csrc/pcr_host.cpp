@@ -1,0 +1,335 @@
+// pcr_host.cpp -- host data path of libprimalcr: meta/ratings loader, CSR conversion, level
+// ranking, model file I/O, initial(), user partitioning.  No GPU calls in this file.
+//
+// Mirrors the *formats and semantics* of the reference (file:line cited per function); the
+// reference's vector<vector<double>> / smat_t containers are not reproduced.
+#include "pcr_host.h"
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <random>
+
+static thread_local std::string g_err;
+void pcr_set_error(const std::string& msg) { g_err = msg; }
+
+extern "C" const char* pcr_last_error(void) { return g_err.c_str(); }
+extern "C" const char* pcr_version(void) { return "primalcr-mi355x 0.1 (gfx950)"; }
+
+// pmf.h:27-48
+extern "C" void pcr_params_default(pcr_params* p) {
+    p->solver_type = PCR_SOLVER_PCRPP;
+    p->k = 10;
+    p->threads = 4;
+    p->maxiter = 10;
+    p->lambda = 5000;
+    p->do_predict = 1;
+    p->verbose = 0;
+    p->stepsize = 1.0;
+    p->ndcg_k = 10;
+    p->precision = PCR_F32;
+    p->device = 0;
+}
+
+// util.cpp:80-93.  Init parity depends on libstdc++'s generate_canonical / polar method, so
+// the std facilities are called directly.
+extern "C" int pcr_initial(double* X, int64_t n, int64_t k) {
+    if (!X || n < 0 || k < 0) { pcr_set_error("pcr_initial: bad argument"); return PCR_ERR_ARG; }
+    std::default_random_engine generator;
+    std::normal_distribution<double> distribution(0.0, 1.0);
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < k; ++j) X[i * k + j] = distribution(generator);
+    return PCR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// CSR conversion
+// ------------------------------------------------------------------------------------------
+
+// util.h:223-247 sorts entries by (row, col); util.cpp:229-243 walks them user by user:
+// items ascending inside a user.  Counting sort by user, then a per-user sort by item.
+static int build_train_csr(int64_t d1, int64_t d2, int64_t nnz, const int32_t* user, const int32_t* item,
+                           const double* val, PcrCsr& X) {
+    X.d1 = d1; X.d2 = d2;
+    X.index.assign(d1 + 1, 0);
+    for (int64_t z = 0; z < nnz; ++z) {
+        if (user[z] < 0 || user[z] >= d1 || item[z] < 0 || item[z] >= d2) {
+            pcr_set_error("rating " + std::to_string(z) + " has user/item id outside the meta dimensions");
+            return PCR_ERR_ARG;
+        }
+        X.index[user[z] + 1]++;
+    }
+    for (int64_t u = 0; u < d1; ++u) X.index[u + 1] += X.index[u];
+    X.item.resize(nnz); X.val.resize(nnz);
+    std::vector<int64_t> cur(X.index.begin(), X.index.end() - 1);
+    std::vector<int64_t> src(nnz);
+    for (int64_t z = 0; z < nnz; ++z) src[cur[user[z]]++] = z;
+    for (int64_t u = 0; u < d1; ++u) {
+        int64_t a = X.index[u], b = X.index[u + 1];
+        bool sorted = true;
+        for (int64_t q = a + 1; q < b && sorted; ++q) sorted = item[src[q - 1]] <= item[src[q]];
+        if (!sorted)
+            std::stable_sort(src.begin() + a, src.begin() + b, [&](int64_t x, int64_t y) { return item[x] < item[y]; });
+        for (int64_t q = a; q < b; ++q) { X.item[q] = item[src[q]]; X.val[q] = val[src[q]]; }
+    }
+    return PCR_OK;
+}
+
+// util.cpp:250-274: the test file is assumed user-sorted; the scan stops assigning at the first
+// entry whose user id exceeds the cursor, so out-of-order tails are dropped -- mirrored.
+static void build_test_csr(int64_t d1, int64_t d2, int64_t nnz, const int32_t* user, const int32_t* item,
+                           const double* val, PcrCsr& X) {
+    X.d1 = d1; X.d2 = d2;
+    X.index.assign(d1 + 1, 0);
+    X.item.clear(); X.val.clear();
+    X.item.reserve(nnz); X.val.reserve(nnz);
+    int64_t cc = 0;
+    for (int64_t j = 0; j < d1; ++j) {
+        X.index[j] = cc;
+        for (; cc < nnz; ++cc) {
+            if (user[cc] > j) break;
+            X.item.push_back(item[cc]);
+            X.val.push_back(val[cc]);
+        }
+    }
+    X.index[d1] = cc;
+}
+
+extern "C" int pcr_dataset_from_triplets(int64_t d1, int64_t d2, int64_t nnz, const int32_t* user,
+                                         const int32_t* item, const double* val, int64_t tnnz,
+                                         const int32_t* tuser, const int32_t* titem, const double* tval,
+                                         pcr_dataset** out) {
+    if (!out || d1 < 0 || d2 < 0 || nnz < 0 || tnnz < 0 || (nnz > 0 && (!user || !item || !val)) ||
+        (tnnz > 0 && (!tuser || !titem || !tval))) {
+        pcr_set_error("pcr_dataset_from_triplets: bad argument");
+        return PCR_ERR_ARG;
+    }
+    pcr_dataset* ds = new (std::nothrow) pcr_dataset();
+    if (!ds) { pcr_set_error("out of memory"); return PCR_ERR_NOMEM; }
+    int rc = build_train_csr(d1, d2, nnz, user, item, val, ds->train);
+    if (rc != PCR_OK) { delete ds; return rc; }
+    for (int64_t z = 0; z < tnnz; ++z)
+        if (titem[z] < 0 || titem[z] >= d2 || tuser[z] < 0) {
+            pcr_set_error("test rating " + std::to_string(z) + " has user/item id outside the meta dimensions");
+            delete ds;
+            return PCR_ERR_ARG;
+        }
+    build_test_csr(d1, d2, tnnz, tuser, titem, tval, ds->test);
+    ds->tnnz_file = tnnz;
+    *out = ds;
+    return PCR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// text loader (util.cpp:6-25, util.h:118-131, util.h:360-371)
+// ------------------------------------------------------------------------------------------
+
+static int read_file(const std::string& path, std::vector<char>& buf) {
+    FILE* fp = fopen(path.c_str(), "rb");
+    if (!fp) { pcr_set_error("can't open " + path + ": " + strerror(errno)); return PCR_ERR_IO; }
+    fseek(fp, 0, SEEK_END);
+    long sz = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    buf.resize((size_t)sz + 1);
+    size_t got = fread(buf.data(), 1, (size_t)sz, fp);
+    fclose(fp);
+    buf[got] = 0;
+    buf.resize(got + 1);
+    return PCR_OK;
+}
+
+// "%d %d %lf" per entry, 1-based ids (util.h:126,131; util.h:367-368)
+static int parse_ratings(const std::string& path, int64_t nnz, std::vector<int32_t>& user,
+                         std::vector<int32_t>& item, std::vector<double>& val) {
+    std::vector<char> buf;
+    int rc = read_file(path, buf);
+    if (rc != PCR_OK) return rc;
+    user.resize(nnz); item.resize(nnz); val.resize(nnz);
+    char* p = buf.data();
+    for (int64_t z = 0; z < nnz; ++z) {
+        char* e;
+        long i = strtol(p, &e, 10);
+        if (e == p) { pcr_set_error(path + ": expected " + std::to_string(nnz) + " ratings, found " + std::to_string(z)); return PCR_ERR_IO; }
+        p = e;
+        long j = strtol(p, &e, 10);
+        if (e == p) { pcr_set_error(path + ": malformed rating line " + std::to_string(z + 1)); return PCR_ERR_IO; }
+        p = e;
+        double v = strtod(p, &e);
+        if (e == p) { pcr_set_error(path + ": malformed rating line " + std::to_string(z + 1)); return PCR_ERR_IO; }
+        p = e;
+        user[z] = (int32_t)(i - 1); item[z] = (int32_t)(j - 1); val[z] = v;
+    }
+    return PCR_OK;
+}
+
+extern "C" int pcr_dataset_load(const char* dir, pcr_dataset** out) {
+    if (!dir || !out) { pcr_set_error("pcr_dataset_load: bad argument"); return PCR_ERR_ARG; }
+    std::string d(dir);
+    std::string metap = d + "/meta";
+    FILE* fp = fopen(metap.c_str(), "r");
+    if (!fp) { pcr_set_error("can't open " + metap + ": " + strerror(errno)); return PCR_ERR_IO; }
+    long m = 0, n = 0, nnz = 0, tnnz = 0;
+    char name[1024], tname[1024];
+    bool have_test = false;
+    if (fscanf(fp, "%ld %ld", &m, &n) != 2 || fscanf(fp, "%ld %1023s", &nnz, name) != 2) {
+        fclose(fp);
+        pcr_set_error(metap + ": expected 'm n' then 'nnz training_file'");
+        return PCR_ERR_IO;
+    }
+    if (fscanf(fp, "%ld %1023s", &tnnz, tname) == 2) have_test = true;   // third line optional (util.cpp:18)
+    fclose(fp);
+    std::vector<int32_t> u, i, tu, ti;
+    std::vector<double> v, tv;
+    int rc = parse_ratings(d + "/" + name, nnz, u, i, v);
+    if (rc != PCR_OK) return rc;
+    if (have_test) {
+        rc = parse_ratings(d + "/" + tname, tnnz, tu, ti, tv);
+        if (rc != PCR_OK) return rc;
+    } else {
+        tnnz = 0;
+    }
+    return pcr_dataset_from_triplets(m, n, nnz, u.data(), i.data(), v.data(), tnnz, tu.data(), ti.data(), tv.data(), out);
+}
+
+extern "C" void pcr_dataset_free(pcr_dataset* ds) { delete ds; }
+
+extern "C" int pcr_dataset_dims(const pcr_dataset* ds, int64_t* d1, int64_t* d2, int64_t* nnz, int64_t* tnnz) {
+    if (!ds) { pcr_set_error("null dataset"); return PCR_ERR_ARG; }
+    if (d1) *d1 = ds->train.d1;
+    if (d2) *d2 = ds->train.d2;
+    if (nnz) *nnz = ds->train.nnz();
+    if (tnnz) *tnnz = ds->test.nnz();
+    return PCR_OK;
+}
+
+extern "C" int pcr_dataset_csr(const pcr_dataset* ds, int which, int64_t* index, int64_t* item, double* val) {
+    if (!ds || (which != 0 && which != 1)) { pcr_set_error("pcr_dataset_csr: bad argument"); return PCR_ERR_ARG; }
+    const PcrCsr& X = which == 0 ? ds->train : ds->test;
+    if (index) std::copy(X.index.begin(), X.index.end(), index);
+    if (item) for (size_t z = 0; z < X.item.size(); ++z) item[z] = X.item[z];
+    if (val) std::copy(X.val.begin(), X.val.end(), val);
+    return PCR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// levels
+// ------------------------------------------------------------------------------------------
+
+int pcr_build_levels(const PcrCsr& X, int64_t u0, int64_t u1, int solver_type, PcrLevels& out, std::string& err) {
+    int64_t z0 = X.index[u0], z1 = X.index[u1];
+    out.level.assign((size_t)(z1 - z0), 0);
+    out.run_ofs.assign((size_t)(u1 - u0 + 1), 0);
+    out.run_start.clear();
+    out.max_levels = 0;
+    std::vector<double> keys, uniq;
+    for (int64_t u = u0; u < u1; ++u) {
+        int64_t a = X.index[u], b = X.index[u + 1];
+        keys.resize((size_t)(b - a));
+        for (int64_t z = a; z < b; ++z)
+            keys[z - a] = (solver_type == PCR_SOLVER_PCRPP) ? (double)lround(X.val[z]) : X.val[z];
+        uniq = keys;
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        int T = (int)uniq.size();
+        if (T > 65535) { err = "user " + std::to_string(u) + " has more than 65535 distinct rating levels"; return PCR_ERR_UNSUPPORTED; }
+        out.max_levels = std::max(out.max_levels, T);
+        out.run_ofs[u - u0] = (int64_t)out.run_start.size();
+        size_t base = out.run_start.size();
+        out.run_start.resize(base + T + 1, 0);
+        for (int64_t z = a; z < b; ++z) {
+            int l = (int)(std::lower_bound(uniq.begin(), uniq.end(), keys[z - a]) - uniq.begin());
+            out.level[z - z0] = (uint16_t)l;
+            out.run_start[base + l + 1]++;
+        }
+        for (int l = 0; l < T; ++l) out.run_start[base + l + 1] += out.run_start[base + l];
+    }
+    out.run_ofs[u1 - u0] = (int64_t)out.run_start.size();
+    return PCR_OK;
+}
+
+extern "C" int64_t pcr_dataset_count_pairs(const pcr_dataset* ds, int solver_type) {
+    if (!ds) return -1;
+    const PcrCsr& X = ds->train;
+    PcrLevels lv;
+    std::string err;
+    if (pcr_build_levels(X, 0, X.d1, solver_type, lv, err) != PCR_OK) { pcr_set_error(err); return -1; }
+    int64_t total = 0;
+    for (int64_t u = 0; u < X.d1; ++u) {
+        int64_t n = X.index[u + 1] - X.index[u], same = 0;
+        for (int64_t q = lv.run_ofs[u]; q + 1 < lv.run_ofs[u + 1]; ++q) {
+            int64_t c = lv.run_start[q + 1] - lv.run_start[q];
+            same += c * c;
+        }
+        total += (n * n - same) / 2;
+    }
+    return total;
+}
+
+// ------------------------------------------------------------------------------------------
+// model file (pmf-train.cpp:297-310, util.cpp:30-79)
+// ------------------------------------------------------------------------------------------
+
+extern "C" int pcr_model_save(const char* path, const double* U, int64_t d1, const double* V, int64_t d2, int64_t k) {
+    FILE* fp = fopen(path, "wb");
+    if (!fp) { pcr_set_error(std::string("can't open output file ") + path); return PCR_ERR_IO; }
+    long hdr[2];
+    bool ok = true;
+    hdr[0] = (long)d1; hdr[1] = (long)k;
+    ok &= fwrite(hdr, sizeof(long), 2, fp) == 2;
+    ok &= fwrite(U, sizeof(double), (size_t)(d1 * k), fp) == (size_t)(d1 * k);
+    hdr[0] = (long)d2; hdr[1] = (long)k;
+    ok &= fwrite(hdr, sizeof(long), 2, fp) == 2;
+    ok &= fwrite(V, sizeof(double), (size_t)(d2 * k), fp) == (size_t)(d2 * k);
+    ok &= fclose(fp) == 0;
+    if (!ok) { pcr_set_error(std::string("short write to ") + path); return PCR_ERR_IO; }
+    return PCR_OK;
+}
+
+extern "C" int pcr_model_load(const char* path, int64_t* d1, int64_t* d2, int64_t* k, double* U, double* V) {
+    FILE* fp = fopen(path, "rb");
+    if (!fp) { pcr_set_error(std::string("can't open model file ") + path); return PCR_ERR_IO; }
+    long hdr[2];
+    int rc = PCR_OK;
+    do {
+        if (fread(hdr, sizeof(long), 2, fp) != 2 || hdr[0] < 0 || hdr[1] < 0) { rc = PCR_ERR_IO; break; }
+        long m1 = hdr[0], kk = hdr[1];
+        if (U) { if (fread(U, sizeof(double), (size_t)(m1 * kk), fp) != (size_t)(m1 * kk)) { rc = PCR_ERR_IO; break; } }
+        else fseek(fp, (long)sizeof(double) * m1 * kk, SEEK_CUR);
+        if (fread(hdr, sizeof(long), 2, fp) != 2 || hdr[1] != kk) { rc = PCR_ERR_IO; break; }
+        long m2 = hdr[0];
+        if (V && fread(V, sizeof(double), (size_t)(m2 * kk), fp) != (size_t)(m2 * kk)) { rc = PCR_ERR_IO; break; }
+        if (d1) *d1 = m1;
+        if (d2) *d2 = m2;
+        if (k) *k = kk;
+    } while (0);
+    fclose(fp);
+    if (rc != PCR_OK) pcr_set_error(std::string("malformed model file ") + path);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// multi-GPU partition: contiguous user ranges balanced by nnz
+// ------------------------------------------------------------------------------------------
+
+extern "C" int pcr_partition_users(const int64_t* index, int64_t d1, int nparts, int64_t* bounds) {
+    if (!index || !bounds || nparts < 1 || d1 < 0) { pcr_set_error("pcr_partition_users: bad argument"); return PCR_ERR_ARG; }
+    int64_t nnz = index[d1];
+    bounds[0] = 0;
+    for (int p = 1; p < nparts; ++p) {
+        // first user boundary whose prefix nnz reaches p/nparts of the total
+        double target = (double)nnz * p / nparts;
+        int64_t lo = bounds[p - 1], hi = d1;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) / 2;
+            if ((double)index[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        if (nnz == 0) lo = d1 * p / nparts;
+        bounds[p] = std::max(lo, bounds[p - 1]);
+    }
+    bounds[nparts] = d1;
+    return PCR_OK;
+}

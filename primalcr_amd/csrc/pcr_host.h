@@ -1,0 +1,36 @@
+// pcr_host.h -- host-side data structures shared by the loader, the solver and the CLIs.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "primalcr.h"
+
+// user-major CSR in the reference's SparseMat layout (util.h:390-413); `item` is
+// SparseMat::rows, the user id per rating (SparseMat::cols) is implied by `index`.
+struct PcrCsr {
+    int64_t d1 = 0, d2 = 0;
+    std::vector<int64_t> index;   // d1 + 1
+    std::vector<int32_t> item;    // nnz
+    std::vector<double> val;      // nnz
+    int64_t nnz() const { return index.empty() ? 0 : index.back(); }
+};
+
+struct pcr_dataset {
+    PcrCsr train, test;
+    int64_t tnnz_file = 0;        // test entries read from the file (T.nnz, pcrpp.cpp:865)
+};
+
+// dense rank of the rating bucket inside each user: lround(val) for PrimalCR++
+// (pcrpp.cpp:38-49,182-189), the raw double for PrimalCR (pcr.cpp:23 compares doubles).
+// level[z] in [0, T_u); run_ofs[u]..run_ofs[u+1] indexes run_start, which holds T_u + 1
+// cumulative per-level counts for user u (run_start[run_ofs[u] + T_u] == len_u).
+struct PcrLevels {
+    std::vector<uint16_t> level;      // nnz
+    std::vector<int64_t> run_ofs;     // d1 + 1
+    std::vector<int32_t> run_start;   // sum_u (T_u + 1)
+    int max_levels = 0;
+};
+int pcr_build_levels(const PcrCsr& X, int64_t u0, int64_t u1, int solver_type, PcrLevels& out, std::string& err);
+
+void pcr_set_error(const std::string& msg);

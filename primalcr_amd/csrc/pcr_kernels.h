@@ -1,0 +1,1030 @@
+// pcr_kernels.h -- hand-written HIP kernels for gfx950 (CDNA4, wave64) of the PrimalCR /
+// PrimalCR++ hot path.  Header-only templates, instantiated in pcr_solver.hip.
+//
+// Kernel map (reference site -> kernel), SURVEY 2.4:
+//   K1+K2+K6  comp_m_new + get_sorted_mm + objective_new   -> k_prepare   (per user)
+//   K4        obtain_g_new  sweep (pcrpp.cpp:214-238)      -> k_vsweep<GRAD> + k_spmm
+//   K5        compute_Ha_new sweep (pcrpp.cpp:294-318)     -> k_vsweep<HV>   + k_spmm
+//   K7        solve_delta_new vector ops (pcrpp.cpp:335)   -> k_cg_*
+//   K8        update_u_new (pcrpp.cpp:779-815)             -> k_ustep     (per user, fused)
+//   K10       compute_pairwise_error_ndcg (util.cpp:434)   -> k_eval      (per user)
+//
+// Formulation (replaces the sequential two-pointer sweep with data-parallel primitives,
+// same result): a user's ratings are sorted by (level, m), so every rating level is one
+// sorted run.  For item p of level l and another level l':
+//     l' > l : partners are the run prefix {q : m_q <= m_p + 1}   (pcrpp.cpp:218)
+//     l' < l : partners are the run suffix {q : m_q >= m_p - 1}   (pcrpp.cpp:224)
+// found by binary search; counts come from the indices, sums from ONE fp64 exclusive prefix
+// sum over the sorted order.  Work per pass O(len * T * log len), all lane-parallel in LDS.
+//
+// Layout: factor rows are padded to ld = roundup(k, 4) elements so every row is 16-byte
+// aligned; a row is read by a group of G lanes (G = pow2 >= ld/VEC, <= 64), one 16-byte
+// vector per lane -> each wave-instruction moves 64/G whole rows, coalesced.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PCR_WAVE 64
+#define PCR_KMAX 4          // row chunks per lane: supports ld/VEC <= 256
+
+template <typename T> struct VecOf;
+template <> struct VecOf<float>  { typedef float4 type;  static constexpr int N = 4; };
+template <> struct VecOf<double> { typedef double2 type; static constexpr int N = 2; };
+
+__device__ __forceinline__ float  vdot(const float4& a, const float4& b)  { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ double vdot(const double2& a, const double2& b) { return a.x * b.x + a.y * b.y; }
+__device__ __forceinline__ float  velem(const float4& a, int e)  { return e == 0 ? a.x : e == 1 ? a.y : e == 2 ? a.z : a.w; }
+__device__ __forceinline__ double velem(const double2& a, int e) { return e == 0 ? a.x : a.y; }
+
+struct Geo { int r, ld, nchunk, G; };   // rank, padded row length, 16-byte chunks per row, lanes per row
+
+// this rank's training shard on the device
+template <typename T>
+struct Shard {
+    int64_t nu, nnz;
+    int d2;
+    const int64_t* uptr;       // nu+1   user -> CSR offset
+    const int32_t* item;       // nnz    CSR order
+    const uint16_t* lvl;       // nnz    CSR order, dense level inside the user
+    const int32_t* cpos;       // nnz    CSR position -> CSC position
+    const int64_t* runofs;     // nu+1
+    const int32_t* runstart;   // per user T_u+1 cumulative level counts
+    // (level, m)-sorted state written by k_prepare
+    T* ms;                     // nnz
+    int32_t* sitem;            // nnz    item id at sorted position
+    uint16_t* slvl;            // nnz
+    int32_t* scsc;             // nnz    CSC position at sorted position
+    double* objp;              // nu     per-user loss partial
+};
+
+// ---------------------------------------------------------------------------------------
+// wave / block primitives (wave = 64 lanes)
+// ---------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// total to every thread; red: LDS, >= BLOCK/64 doubles
+template <int BLOCK>
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    v = wave_sum(v);
+    if (BLOCK == PCR_WAVE) return v;
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / PCR_WAVE; ++w) t += red[w];
+    return t;
+}
+
+// out[i] = sum_{q<i} f(q) for i in [0, n]; fp64; strided rounds keep LDS access conflict-free
+template <int BLOCK, class F>
+__device__ __forceinline__ void block_excl_scan(F f, double* out, int n, double* red) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double carry = 0.0;
+    for (int base = 0; base < n; base += BLOCK) {
+        const int i = base + tid;
+        const double v = (i < n) ? f(i) : 0.0;
+        double inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            double t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        double woff = 0.0, total;
+        if (BLOCK > PCR_WAVE) {
+            __syncthreads();
+            if (lane == 63) red[wid] = inc;
+            __syncthreads();
+            total = 0.0;
+#pragma unroll
+            for (int w = 0; w < BLOCK / PCR_WAVE; ++w) {
+                double x = red[w];
+                if (w < wid) woff += x;
+                total += x;
+            }
+        } else {
+            total = __shfl(inc, 63);
+        }
+        if (i < n) out[i] = carry + woff + inc - v;
+        carry += total;
+    }
+    if (tid == 0) out[n] = carry;
+    __syncthreads();
+}
+
+// packed (level, index): LDS-resident users use 32 bits (level<<16 | idx), users that live in
+// global scratch use 64 bits (level<<32 | idx)
+template <typename LI> struct LiOps;
+template <> struct LiOps<uint32_t> {
+    static constexpr int SH = 16;
+    static __device__ __forceinline__ uint32_t pack(unsigned lv, unsigned idx) { return (lv << 16) | idx; }
+    static __device__ __forceinline__ unsigned lev(uint32_t x) { return x >> 16; }
+    static __device__ __forceinline__ unsigned idx(uint32_t x) { return x & 0xFFFFu; }
+};
+template <> struct LiOps<uint64_t> {
+    static constexpr int SH = 32;
+    static __device__ __forceinline__ uint64_t pack(unsigned lv, unsigned idx) { return ((uint64_t)lv << 32) | idx; }
+    static __device__ __forceinline__ unsigned lev(uint64_t x) { return (unsigned)(x >> 32); }
+    static __device__ __forceinline__ unsigned idx(uint64_t x) { return (unsigned)(x & 0xFFFFFFFFu); }
+};
+
+// ascending bitonic sort of (key, li) by (level, key); npad = pow2 >= n, padding carries the
+// maximum level so it sinks to the end.  Tie order among equal (level, key) is irrelevant to
+// every sum computed from the order (the reference's std::sort is unstable too).
+template <typename T, typename LI, int BLOCK>
+__device__ __forceinline__ void bitonic_sort(T* key, LI* li, int npad) {
+    const int tid = threadIdx.x;
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (npad >> 1); t += BLOCK) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool up = ((i & k) == 0);
+                T ka = key[i], kb = key[l];
+                LI la = li[i], lb = li[l];
+                unsigned va = LiOps<LI>::lev(la), vb = LiOps<LI>::lev(lb);
+                bool b_lt_a = (vb < va) || (vb == va && kb < ka);
+                bool a_lt_b = (va < vb) || (va == vb && ka < kb);
+                bool sw = up ? b_lt_a : a_lt_b;
+                if (sw) { key[i] = kb; key[l] = ka; li[i] = lb; li[l] = la; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// first index in [s,e) with a[q] > x   (= s + #{a[q] <= x})
+template <typename T>
+__device__ __forceinline__ int ubound(const T* a, int s, int e, T x) {
+    while (s < e) { int m = (s + e) >> 1; if (a[m] <= x) s = m + 1; else e = m; }
+    return s;
+}
+// first index in [s,e) with a[q] >= x  (= s + #{a[q] < x})
+template <typename T>
+__device__ __forceinline__ int lbound(const T* a, int s, int e, T x) {
+    while (s < e) { int m = (s + e) >> 1; if (a[m] < x) s = m + 1; else e = m; }
+    return s;
+}
+
+// Sweep coefficient of one item (pcrpp.cpp:230-238 with x = m, shift = 1; :310-318 with x = b,
+// shift = 0).  ms: (level, m)-sorted scores, S: exclusive prefix sum of x over that order,
+// rs: run boundaries.  strict = PrimalCR's `mask < 1.0` (pcr.cpp:137) instead of the inclusive
+// windows of PrimalCR++ (pcrpp.cpp:218,224).
+template <typename T>
+__device__ __forceinline__ double sweep_coeff(const T* ms, const double* S, const int* rs, int nlev, int lev,
+                                              T mp, double xp, double shift, int strict) {
+    double acc = 0.0;
+    const T lo = mp - (T)1, hi = mp + (T)1;
+    for (int l = 0; l < nlev; ++l) {
+        if (l == lev) continue;
+        const int s = rs[l], e = rs[l + 1];
+        if (l < lev) {
+            const int w = strict ? ubound(ms, s, e, lo) : lbound(ms, s, e, lo);
+            acc += (double)(e - w) * (xp - shift) - (S[e] - S[w]);
+        } else {
+            const int w = strict ? lbound(ms, s, e, hi) : ubound(ms, s, e, hi);
+            acc += (double)(w - s) * (xp + shift) - (S[w] - S[s]);
+        }
+    }
+    return 2.0 * acc;
+}
+
+// Loss of one user (pcrpp.cpp:392-407): sum over items p and higher levels l' of
+//   cnt*m_p^2 - 2 m_p * sum(m_q - 1) + sum((m_q - 1)^2)  over the active prefix of run l'.
+// Two passes share ONE fp64 prefix array S (LDS budget); levf(p) = level of sorted position p.
+template <typename T, int BLOCK, class LevF>
+__device__ __forceinline__ double block_objective(const T* ms, LevF levf, const int* rs, int nlev, int n,
+                                                  double* S, double* red, int strict) {
+    const int tid = threadIdx.x;
+    double part = 0.0;
+    block_excl_scan<BLOCK>([&](int i) { return (double)ms[i] - 1.0; }, S, n, red);
+    for (int p = tid; p < n; p += BLOCK) {
+        const int lev = levf(p);
+        const T mp = ms[p];
+        const T hi = mp + (T)1;
+        const double m = (double)mp;
+        for (int l = lev + 1; l < nlev; ++l) {
+            const int s = rs[l], e = rs[l + 1];
+            const int w = strict ? lbound(ms, s, e, hi) : ubound(ms, s, e, hi);
+            part += (double)(w - s) * m * m - 2.0 * m * (S[w] - S[s]);
+        }
+    }
+    __syncthreads();
+    block_excl_scan<BLOCK>([&](int i) { double d = (double)ms[i] - 1.0; return d * d; }, S, n, red);
+    for (int p = tid; p < n; p += BLOCK) {
+        const int lev = levf(p);
+        const T hi = ms[p] + (T)1;
+        for (int l = lev + 1; l < nlev; ++l) {
+            const int s = rs[l], e = rs[l + 1];
+            const int w = strict ? lbound(ms, s, e, hi) : ubound(ms, s, e, hi);
+            part += S[w] - S[s];
+        }
+    }
+    __syncthreads();
+    return block_sum<BLOCK>(part, red);
+}
+
+// out[p] = vec . M[rows[p]]  for p in [0, n)   (SDDMM of one user; pcrpp.cpp:28-31, :266-271,
+// :592-594, :735-742).  vecT: LDS, ld entries of T.  rows: LDS or global.  G lanes per row.
+template <typename T, int BLOCK>
+__device__ __forceinline__ void block_sddmm(const T* __restrict__ M, const T* vecT, const int32_t* rows, int n,
+                                            T* out, const Geo& geo) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VEC = VecOf<T>::N;
+    const int G = geo.G, g = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = BLOCK / G;
+    V uv[PCR_KMAX];
+#pragma unroll
+    for (int k = 0; k < PCR_KMAX; ++k) {
+        const int ch = g + k * G;
+        if (ch < geo.nchunk) uv[k] = *reinterpret_cast<const V*>(vecT + ch * VEC);
+    }
+    for (int base = grp; base < n; base += ngrp * 4) {
+        T acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = base + q * ngrp;
+            acc[q] = (T)0;
+            if (row < n) {
+                const T* rp = M + (size_t)rows[row] * geo.ld;
+#pragma unroll
+                for (int k = 0; k < PCR_KMAX; ++k) {
+                    const int ch = g + k * G;
+                    if (ch < geo.nchunk) acc[q] += vdot(*reinterpret_cast<const V*>(rp + ch * VEC), uv[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            T v = acc[q];
+            for (int off = G >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            const int row = base + q * ngrp;
+            if (g == 0 && row < n) out[row] = v;
+        }
+    }
+}
+
+// outvec[0..ld) += sum_p c[p] * M[rows[p]]   (pcrpp.cpp:536, :622).  fp64 accumulation.
+// wbuf: LDS, (BLOCK/64) * ld doubles.  Ends with a barrier; outvec valid for all threads.
+template <typename T, typename CT, int BLOCK>
+__device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const int32_t* rows, const CT* c, int n,
+                                                  double* outvec, double* wbuf, const Geo& geo) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VEC = VecOf<T>::N;
+    const int G = geo.G, g = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = BLOCK / G;
+    double acc[PCR_KMAX][VEC];
+#pragma unroll
+    for (int k = 0; k < PCR_KMAX; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[k][e] = 0.0;
+    for (int base = grp; base < n; base += ngrp * 4) {
+        V rv[4][PCR_KMAX];
+        double cc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = base + q * ngrp;
+            cc[q] = 0.0;
+            if (row < n) {
+                cc[q] = (double)c[row];
+                const T* rp = M + (size_t)rows[row] * geo.ld;
+#pragma unroll
+                for (int k = 0; k < PCR_KMAX; ++k) {
+                    const int ch = g + k * G;
+                    if (ch < geo.nchunk) rv[q][k] = *reinterpret_cast<const V*>(rp + ch * VEC);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = base + q * ngrp;
+            if (row < n) {
+#pragma unroll
+                for (int k = 0; k < PCR_KMAX; ++k) {
+                    const int ch = g + k * G;
+                    if (ch < geo.nchunk) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[k][e] += cc[q] * (double)velem(rv[q][k], e);
+                    }
+                }
+            }
+        }
+    }
+    // groups of one wave -> one vector
+    for (int off = G; off < PCR_WAVE; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < PCR_KMAX; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[k][e] += __shfl_xor(acc[k][e], off);
+    }
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane < G) {
+#pragma unroll
+        for (int k = 0; k < PCR_KMAX; ++k) {
+            const int ch = g + k * G;
+            if (ch < geo.nchunk) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) wbuf[wid * geo.ld + ch * VEC + e] = acc[k][e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < geo.ld; t += BLOCK) {
+        double s = 0.0;
+        for (int w = 0; w < BLOCK / PCR_WAVE; ++w) s += wbuf[w * geo.ld + t];
+        outvec[t] += s;
+    }
+    __syncthreads();
+}
+
+// carve typed arrays out of a byte region (16-byte aligned pieces)
+struct Carver {
+    char* p;
+    __device__ explicit Carver(char* base) : p(base) {}
+    template <class X> __device__ X* take(size_t n) {
+        X* r = reinterpret_cast<X*>(p);
+        p += (n * sizeof(X) + 15) & ~(size_t)15;
+        return r;
+    }
+};
+static inline size_t carve_bytes(size_t n, size_t elt) { return (n * elt + 15) & ~(size_t)15; }
+
+__device__ __forceinline__ int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+// ---------------------------------------------------------------------------------------
+// k_prepare: m = V_I u_i, sort by (level, m), per-user loss.   One workgroup per user.
+//   BIG = false: n-sized arrays in LDS;  BIG = true: in a per-workgroup global scratch slice.
+// ---------------------------------------------------------------------------------------
+template <typename T, bool BIG> struct LiSel { typedef uint32_t type; };
+template <typename T> struct LiSel<T, true> { typedef uint64_t type; };
+
+template <typename T>
+static inline size_t prepare_bytes(int cap_pad, int rs_cap, int li_bytes) {
+    return carve_bytes(cap_pad, sizeof(T)) + carve_bytes(cap_pad, li_bytes) + carve_bytes(cap_pad + 1, 8) + carve_bytes(rs_cap, 4);
+}
+
+template <typename T, int BLOCK, bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
+                                                   const T* __restrict__ U, const T* __restrict__ Vm, T* __restrict__ m_csr,
+                                                   int cap_pad, int rs_cap, char* scratch, size_t stride, int strict) {
+    typedef typename LiSel<T, BIG>::type LI;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Carver small(smem);
+    T* vecT = small.take<T>(geo.ld);
+    double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
+    Carver big(BIG ? scratch + (size_t)blockIdx.x * stride : small.p);
+    T* key = big.take<T>(cap_pad);
+    LI* li = big.take<LI>(cap_pad);
+    double* Sx = big.take<double>(cap_pad + 1);
+    int* rs = big.take<int>(rs_cap);
+    const int tid = threadIdx.x;
+
+    for (int ui = blockIdx.x; ui < nusers; ui += gridDim.x) {
+        const int u = users[ui];
+        const int64_t s0 = S.uptr[u];
+        const int n = (int)(S.uptr[u + 1] - s0);
+        const int nlev = (int)(S.runofs[u + 1] - S.runofs[u]) - 1;
+        if (n == 0) {
+            if (tid == 0) S.objp[u] = 0.0;
+            continue;
+        }
+        for (int t = tid; t < geo.ld; t += BLOCK) vecT[t] = U[(size_t)u * geo.ld + t];
+        for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
+        __syncthreads();
+        block_sddmm<T, BLOCK>(Vm, vecT, S.item + s0, n, key, geo);
+        const int npad = next_pow2(n);
+        for (int p = tid; p < npad; p += BLOCK) {
+            if (p < n) li[p] = LiOps<LI>::pack(S.lvl[s0 + p], (unsigned)p);
+            else { li[p] = LiOps<LI>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
+        }
+        __syncthreads();
+        if (m_csr) for (int p = tid; p < n; p += BLOCK) m_csr[s0 + p] = key[p];
+        bitonic_sort<T, LI, BLOCK>(key, li, npad);
+        for (int p = tid; p < n; p += BLOCK) {
+            const LI x = li[p];
+            const unsigned idx = LiOps<LI>::idx(x);
+            S.ms[s0 + p] = key[p];
+            S.slvl[s0 + p] = (uint16_t)LiOps<LI>::lev(x);
+            S.sitem[s0 + p] = S.item[s0 + idx];
+            S.scsc[s0 + p] = S.cpos[s0 + idx];
+        }
+        double loss = block_objective<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, Sx, red, strict);
+        if (tid == 0) S.objp[u] = loss;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_vsweep: per-user sweep coefficients for the V side, scattered to CSC order.
+//   HV = false: gradient (x = m, shift 1)           pcrpp.cpp:214-238
+//   HV = true : Hessian-vector (x = u_i . a_item)   pcrpp.cpp:266-271, 294-318
+// ---------------------------------------------------------------------------------------
+template <typename T>
+static inline size_t vsweep_bytes(int cap, int rs_cap) {
+    return carve_bytes(cap, sizeof(T)) * 2 + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
+}
+
+template <typename T, int BLOCK, bool BIG, bool HV>
+__global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
+                                                  const T* __restrict__ U, const T* __restrict__ A, T* __restrict__ c_csc,
+                                                  int cap, int rs_cap, char* scratch, size_t stride, int strict) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Carver small(smem);
+    T* vecT = small.take<T>(geo.ld);
+    double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
+    Carver big(BIG ? scratch + (size_t)blockIdx.x * stride : small.p);
+    T* ms = big.take<T>(cap);
+    T* x = big.take<T>(cap);
+    double* Sx = big.take<double>(cap + 1);
+    int* rs = big.take<int>(rs_cap);
+    const int tid = threadIdx.x;
+
+    for (int ui = blockIdx.x; ui < nusers; ui += gridDim.x) {
+        const int u = users[ui];
+        const int64_t s0 = S.uptr[u];
+        const int n = (int)(S.uptr[u + 1] - s0);
+        const int nlev = (int)(S.runofs[u + 1] - S.runofs[u]) - 1;
+        if (n == 0) continue;
+        for (int p = tid; p < n; p += BLOCK) ms[p] = S.ms[s0 + p];
+        for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
+        const T* xs = ms;
+        if (HV) {
+            for (int t = tid; t < geo.ld; t += BLOCK) vecT[t] = U[(size_t)u * geo.ld + t];
+            __syncthreads();
+            block_sddmm<T, BLOCK>(A, vecT, S.sitem + s0, n, x, geo);
+            xs = x;
+        }
+        __syncthreads();
+        block_excl_scan<BLOCK>([&](int i) { return (double)xs[i]; }, Sx, n, red);
+        for (int p = tid; p < n; p += BLOCK) {
+            const int lev = S.slvl[s0 + p];
+            const double c = sweep_coeff<T>(ms, Sx, rs, nlev, lev, ms[p], (double)xs[p], HV ? 0.0 : 1.0, strict);
+            c_csc[S.scsc[s0 + p]] = (T)c;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_spmm: out[j,:] += sum_{z in column j} c[z] * U[cuser[z],:]   (pcrpp.cpp:240-243, 323-327)
+// Item-major (CSC) gather instead of the reference's per-scalar atomics: the CSC nnz range is
+// cut into equal chunks (load balance independent of item popularity); a group of G lanes walks
+// one chunk, keeps the running row in fp64 registers and issues ONE row of float atomics per
+// item boundary (out is pre-initialised with lambda * base by the caller).
+// ---------------------------------------------------------------------------------------
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const int32_t* __restrict__ cuser,
+                                                const int32_t* __restrict__ crow, int64_t nnz, const T* __restrict__ U,
+                                                T* __restrict__ out, Geo geo, int chunk) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VEC = VecOf<T>::N;
+    const int G = geo.G, g = threadIdx.x & (G - 1);
+    const int64_t gid = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / G;
+    const int64_t z0 = gid * chunk;
+    if (z0 >= nnz) return;
+    const int64_t z1 = (z0 + chunk < nnz) ? z0 + chunk : nnz;
+    double acc[PCR_KMAX][VEC];
+#pragma unroll
+    for (int k = 0; k < PCR_KMAX; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[k][e] = 0.0;
+    int cur = crow[z0];
+    auto flush = [&](int j) {
+#pragma unroll
+        for (int k = 0; k < PCR_KMAX; ++k) {
+            const int ch = g + k * G;
+            if (ch < geo.nchunk) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    atomicAdd(out + (size_t)j * geo.ld + ch * VEC + e, (T)acc[k][e]);
+                    acc[k][e] = 0.0;
+                }
+            }
+        }
+    };
+    for (int64_t zb = z0; zb < z1; zb += G) {
+        const int64_t zi = zb + g;
+        T cr = (T)0;
+        int ur = 0, jr = 0;
+        if (zi < z1) { cr = c[zi]; ur = cuser[zi]; jr = crow[zi]; }
+        const int cnt = (int)((z1 - zb < G) ? (z1 - zb) : G);
+        for (int q = 0; q < cnt; q += 4) {
+            V rv[4][PCR_KMAX];
+            double cc[4];
+            int jj[4];
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                if (q + e4 < cnt) {
+                    cc[e4] = (double)__shfl(cr, q + e4, G);
+                    const int uu = __shfl(ur, q + e4, G);
+                    jj[e4] = __shfl(jr, q + e4, G);
+                    const T* rp = U + (size_t)uu * geo.ld;
+#pragma unroll
+                    for (int k = 0; k < PCR_KMAX; ++k) {
+                        const int ch = g + k * G;
+                        if (ch < geo.nchunk) rv[e4][k] = *reinterpret_cast<const V*>(rp + ch * VEC);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                if (q + e4 < cnt) {
+                    if (jj[e4] != cur) { flush(cur); cur = jj[e4]; }
+#pragma unroll
+                    for (int k = 0; k < PCR_KMAX; ++k) {
+                        const int ch = g + k * G;
+                        if (ch < geo.nchunk) {
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) acc[k][e] += cc[e4] * (double)velem(rv[e4][k], e);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    flush(cur);
+}
+
+// ---------------------------------------------------------------------------------------
+// elementwise / CG kernels (solve_delta_new, pcrpp.cpp:335-358).  Scalars stay on the device;
+// every reduction is two-stage and deterministic (per-block partials, then each consumer
+// block re-reduces the short partial array in a fixed order).
+// ---------------------------------------------------------------------------------------
+struct CGState {
+    double g2, err, pHp, rp, alpha, rr2, rHp, beta;
+    int done, iters;
+};
+
+#define PCR_EW_BLOCK 256
+
+template <typename T>
+__global__ void k_scale(T* __restrict__ out, const T* __restrict__ in, double s, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (T)(s * (double)in[i]);
+}
+
+template <typename T>
+__global__ void k_axpy_out(T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b, double s, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // out = a + s*b (mat_substract_vec, util.cpp:395)
+    if (i < n) out[i] = (T)((double)a[i] + s * (double)b[i]);
+}
+
+__device__ __forceinline__ void reduce_partials2(const double* part, int nblk, double* a, double* b, double* red) {
+    // every block reduces the (short) partial array identically: deterministic
+    double x = 0.0, y = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += PCR_EW_BLOCK) { x += part[2 * i]; y += part[2 * i + 1]; }
+    x = block_sum<PCR_EW_BLOCK>(x, red);
+    y = block_sum<PCR_EW_BLOCK>(y, red);
+    *a = x; *b = y;
+}
+
+// sum of squares of a (and optionally dot(a, b)) -> part[blk][2]
+template <typename T>
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_dots(const T* __restrict__ a, const T* __restrict__ b, int64_t n,
+                                                        int per_block, double* __restrict__ part) {
+    __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
+    const int64_t lo = (int64_t)blockIdx.x * per_block;
+    const int64_t hi = (lo + per_block < n) ? lo + per_block : n;
+    double x = 0.0, y = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) {
+        const double av = (double)a[i];
+        x += av * av;
+        if (b) y += av * (double)b[i];
+    }
+    x = block_sum<PCR_EW_BLOCK>(x, red);
+    y = block_sum<PCR_EW_BLOCK>(y, red);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = x; part[2 * blockIdx.x + 1] = y; }
+}
+
+// out[0] = sum part[2i], out[1] = sum part[2i+1]
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_fin2(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+    __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
+    double a, b;
+    reduce_partials2(part, nblk, &a, &b, red);
+    if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
+}
+
+// plain sum of a double array, two-stage
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_sum_stage1(const double* __restrict__ in, int64_t n, int per_block,
+                                                              double* __restrict__ part) {
+    __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
+    const int64_t lo = (int64_t)blockIdx.x * per_block;
+    const int64_t hi = (lo + per_block < n) ? lo + per_block : n;
+    double x = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) x += in[i];
+    x = block_sum<PCR_EW_BLOCK>(x, red);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = x; part[2 * blockIdx.x + 1] = 0.0; }
+}
+
+// CG start: delta = 0, rr = -g, p = g, Hp = hp_scale * p; partial |g|^2
+template <typename T>
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_init(const T* __restrict__ g, T* __restrict__ delta, T* __restrict__ rr,
+                                                           T* __restrict__ p, T* __restrict__ Hp, double hp_scale, int64_t n,
+                                                           int per_block, double* __restrict__ part) {
+    __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
+    const int64_t lo = (int64_t)blockIdx.x * per_block;
+    const int64_t hi = (lo + per_block < n) ? lo + per_block : n;
+    double x = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) {
+        const T gv = g[i];
+        delta[i] = (T)0;
+        rr[i] = -gv;
+        p[i] = gv;
+        Hp[i] = (T)(hp_scale * (double)gv);
+        x += (double)gv * (double)gv;
+    }
+    x = block_sum<PCR_EW_BLOCK>(x, red);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = x; part[2 * blockIdx.x + 1] = 0.0; }
+}
+
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_init_fin(const double* __restrict__ part, int nblk, CGState* st) {
+    __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
+    double a, b;
+    reduce_partials2(part, nblk, &a, &b, red);
+    if (threadIdx.x == 0) {
+        st->g2 = a;
+        st->err = sqrt(a) * 0.01;            // pcrpp.cpp:340
+        st->done = 0;
+        st->iters = 0;
+    }
+}
+
+// A: partials of p.Hp and rr.p   (Hp += lam_add * p first: the lambda*p term when it was not
+// folded into the SpMM's initial value, i.e. after a multi-GPU all-reduce)
+template <typename T>
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_a(const T* __restrict__ p, T* __restrict__ Hp, const T* __restrict__ rr,
+                                                        double lam_add, int64_t n, int per_block, double* __restrict__ part,
+                                                        CGState* st) {
+    __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
+    if (st->done) return;
+    const int64_t lo = (int64_t)blockIdx.x * per_block;
+    const int64_t hi = (lo + per_block < n) ? lo + per_block : n;
+    double x = 0.0, y = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) {
+        const double pv = (double)p[i];
+        double h = (double)Hp[i];
+        if (lam_add != 0.0) { h += lam_add * pv; Hp[i] = (T)h; h = (double)Hp[i]; }
+        x += pv * h;
+        y += (double)rr[i] * pv;
+    }
+    x = block_sum<PCR_EW_BLOCK>(x, red);
+    y = block_sum<PCR_EW_BLOCK>(y, red);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = x; part[2 * blockIdx.x + 1] = y; }
+}
+
+// B: alpha = -(rr.p)/(p.Hp); delta += alpha p; rr += alpha Hp; partials of rr.rr and rr.Hp
+template <typename T>
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_b(const T* __restrict__ p, const T* __restrict__ Hp, T* __restrict__ rr,
+                                                        T* __restrict__ delta, int64_t n, int per_block, int nblk,
+                                                        const double* __restrict__ partA, double* __restrict__ partB, CGState* st) {
+    __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
+    if (st->done) return;
+    double pHp, rp;
+    reduce_partials2(partA, nblk, &pHp, &rp, red);
+    const double alpha = -1.0 * rp / pHp;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->pHp = pHp; st->rp = rp; st->alpha = alpha; st->iters += 1; }
+    const int64_t lo = (int64_t)blockIdx.x * per_block;
+    const int64_t hi = (lo + per_block < n) ? lo + per_block : n;
+    double x = 0.0, y = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) {
+        const double pv = (double)p[i], hv = (double)Hp[i];
+        delta[i] = (T)((double)delta[i] + pv * alpha);
+        const T rn = (T)((double)rr[i] + hv * alpha);
+        rr[i] = rn;
+        x += (double)rn * (double)rn;
+        y += (double)rn * hv;
+    }
+    __syncthreads();
+    x = block_sum<PCR_EW_BLOCK>(x, red);
+    y = block_sum<PCR_EW_BLOCK>(y, red);
+    if (threadIdx.x == 0) { partB[2 * blockIdx.x] = x; partB[2 * blockIdx.x + 1] = y; }
+}
+
+// C: stop if |rr| < err, else beta = (rr.Hp)/(p.Hp); p = -rr + beta p; Hp = hp_scale * p (the
+// SpMM's initial value for the next product)
+template <typename T>
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_c(T* __restrict__ p, T* __restrict__ Hp, const T* __restrict__ rr,
+                                                        double hp_scale, int64_t n, int per_block, int nblk,
+                                                        const double* __restrict__ partB, CGState* st) {
+    __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
+    if (st->done) return;
+    double rr2, rHp;
+    reduce_partials2(partB, nblk, &rr2, &rHp, red);
+    const bool conv = sqrt(rr2) < st->err;                 // pcrpp.cpp:350
+    const double beta = rHp / st->pHp;
+    const int64_t lo = (int64_t)blockIdx.x * per_block;
+    const int64_t hi = (lo + per_block < n) ? lo + per_block : n;
+    if (!conv) {
+        for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) {
+            const T pn = (T)((double)rr[i] * -1.0 + (double)p[i] * beta);
+            p[i] = pn;
+            Hp[i] = (T)(hp_scale * (double)pn);
+        }
+    }
+    // st->done is only written after every block has passed its `if (st->done)` read above:
+    // the flag is consumed by LATER kernels on the stream, never by blocks of this launch.
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { st->rr2 = rr2; st->rHp = rHp; st->beta = beta; }
+}
+// sets done after k_cg_c so that no block of k_cg_c can observe a half-updated flag
+__global__ void k_cg_mark(CGState* st) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && !st->done && sqrt(st->rr2) < st->err) st->done = 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// k_ustep: the whole per-user Newton step of update_u_new (pcrpp.cpp:779-815) in one
+// workgroup: gradient (obtain_g_u_new :493), objective (:542), <=10 CG iterations with
+// obtain_Hs_new (:576, :628), <=20 line-search evaluations each with a fresh sort (:794-813).
+// r-vectors live in LDS as fp64; the user's sorted item block lives in LDS (or scratch).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+static inline size_t ustep_big_bytes(int cap_pad, int rs_cap, int li_bytes) {
+    return carve_bytes(cap_pad, sizeof(T)) * 2 + carve_bytes(cap_pad, 2) + carve_bytes(cap_pad, 4) + carve_bytes(cap_pad, li_bytes) +
+           carve_bytes(cap_pad + 1, 8) + carve_bytes(rs_cap, 4);
+}
+static inline size_t ustep_small_bytes(int ld, int block, size_t elt) {
+    return carve_bytes(ld, elt) + carve_bytes(block / PCR_WAVE + 1, 8) + 7 * carve_bytes(ld, 8) +
+           carve_bytes((size_t)(block / PCR_WAVE) * ld, 8);
+}
+
+template <typename T, int BLOCK, bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
+                                                 T* __restrict__ U, const T* __restrict__ Vm, double lambda, double stepsize0,
+                                                 int strict, int solver1, int cap_pad, int rs_cap, char* scratch, size_t stride,
+                                                 unsigned long long* counters) {
+    typedef typename LiSel<T, BIG>::type LI;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Carver small(smem);
+    T* vecT = small.take<T>(geo.ld);
+    double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
+    double* uvec = small.take<double>(geo.ld);
+    double* gvec = small.take<double>(geo.ld);
+    double* delta = small.take<double>(geo.ld);
+    double* rr = small.take<double>(geo.ld);
+    double* pv = small.take<double>(geo.ld);
+    double* Hp = small.take<double>(geo.ld);
+    double* unew = small.take<double>(geo.ld);
+    double* wbuf = small.take<double>((size_t)(BLOCK / PCR_WAVE) * geo.ld);
+    Carver big(BIG ? scratch + (size_t)blockIdx.x * stride : small.p);
+    T* ms0 = big.take<T>(cap_pad);
+    T* key = big.take<T>(cap_pad);
+    uint16_t* lv0 = big.take<uint16_t>(cap_pad);
+    int32_t* itm = big.take<int32_t>(cap_pad);
+    LI* li = big.take<LI>(cap_pad);
+    double* Sx = big.take<double>(cap_pad + 1);
+    int* rs = big.take<int>(rs_cap);
+    const int tid = threadIdx.x;
+    const int ld = geo.ld;
+
+    for (int ui = blockIdx.x; ui < nusers; ui += gridDim.x) {
+        const int u = users[ui];
+        const int64_t s0 = S.uptr[u];
+        const int n = (int)(S.uptr[u + 1] - s0);
+        const int nlev = (int)(S.runofs[u + 1] - S.runofs[u]) - 1;
+        for (int t = tid; t < ld; t += BLOCK) uvec[t] = (double)U[(size_t)u * ld + t];
+        for (int p = tid; p < n; p += BLOCK) { ms0[p] = S.ms[s0 + p]; lv0[p] = S.slvl[s0 + p]; itm[p] = S.sitem[s0 + p]; }
+        for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
+        __syncthreads();
+        // ---- gradient coefficients, obtain_g_u_new (pcrpp.cpp:506-535)
+        block_excl_scan<BLOCK>([&](int i) { return (double)ms0[i]; }, Sx, n, red);
+        for (int p = tid; p < n; p += BLOCK)
+            key[p] = (T)sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)ms0[p], 1.0, strict);
+        for (int t = tid; t < ld; t += BLOCK) gvec[t] = (n == 0) ? 0.0 : uvec[t] * lambda;   // :495-498
+        __syncthreads();
+        block_gather_axpy<T, T, BLOCK>(Vm, itm, key, n, gvec, wbuf, geo);
+        double un2 = 0.0, gn2 = 0.0;
+        for (int t = tid; t < ld; t += BLOCK) { un2 += uvec[t] * uvec[t]; gn2 += gvec[t] * gvec[t]; }
+        un2 = block_sum<BLOCK>(un2, red);
+        gn2 = block_sum<BLOCK>(gn2, red);
+        // ---- prev_obj, objective_u_new (pcrpp.cpp:542-573)
+        const double prev_obj = lambda / 2.0 * un2 +
+            block_objective<T, BLOCK>(ms0, [&](int p) { return (int)lv0[p]; }, rs, nlev, n, Sx, red, strict);
+        double obj_new = prev_obj;
+        int n_cg = 0, n_ls = 0;
+        // pcrpp.cpp:787-790; PrimalCR additionally keeps u when no comparable pair exists
+        // (cc == 0, pcr.cpp:552)
+        const bool skip = (gn2 < 0.0001) || (solver1 && nlev <= 1);
+        for (int t = tid; t < ld; t += BLOCK) unew[t] = uvec[t];
+        __syncthreads();
+        if (!skip) {
+            // ---- CG, solve_delta_u_new (pcrpp.cpp:628-647)
+            for (int t = tid; t < ld; t += BLOCK) { delta[t] = 0.0; rr[t] = gvec[t] * -1.0; pv[t] = gvec[t]; }
+            const double err = sqrt(gn2) * 0.01;
+            __syncthreads();
+            for (int k = 1; k <= 10; ++k) {
+                for (int t = tid; t < ld; t += BLOCK) { vecT[t] = (T)pv[t]; Hp[t] = pv[t] * lambda; }
+                __syncthreads();
+                block_sddmm<T, BLOCK>(Vm, vecT, itm, n, key, geo);             // b = V_I p  (:592-594)
+                __syncthreads();
+                block_excl_scan<BLOCK>([&](int i) { return (double)key[i]; }, Sx, n, red);
+                for (int p = tid; p < n; p += BLOCK)
+                    key[p] = (T)sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)key[p], 0.0, strict);
+                __syncthreads();
+                block_gather_axpy<T, T, BLOCK>(Vm, itm, key, n, Hp, wbuf, geo);
+                ++n_cg;
+                double a = 0.0, b = 0.0;
+                for (int t = tid; t < ld; t += BLOCK) { a += pv[t] * Hp[t]; b += rr[t] * pv[t]; }
+                const double pHp = block_sum<BLOCK>(a, red);
+                const double rp = block_sum<BLOCK>(b, red);
+                const double alpha = -1.0 * rp / pHp;
+                a = 0.0; b = 0.0;
+                for (int t = tid; t < ld; t += BLOCK) {
+                    delta[t] = delta[t] + pv[t] * alpha;
+                    const double rn = rr[t] + Hp[t] * alpha;
+                    rr[t] = rn;
+                    a += rn * rn;
+                    b += rn * Hp[t];
+                }
+                const double rr2 = block_sum<BLOCK>(a, red);
+                const double rHp = block_sum<BLOCK>(b, red);
+                if (sqrt(rr2) < err) break;
+                const double beta = rHp / pHp;
+                for (int t = tid; t < ld; t += BLOCK) pv[t] = rr[t] * -1.0 + pv[t] * beta;
+                __syncthreads();
+            }
+            __syncthreads();
+            // ---- line search (pcrpp.cpp:794-813): fresh scores, fresh sort, objective
+            double step = stepsize0;
+            const int npad = next_pow2(n);
+            for (int it = 0; it < 20; ++it) {
+                double nn = 0.0;
+                for (int t = tid; t < ld; t += BLOCK) {
+                    const double v = uvec[t] + delta[t] * -step;
+                    unew[t] = v;
+                    vecT[t] = (T)v;
+                    nn += (double)(T)v * (double)(T)v;
+                }
+                nn = block_sum<BLOCK>(nn, red);
+                __syncthreads();
+                block_sddmm<T, BLOCK>(Vm, vecT, itm, n, key, geo);             // compute_mm_old (:728-744)
+                for (int p = tid; p < npad; p += BLOCK) {
+                    if (p < n) li[p] = LiOps<LI>::pack(lv0[p], (unsigned)p);
+                    else { li[p] = LiOps<LI>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
+                }
+                __syncthreads();
+                bitonic_sort<T, LI, BLOCK>(key, li, npad);                      // update_infor_ui (:684-726)
+                obj_new = lambda / 2.0 * nn +
+                    block_objective<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, Sx, red, strict);
+                ++n_ls;
+                if (obj_new < prev_obj) break;
+                step /= 2.0;
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < ld; t += BLOCK) U[(size_t)u * ld + t] = (T)unew[t];
+        if (tid == 0) {
+            S.objp[u] = obj_new;
+            if (n_cg) atomicAdd(counters + 0, (unsigned long long)n_cg);
+            if (n_ls) atomicAdd(counters + 1, (unsigned long long)n_ls);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_eval: compute_pairwise_error_ndcg (util.cpp:434-542), one workgroup per user.
+//   pairwise error: #{ordered (a,b): s_a >= s_b && v_a < v_b} / (n(n-1)/2)   (util.cpp:467-483;
+//     the reference's two tests on unordered pairs are this one test on ordered pairs; score
+//     ties count as errors, all pairs are in the denominator)
+//   NDCG@min(k,n): top-k by score (util.cpp:494-495; ties: lower index first -- the reference's
+//     std::sort leaves tie order unspecified), gains 2^v - 1 and the ideal DCG are static per
+//     data set and precomputed on the host with the reference's own pow()/log2() arithmetic.
+// out4[u] = {err ratio, has pairs, ndcg, has ratings}
+// ---------------------------------------------------------------------------------------
+template <typename T>
+static inline size_t eval_bytes(int cap) { return carve_bytes(cap, sizeof(T)) + carve_bytes(cap, 8); }
+
+template <typename T, int BLOCK, bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_eval(const int64_t* __restrict__ uptr, const int32_t* __restrict__ item,
+                                                const double* __restrict__ val, const double* __restrict__ gain,
+                                                const double* __restrict__ idcg, const double* __restrict__ disc, int ndcg_k,
+                                                const int32_t* __restrict__ users, int nusers, const T* __restrict__ U,
+                                                const T* __restrict__ Vm, Geo geo, double* __restrict__ out4, int cap,
+                                                char* scratch, size_t stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Carver small(smem);
+    T* vecT = small.take<T>(geo.ld);
+    double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
+    T* wmax = small.take<T>(BLOCK / PCR_WAVE + 1);
+    int* widx = small.take<int>(BLOCK / PCR_WAVE + 1);
+    Carver big(BIG ? scratch + (size_t)blockIdx.x * stride : small.p);
+    T* sc = big.take<T>(cap);
+    double* vv = big.take<double>(cap);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+    for (int ui = blockIdx.x; ui < nusers; ui += gridDim.x) {
+        const int u = users[ui];
+        const int64_t s0 = uptr[u];
+        const int n = (int)(uptr[u + 1] - s0);
+        if (n == 0) {
+            if (tid == 0) { out4[4 * (size_t)u] = 0.0; out4[4 * (size_t)u + 1] = 0.0; out4[4 * (size_t)u + 2] = 0.0; out4[4 * (size_t)u + 3] = 0.0; }
+            continue;
+        }
+        for (int t = tid; t < geo.ld; t += BLOCK) vecT[t] = U[(size_t)u * geo.ld + t];
+        for (int p = tid; p < n; p += BLOCK) vv[p] = val[s0 + p];
+        __syncthreads();
+        block_sddmm<T, BLOCK>(Vm, vecT, item + s0, n, sc, geo);
+        __syncthreads();
+        // ---- pairwise error
+        unsigned long long bad = 0;
+        for (int a = tid; a < n; a += BLOCK) {
+            const T sa = sc[a];
+            const double va = vv[a];
+            unsigned long long cnt = 0;
+            for (int b = 0; b < n; ++b) cnt += (sa >= sc[b] && va < vv[b]) ? 1u : 0u;
+            bad += cnt;
+        }
+        const double badsum = block_sum<BLOCK>((double)bad, red);       // exact below 2^53
+        const double npairs = 0.5 * (double)n * (double)(n - 1);
+        // ---- top-k by score, k = min(ndcg_k, n); ties -> lower index
+        const int nowk = n < ndcg_k ? n : ndcg_k;
+        double dcg = 0.0;
+        for (int k = 0; k < nowk; ++k) {
+            T best = (T)0; int bi = -1;
+            for (int p = tid; p < n; p += BLOCK) {
+                const T s = sc[p];
+                if (!(s != s) && (bi < 0 || s > best)) { best = s; bi = p; }       // strided scan keeps the lowest index per lane
+            }
+            // NaN scores (never expected) are treated as -inf: pick them last by index
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const T ob = __shfl_xor(best, off);
+                const int oi = __shfl_xor(bi, off);
+                if (oi >= 0 && (bi < 0 || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
+            }
+            if (BLOCK > PCR_WAVE) {
+                __syncthreads();
+                if (lane == 0) { wmax[wid] = best; widx[wid] = bi; }
+                __syncthreads();
+                best = wmax[0]; bi = widx[0];
+                for (int w = 1; w < BLOCK / PCR_WAVE; ++w) {
+                    const T ob = wmax[w]; const int oi = widx[w];
+                    if (oi >= 0 && (bi < 0 || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
+                }
+            }
+            if (bi < 0) {                                   // only NaN scores left: take the lowest unused index
+                for (int p = 0; p < n; ++p) if (sc[p] != sc[p]) { bi = p; break; }
+            }
+            dcg += gain[s0 + bi] * disc[k];
+            __syncthreads();
+            if (tid == 0) sc[bi] = -INFINITY;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            out4[4 * (size_t)u] = (npairs > 0.0) ? badsum / npairs : 0.0;
+            out4[4 * (size_t)u + 1] = (npairs > 0.0) ? 1.0 : 0.0;
+            out4[4 * (size_t)u + 2] = dcg / idcg[u];
+            out4[4 * (size_t)u + 3] = 1.0;
+        }
+        __syncthreads();
+    }
+}
+
+// sums of the 4 interleaved columns of out4 -> part[blk][4]; then k_fin4
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_sum4_stage1(const double* __restrict__ in, int64_t n, int per_block,
+                                                               double* __restrict__ part) {
+    __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
+    const int64_t lo = (int64_t)blockIdx.x * per_block;
+    const int64_t hi = (lo + per_block < n) ? lo + per_block : n;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK)
+        for (int c = 0; c < 4; ++c) a[c] += in[4 * i + c];
+    for (int c = 0; c < 4; ++c) {
+        const double s = block_sum<PCR_EW_BLOCK>(a[c], red);
+        if (threadIdx.x == 0) part[4 * blockIdx.x + c] = s;
+    }
+}
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_fin4(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+    __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
+    for (int c = 0; c < 4; ++c) {
+        double x = 0.0;
+        for (int i = threadIdx.x; i < nblk; i += PCR_EW_BLOCK) x += part[4 * i + c];
+        x = block_sum<PCR_EW_BLOCK>(x, red);
+        if (threadIdx.x == 0) out[c] = x;
+    }
+}
+
+// pmf-predict.cpp:58-63: pred[z] = U[user[z]] . V[item[z]]; G lanes per pair
+template <typename T>
+__global__ __launch_bounds__(256) void k_predict(const T* __restrict__ U, const T* __restrict__ Vm, const int32_t* __restrict__ user,
+                                                 const int32_t* __restrict__ item, int64_t n, Geo geo, double* __restrict__ pred) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VEC = VecOf<T>::N;
+    const int G = geo.G, g = threadIdx.x & (G - 1);
+    const int64_t z = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    if (z >= n) return;
+    const T* up = U + (size_t)user[z] * geo.ld;
+    const T* vp = Vm + (size_t)item[z] * geo.ld;
+    T acc = (T)0;
+#pragma unroll
+    for (int k = 0; k < PCR_KMAX; ++k) {
+        const int ch = g + k * G;
+        if (ch < geo.nchunk) acc += vdot(*reinterpret_cast<const V*>(up + ch * VEC), *reinterpret_cast<const V*>(vp + ch * VEC));
+    }
+    for (int off = G >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (g == 0) pred[z] = (double)acc;
+}

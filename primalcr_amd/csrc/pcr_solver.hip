@@ -1,0 +1,880 @@
+// pcr_solver.hip -- device solver behind the C ABI of include/primalcr.h.
+//
+// Host orchestration of the PrimalCR++ / PrimalCR training loop (pcrpp.cpp:841-901,
+// pcr.cpp:616-704) over the HIP kernels of pcr_kernels.h.  One process per GPU; users are
+// sharded across ranks (contiguous, nnz-balanced), V and the CG vectors are replicated, the
+// V-gradient and every Hessian-vector product are combined with an RCCL all-reduce.
+//
+// There is NO CPU compute path in this file: every [device] entry point fails with
+// PCR_ERR_DEVICE when HIP is unusable.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "pcr_host.h"
+#include "pcr_kernels.h"
+
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            pcr_set_error(std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
+            return PCR_ERR_DEVICE;                                                             \
+        }                                                                                      \
+    } while (0)
+#define NCCLCHK(expr)                                                                          \
+    do {                                                                                       \
+        ncclResult_t e_ = (expr);                                                              \
+        if (e_ != ncclSuccess) {                                                               \
+            pcr_set_error(std::string(#expr) + ": " + ncclGetErrorString(e_));                 \
+            return PCR_ERR_COMM;                                                               \
+        }                                                                                      \
+    } while (0)
+#define RC(expr) do { int rc_ = (expr); if (rc_ != PCR_OK) return rc_; } while (0)
+
+static inline int host_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// device buffer with RAII
+template <typename X>
+struct DBuf {
+    X* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        free();
+        n = count;
+        if (count == 0) count = 1;
+        HIPCHK(hipMalloc((void**)&p, count * sizeof(X)));
+        return PCR_OK;
+    }
+    int upload(const std::vector<X>& h, hipStream_t st) {
+        RC(alloc(h.size()));
+        (void)st;
+        if (!h.empty()) HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(X), hipMemcpyHostToDevice));
+        return PCR_OK;
+    }
+    void free() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    ~DBuf() { free(); }
+};
+
+// users of one CSR grouped by length class; each class has its own workgroup size
+struct Bin {
+    int block = 64;
+    bool big = false;
+    int cap = 0;         // longest user in the bin
+    int max_lev = 0;
+    std::vector<int32_t> users;
+    DBuf<int32_t> d_users;
+};
+static const int BIN_LIMIT[3] = {256, 1024, 4096};
+static const int BIN_BLOCK[4] = {64, 256, 1024, 1024};
+
+struct ProfSlot {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double ms = 0.0;
+    int64_t n = 0;
+};
+
+struct pcr_solver {
+    virtual ~pcr_solver() {}
+    virtual int set_factors(const double* U, const double* V) = 0;
+    virtual int get_factors(double* U, double* V) = 0;
+    virtual int comp_m(double* m_out) = 0;
+    virtual int objective(double* obj) = 0;
+    virtual int obtain_g(double* g) = 0;
+    virtual int compute_Ha(const double* a, double* Ha) = 0;
+    virtual int solve_delta(const double* g, double* delta, int* iters) = 0;
+    virtual int update_V(double* now_obj, int* info) = 0;
+    virtual int update_U(double* now_obj, int64_t* info) = 0;
+    virtual int evaluate(int which, int ndcg_k, double* err, double* ndcg) = 0;
+    virtual int train(pcr_log_fn log, void* ctx, pcr_iter_stats* hist) = 0;
+    virtual int comm_init(const void* id) = 0;
+    virtual int sync() = 0;
+    int64_t first_user = 0, n_users = 0, nnz_local = 0;
+    bool prof_on = false;
+    std::map<std::string, ProfSlot> prof;
+    virtual int prof_resolve() = 0;
+};
+
+template <typename T>
+struct Solver final : pcr_solver {
+    pcr_params prm;
+    int rank = 0, nranks = 1;
+    int64_t d1 = 0, d2 = 0, tnnz_file = 0;
+    Geo geo;
+    hipStream_t st = nullptr;
+    ncclComm_t comm = nullptr;
+    int ncu = 256;
+
+    // ---- training shard
+    Shard<T> sh;
+    DBuf<int64_t> d_uptr, d_runofs;
+    DBuf<int32_t> d_item, d_cpos, d_runstart, d_sitem, d_scsc, d_cuser, d_crow;
+    DBuf<uint16_t> d_lvl, d_slvl;
+    DBuf<T> d_ms, d_c, d_mcsr;
+    DBuf<double> d_objp;
+    std::vector<Bin> bins;
+    // ---- eval data (0 = train, 1 = test)
+    struct EvalSet {
+        int64_t nnz = 0;
+        DBuf<int64_t> uptr;
+        DBuf<int32_t> item;
+        DBuf<double> val, gain, idcg, disc;
+        std::vector<Bin> bins;
+        std::vector<int64_t> h_uptr;
+        std::vector<double> h_val;
+        int idcg_k = -1;
+    } ev[2];
+    DBuf<double> d_out4;
+    // ---- factors and CG vectors (d2 x ld, nu x ld)
+    DBuf<T> d_U, d_V, d_Vnew, d_g, d_delta, d_rr, d_p, d_Hp;
+    DBuf<CGState> d_cg;
+    DBuf<double> d_partA, d_partB, d_scal;       // reduction partials, small scalar block
+    DBuf<unsigned long long> d_counters;
+    DBuf<char> d_scratch;
+    size_t scratch_stride = 0;
+    int scratch_blocks = 0;
+    double* h_scal = nullptr;                     // pinned
+    CGState* h_cg = nullptr;                      // pinned
+    unsigned long long* h_counters = nullptr;     // pinned
+    int ew_blocks = 1, ew_per_block = 1;          // elementwise decomposition over d2*ld
+    bool have_sorted = false;
+    double unorm2 = 0.0;                          // all-rank |U|^2 of the current U
+    bool unorm_valid = false;
+    double last_loss = 0.0;                       // all-rank loss of the last prepare
+
+    ~Solver() override {
+        if (st) (void)hipStreamSynchronize(st);
+        prof_resolve();
+        if (comm) ncclCommDestroy(comm);
+        if (h_scal) (void)hipHostFree(h_scal);
+        if (h_cg) (void)hipHostFree(h_cg);
+        if (h_counters) (void)hipHostFree(h_counters);
+        if (st) (void)hipStreamDestroy(st);
+    }
+
+    // ------------------------------------------------------------------------------ profiling
+    struct ProfScope {
+        Solver* s; ProfSlot* slot = nullptr; hipEvent_t a = nullptr, b = nullptr;
+        ProfScope(Solver* s_, const char* name) : s(s_) {
+            if (!s->prof_on) return;
+            slot = &s->prof[name];
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, s->st);
+        }
+        ~ProfScope() {
+            if (!slot) return;
+            (void)hipEventRecord(b, s->st);
+            slot->pending.emplace_back(a, b);
+            slot->n += 1;
+        }
+    };
+    int prof_resolve() override {
+        for (auto& kv : prof) {
+            for (auto& pr : kv.second.pending) {
+                float ms = 0.f;
+                (void)hipEventSynchronize(pr.second);
+                if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) kv.second.ms += ms;
+                (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+            }
+            kv.second.pending.clear();
+        }
+        return PCR_OK;
+    }
+
+    // ------------------------------------------------------------------------------ setup
+    static void make_bins(const std::vector<int64_t>& uptr, int64_t nu, const std::vector<int64_t>* runofs, std::vector<Bin>& out) {
+        out.clear();
+        out.resize(4);
+        for (int b = 0; b < 4; ++b) { out[b].block = BIN_BLOCK[b]; out[b].big = (b == 3); }
+        for (int64_t u = 0; u < nu; ++u) {
+            int64_t len = uptr[u + 1] - uptr[u];
+            int b = len <= BIN_LIMIT[0] ? 0 : len <= BIN_LIMIT[1] ? 1 : len <= BIN_LIMIT[2] ? 2 : 3;
+            out[b].users.push_back((int32_t)u);
+            out[b].cap = std::max<int>(out[b].cap, (int)len);
+            if (runofs) out[b].max_lev = std::max<int>(out[b].max_lev, (int)((*runofs)[u + 1] - (*runofs)[u]) - 1);
+        }
+        for (auto& bn : out)   // longest first: the tail of the launch is made of short users
+            std::stable_sort(bn.users.begin(), bn.users.end(), [&](int32_t a, int32_t b2) {
+                return (uptr[a + 1] - uptr[a]) > (uptr[b2 + 1] - uptr[b2]);
+            });
+    }
+
+    int init(const pcr_dataset* ds, const pcr_params* p, int rank_, int nranks_) {
+        prm = *p; rank = rank_; nranks = nranks_;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+            pcr_set_error("no HIP device available: libprimalcr has no CPU fallback for the training path");
+            return PCR_ERR_DEVICE;
+        }
+        if (prm.device < 0 || prm.device >= ndev) { pcr_set_error("device ordinal out of range"); return PCR_ERR_ARG; }
+        HIPCHK(hipSetDevice(prm.device));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, prm.device));
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+
+        const PcrCsr& X = ds->train;
+        d1 = X.d1; d2 = X.d2; tnnz_file = ds->tnnz_file;
+        if (prm.k < 1) { pcr_set_error("rank k must be >= 1"); return PCR_ERR_ARG; }
+        if (d2 >= (int64_t)1 << 31 || d1 >= (int64_t)1 << 31) { pcr_set_error("d1/d2 must fit in int32"); return PCR_ERR_UNSUPPORTED; }
+        geo.r = prm.k;
+        geo.ld = (prm.k + 3) & ~3;
+        geo.nchunk = geo.ld / VecOf<T>::N;
+        geo.G = std::min(64, host_pow2(geo.nchunk));
+        if (geo.nchunk > 64 * PCR_KMAX) { pcr_set_error("rank too large for this build (ld/VEC > 256)"); return PCR_ERR_UNSUPPORTED; }
+
+        std::vector<int64_t> bounds(nranks + 1);
+        RC(pcr_partition_users(X.index.data(), d1, nranks, bounds.data()));
+        first_user = bounds[rank];
+        n_users = bounds[rank + 1] - bounds[rank];
+        const int64_t z0 = X.index[first_user], z1 = X.index[first_user + n_users];
+        nnz_local = z1 - z0;
+        if (nnz_local >= ((int64_t)1 << 31) - 1) { pcr_set_error("more than 2^31 ratings on one GPU"); return PCR_ERR_UNSUPPORTED; }
+        const int64_t nu = n_users;
+
+        // ---- host-side shard preparation
+        std::vector<int64_t> uptr(nu + 1);
+        for (int64_t u = 0; u <= nu; ++u) uptr[u] = X.index[first_user + u] - z0;
+        std::vector<int32_t> item(X.item.begin() + z0, X.item.begin() + z1);
+        PcrLevels lv;
+        std::string err;
+        int rc = pcr_build_levels(X, first_user, first_user + nu, prm.solver_type, lv, err);
+        if (rc != PCR_OK) { pcr_set_error(err); return rc; }
+        // CSC of the shard: entries of one item ordered by local user
+        std::vector<int64_t> cptr(d2 + 1, 0);
+        for (int64_t z = 0; z < nnz_local; ++z) cptr[item[z] + 1]++;
+        for (int64_t j = 0; j < d2; ++j) cptr[j + 1] += cptr[j];
+        std::vector<int32_t> cpos(nnz_local), cuser(nnz_local), crow(nnz_local);
+        {
+            std::vector<int64_t> cur(cptr.begin(), cptr.end() - 1);
+            for (int64_t u = 0; u < nu; ++u)
+                for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) {
+                    int64_t q = cur[item[z]]++;
+                    cpos[z] = (int32_t)q; cuser[q] = (int32_t)u; crow[q] = item[z];
+                }
+        }
+        make_bins(uptr, nu, &lv.run_ofs, bins);
+        for (auto& b : bins) RC(b.d_users.upload(b.users, st));
+
+        RC(d_uptr.upload(uptr, st)); RC(d_item.upload(item, st)); RC(d_lvl.upload(lv.level, st));
+        RC(d_cpos.upload(cpos, st)); RC(d_cuser.upload(cuser, st)); RC(d_crow.upload(crow, st));
+        RC(d_runofs.upload(lv.run_ofs, st)); RC(d_runstart.upload(lv.run_start, st));
+        RC(d_ms.alloc(nnz_local)); RC(d_sitem.alloc(nnz_local)); RC(d_slvl.alloc(nnz_local)); RC(d_scsc.alloc(nnz_local));
+        RC(d_c.alloc(nnz_local)); RC(d_objp.alloc(nu));
+        sh.nu = nu; sh.nnz = nnz_local; sh.d2 = (int)d2;
+        sh.uptr = d_uptr.p; sh.item = d_item.p; sh.lvl = d_lvl.p; sh.cpos = d_cpos.p;
+        sh.runofs = d_runofs.p; sh.runstart = d_runstart.p;
+        sh.ms = d_ms.p; sh.sitem = d_sitem.p; sh.slvl = d_slvl.p; sh.scsc = d_scsc.p; sh.objp = d_objp.p;
+
+        // ---- eval sets (train shard, test shard)
+        for (int w = 0; w < 2; ++w) {
+            const PcrCsr& E = w == 0 ? ds->train : ds->test;
+            EvalSet& es = ev[w];
+            const int64_t a = E.index[first_user], b = E.index[first_user + nu];
+            es.nnz = b - a;
+            es.h_uptr.resize(nu + 1);
+            for (int64_t u = 0; u <= nu; ++u) es.h_uptr[u] = E.index[first_user + u] - a;
+            es.h_val.assign(E.val.begin() + a, E.val.begin() + b);
+            if (w == 1) {
+                std::vector<int32_t> it(E.item.begin() + a, E.item.begin() + b);
+                RC(es.uptr.upload(es.h_uptr, st)); RC(es.item.upload(it, st));
+            }
+            RC(es.val.upload(es.h_val, st));
+            std::vector<double> gain(es.nnz);
+            for (int64_t z = 0; z < es.nnz; ++z) gain[z] = pow(2.0, es.h_val[z]) - 1.0;     // util.cpp:519
+            RC(es.gain.upload(gain, st));
+            RC(es.idcg.alloc(nu));
+            make_bins(es.h_uptr, nu, nullptr, es.bins);
+            for (auto& bn : es.bins) RC(bn.d_users.upload(bn.users, st));
+        }
+        RC(d_out4.alloc(4 * (size_t)std::max<int64_t>(nu, 1)));
+
+        // ---- factors / vectors
+        const size_t nV = (size_t)d2 * geo.ld, nU = (size_t)nu * geo.ld;
+        RC(d_U.alloc(nU)); RC(d_V.alloc(nV)); RC(d_Vnew.alloc(nV)); RC(d_g.alloc(nV)); RC(d_delta.alloc(nV));
+        RC(d_rr.alloc(nV)); RC(d_p.alloc(nV)); RC(d_Hp.alloc(nV));
+        HIPCHK(hipMemsetAsync(d_U.p, 0, std::max<size_t>(nU, 1) * sizeof(T), st));
+        HIPCHK(hipMemsetAsync(d_V.p, 0, std::max<size_t>(nV, 1) * sizeof(T), st));
+        RC(d_cg.alloc(1));
+        ew_blocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, cdiv((int64_t)nV, 4096)));
+        ew_per_block = cdiv((int64_t)nV, ew_blocks);
+        RC(d_partA.alloc(4 * 2048)); RC(d_partB.alloc(4 * 2048)); RC(d_scal.alloc(64));
+        RC(d_counters.alloc(4));
+        HIPCHK(hipHostMalloc((void**)&h_scal, 64 * sizeof(double)));
+        HIPCHK(hipHostMalloc((void**)&h_cg, sizeof(CGState)));
+        HIPCHK(hipHostMalloc((void**)&h_counters, 4 * sizeof(unsigned long long)));
+
+        // ---- scratch for users that do not fit in LDS
+        size_t need = 0;
+        if (!bins[3].users.empty()) {
+            int cp = host_pow2(bins[3].cap), rsc = bins[3].max_lev + 2;
+            need = std::max(need, prepare_bytes<T>(cp, rsc, 8));   // LI is 8 bytes in scratch
+            need = std::max(need, vsweep_bytes<T>(bins[3].cap, rsc));
+            need = std::max(need, ustep_big_bytes<T>(cp, rsc, 8));
+        }
+        for (int w = 0; w < 2; ++w)
+            if (!ev[w].bins[3].users.empty()) need = std::max(need, eval_bytes<T>(ev[w].bins[3].cap));
+        if (need) {
+            scratch_stride = (need + 255) & ~(size_t)255;
+            size_t nbig = bins[3].users.size();
+            for (int w = 0; w < 2; ++w) nbig = std::max(nbig, ev[w].bins[3].users.size());
+            scratch_blocks = (int)std::min<size_t>(nbig, (size_t)ncu * 2);
+            RC(d_scratch.alloc(scratch_stride * (size_t)scratch_blocks));
+        }
+        RC(set_lds_limits());
+        HIPCHK(hipStreamSynchronize(st));
+        return PCR_OK;
+    }
+
+    // opt in to > 64 KiB dynamic LDS for the 1024-thread instantiations
+    int set_lds_limits() {
+        const int lim = 160 * 1024;
+        HIPCHK(hipFuncSetAttribute((const void*)k_prepare<T, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 1024, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_eval<T, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        return PCR_OK;
+    }
+
+    size_t small_common(int block) const { return carve_bytes(geo.ld, sizeof(T)) + carve_bytes(block / PCR_WAVE + 1, 8); }
+    int strict() const { return prm.solver_type == PCR_SOLVER_PCR ? 1 : 0; }
+
+    // ------------------------------------------------------------------------------ launches
+    // m = V_I u, sort, per-user loss -> objp.  Vm = matrix the scores are taken against.
+    int launch_prepare(const T* Vm, T* m_csr) {
+        ProfScope ps(this, "prepare");
+        for (auto& b : bins) {
+            if (b.users.empty()) continue;
+            const int nus = (int)b.users.size();
+            const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
+            const size_t bigb = prepare_bytes<T>(cap_pad, rsc, b.big ? 8 : 4);
+            const size_t lds = small_common(b.block) + (b.big ? 0 : bigb);
+            const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
+#define LP(BL, BG) hipLaunchKernelGGL((k_prepare<T, BL, BG>), dim3(grid), dim3(BL), lds, st, sh, geo, b.d_users.p, nus, d_U.p, Vm, m_csr, cap_pad, rsc, d_scratch.p, scratch_stride, strict())
+            if (b.big) LP(1024, true);
+            else if (b.block == 64) LP(64, false);
+            else if (b.block == 256) LP(256, false);
+            else LP(1024, false);
+#undef LP
+        }
+        HIPCHK(hipGetLastError());
+        have_sorted = true;
+        return PCR_OK;
+    }
+
+    int launch_vsweep(bool hv, const T* A) {
+        ProfScope ps(this, hv ? "vhv" : "vgrad");
+        for (auto& b : bins) {
+            if (b.users.empty()) continue;
+            const int nus = (int)b.users.size();
+            const int rsc = b.max_lev + 2;
+            const size_t bigb = vsweep_bytes<T>(b.cap, rsc);
+            const size_t lds = small_common(b.block) + (b.big ? 0 : bigb);
+            const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
+#define LV(BL, BG, HV) hipLaunchKernelGGL((k_vsweep<T, BL, BG, HV>), dim3(grid), dim3(BL), lds, st, sh, geo, b.d_users.p, nus, d_U.p, A, d_c.p, b.cap, rsc, d_scratch.p, scratch_stride, strict())
+            if (hv) {
+                if (b.big) LV(1024, true, true);
+                else if (b.block == 64) LV(64, false, true);
+                else if (b.block == 256) LV(256, false, true);
+                else LV(1024, false, true);
+            } else {
+                if (b.big) LV(1024, true, false);
+                else if (b.block == 64) LV(64, false, false);
+                else if (b.block == 256) LV(256, false, false);
+                else LV(1024, false, false);
+            }
+#undef LV
+        }
+        HIPCHK(hipGetLastError());
+        return PCR_OK;
+    }
+
+    // out += sum c * U-rows (item-major); out must hold its initial value already
+    int launch_spmm(T* out) {
+        ProfScope ps(this, "spmm");
+        if (nnz_local > 0) {
+            const int chunk = 128;
+            const int64_t ngroups = (nnz_local + chunk - 1) / chunk;
+            const int gpb = 256 / geo.G;
+            const int grid = cdiv(ngroups, gpb);
+            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(grid), dim3(256), 0, st, d_c.p, d_cuser.p, d_crow.p, nnz_local, d_U.p, out, geo, chunk);
+            HIPCHK(hipGetLastError());
+        }
+        return PCR_OK;
+    }
+
+    int allreduce_T(T* buf, size_t count) {
+        if (nranks == 1) return PCR_OK;
+        if (!comm) { pcr_set_error("nranks > 1 but pcr_solver_comm_init was not called"); return PCR_ERR_STATE; }
+        ProfScope ps(this, "allreduce");
+        NCCLCHK(ncclAllReduce(buf, buf, count, sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, comm, st));
+        return PCR_OK;
+    }
+    int allreduce_f64(double* buf, size_t count) {
+        if (nranks == 1) return PCR_OK;
+        if (!comm) { pcr_set_error("nranks > 1 but pcr_solver_comm_init was not called"); return PCR_ERR_STATE; }
+        ProfScope ps(this, "allreduce");
+        NCCLCHK(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, st));
+        return PCR_OK;
+    }
+
+    // deterministic sum of a double array into d_scal[slot] (two-stage)
+    int reduce_sum(const double* in, int64_t n, int slot) {
+        const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, cdiv(n, 2048)));
+        const int per = cdiv(std::max<int64_t>(n, 1), nb);
+        hipLaunchKernelGGL(k_sum_stage1, dim3(nb), dim3(PCR_EW_BLOCK), 0, st, in, n, per, d_partA.p);
+        hipLaunchKernelGGL(k_fin2, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + slot);
+        HIPCHK(hipGetLastError());
+        return PCR_OK;
+    }
+    // |a|^2 of a T array into d_scal[slot] (slot+1 receives dot(a,b) or 0)
+    int norm2(const T* a, int64_t n, int slot) {
+        const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, cdiv(n, 4096)));
+        const int per = cdiv(std::max<int64_t>(n, 1), nb);
+        hipLaunchKernelGGL((k_dots<T>), dim3(nb), dim3(PCR_EW_BLOCK), 0, st, a, (const T*)nullptr, n, per, d_partB.p);
+        hipLaunchKernelGGL(k_fin2, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partB.p, nb, d_scal.p + slot);
+        HIPCHK(hipGetLastError());
+        return PCR_OK;
+    }
+    int fetch_scal(int count) {
+        HIPCHK(hipMemcpyAsync(h_scal, d_scal.p, count * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return PCR_OK;
+    }
+
+    // all-rank |U|^2 (cached until U changes)
+    int ensure_unorm() {
+        if (unorm_valid) return PCR_OK;
+        RC(norm2(d_U.p, (int64_t)n_users * geo.ld, 8));
+        RC(allreduce_f64(d_scal.p + 8, 1));
+        HIPCHK(hipMemcpyAsync(h_scal + 8, d_scal.p + 8, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        unorm2 = h_scal[8];
+        unorm_valid = true;
+        return PCR_OK;
+    }
+
+    // loss (all ranks) of the last prepare + lambda/2 (|U|^2 + |Vm|^2)   (pcrpp.cpp:410)
+    int full_objective(const T* Vm, double* obj) {
+        RC(ensure_unorm());
+        RC(reduce_sum(d_objp.p, n_users, 0));
+        RC(allreduce_f64(d_scal.p, 1));
+        RC(norm2(Vm, (int64_t)d2 * geo.ld, 2));
+        RC(fetch_scal(4));
+        last_loss = h_scal[0];
+        *obj = h_scal[0] + prm.lambda * (unorm2 + h_scal[2]) / 2.0;
+        return PCR_OK;
+    }
+
+    // ------------------------------------------------------------------------------ host <-> device
+    int upload_mat(const double* H, int64_t rows, T* D) {
+        std::vector<T> tmp((size_t)rows * geo.ld, (T)0);
+        for (int64_t i = 0; i < rows; ++i)
+            for (int j = 0; j < geo.r; ++j) tmp[(size_t)i * geo.ld + j] = (T)H[i * geo.r + j];
+        if (!tmp.empty()) HIPCHK(hipMemcpyAsync(D, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return PCR_OK;
+    }
+    int download_mat(const T* D, int64_t rows, double* H) {
+        std::vector<T> tmp((size_t)rows * geo.ld);
+        if (!tmp.empty()) HIPCHK(hipMemcpyAsync(tmp.data(), D, tmp.size() * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int64_t i = 0; i < rows; ++i)
+            for (int j = 0; j < geo.r; ++j) H[i * geo.r + j] = (double)tmp[(size_t)i * geo.ld + j];
+        return PCR_OK;
+    }
+
+    int set_factors(const double* U, const double* V) override {
+        if (U) { RC(upload_mat(U + first_user * geo.r, n_users, d_U.p)); unorm_valid = false; }
+        if (V) RC(upload_mat(V, d2, d_V.p));
+        have_sorted = false;
+        return PCR_OK;
+    }
+    int get_factors(double* U, double* V) override {
+        if (U) RC(download_mat(d_U.p, n_users, U + first_user * geo.r));
+        if (V) RC(download_mat(d_V.p, d2, V));
+        return PCR_OK;
+    }
+
+    // ------------------------------------------------------------------------------ per-function ABI
+    int comp_m(double* m_out) override {
+        T* mc = nullptr;
+        if (m_out) { if (d_mcsr.n < (size_t)nnz_local) RC(d_mcsr.alloc(nnz_local)); mc = d_mcsr.p; }
+        RC(launch_prepare(d_V.p, mc));
+        if (m_out) {
+            std::vector<T> tmp(nnz_local);
+            if (nnz_local) HIPCHK(hipMemcpyAsync(tmp.data(), mc, nnz_local * sizeof(T), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (int64_t z = 0; z < nnz_local; ++z) m_out[z] = (double)tmp[z];
+        }
+        return PCR_OK;
+    }
+    int need_sorted() const {
+        if (!have_sorted) { pcr_set_error("call pcr_comp_m first (no sorted state for the current factors)"); return PCR_ERR_STATE; }
+        return PCR_OK;
+    }
+    int objective(double* obj) override {
+        RC(need_sorted());
+        return full_objective(d_V.p, obj);
+    }
+
+    // g = lambda V + sum_i sum_j c_ij u_i   (pcrpp.cpp:140-249) into d_g
+    int device_gradient() {
+        RC(launch_vsweep(false, nullptr));
+        {
+            ProfScope ps(this, "cg");
+            const int64_t n = (int64_t)d2 * geo.ld;
+            hipLaunchKernelGGL((k_scale<T>), dim3(cdiv(n, 256)), dim3(256), 0, st, d_g.p, d_V.p, rank == 0 ? prm.lambda : 0.0, n);
+        }
+        RC(launch_spmm(d_g.p));
+        RC(allreduce_T(d_g.p, (size_t)d2 * geo.ld));
+        return PCR_OK;
+    }
+    int obtain_g(double* g) override {
+        RC(need_sorted());
+        RC(device_gradient());
+        return download_mat(d_g.p, d2, g);
+    }
+    // Hp = lambda p + sum c(b) u, with Hp pre-initialised to hp_scale * p by the caller
+    int device_hv(const T* pvec, T* out) {
+        RC(launch_vsweep(true, pvec));
+        RC(launch_spmm(out));
+        RC(allreduce_T(out, (size_t)d2 * geo.ld));
+        return PCR_OK;
+    }
+    int compute_Ha(const double* a, double* Ha) override {
+        RC(need_sorted());
+        RC(upload_mat(a, d2, d_p.p));
+        const int64_t n = (int64_t)d2 * geo.ld;
+        hipLaunchKernelGGL((k_scale<T>), dim3(cdiv(n, 256)), dim3(256), 0, st, d_Hp.p, d_p.p, rank == 0 ? prm.lambda : 0.0, n);
+        RC(device_hv(d_p.p, d_Hp.p));
+        return download_mat(d_Hp.p, d2, Ha);
+    }
+
+    // CG on H delta = g with g in d_g (pcrpp.cpp:335-358); result in d_delta
+    int device_cg(int* iters) {
+        const int64_t n = (int64_t)d2 * geo.ld;
+        const double hp_scale = rank == 0 ? prm.lambda : 0.0;
+        {
+            ProfScope ps(this, "cg");
+            hipLaunchKernelGGL((k_cg_init<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_g.p, d_delta.p, d_rr.p, d_p.p, d_Hp.p, hp_scale, n, ew_per_block, d_partA.p);
+            hipLaunchKernelGGL(k_cg_init_fin, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, ew_blocks, d_cg.p);
+        }
+        int done = 0;
+        for (int k = 1; k <= 10 && !done; ++k) {
+            RC(device_hv(d_p.p, d_Hp.p));
+            {
+                ProfScope ps(this, "cg");
+                hipLaunchKernelGGL((k_cg_a<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, 0.0, n, ew_per_block, d_partA.p, d_cg.p);
+                hipLaunchKernelGGL((k_cg_b<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, d_delta.p, n, ew_per_block, ew_blocks, d_partA.p, d_partB.p, d_cg.p);
+                hipLaunchKernelGGL((k_cg_c<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, hp_scale, n, ew_per_block, ew_blocks, d_partB.p, d_cg.p);
+                hipLaunchKernelGGL(k_cg_mark, dim3(1), dim3(64), 0, st, d_cg.p);
+            }
+            HIPCHK(hipGetLastError());
+            // the stop test needs the residual on the host; every rank sees the same replicated value
+            HIPCHK(hipMemcpyAsync(h_cg, d_cg.p, sizeof(CGState), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            done = h_cg->done;
+        }
+        if (iters) *iters = h_cg->iters;
+        return PCR_OK;
+    }
+    int solve_delta(const double* g, double* delta, int* iters) override {
+        RC(need_sorted());
+        RC(upload_mat(g, d2, d_g.p));
+        RC(device_cg(iters));
+        return download_mat(d_delta.p, d2, delta);
+    }
+
+    // pcrpp.cpp:415-444
+    int update_V(double* now_obj, int* info) override {
+        int cg_iters = 0, tries = 0, accepted = 0;
+        RC(launch_prepare(d_V.p, nullptr));                        // comp_m_new (:417)
+        double prev_obj = 0.0;
+        RC(full_objective(d_V.p, &prev_obj));                      // objective_new(m, U, V) (:425); m is the same
+        RC(device_gradient());                                     // obtain_g_new (:418)
+        RC(device_cg(&cg_iters));                                  // solve_delta_new (:422)
+        double step = prm.stepsize, obj = prev_obj;
+        const int64_t n = (int64_t)d2 * geo.ld;
+        for (int it = 0; it < 20; ++it) {                          // :427-441
+            hipLaunchKernelGGL((k_axpy_out<T>), dim3(cdiv(n, 256)), dim3(256), 0, st, d_Vnew.p, d_V.p, d_delta.p, -step, n);
+            RC(launch_prepare(d_Vnew.p, nullptr));
+            RC(full_objective(d_Vnew.p, &obj));
+            ++tries;
+            if (obj < prev_obj) {
+                std::swap(d_V.p, d_Vnew.p);
+                accepted = 1;
+                break;
+            }
+            step /= 2.0;
+        }
+        // the sorted state now belongs to the LAST TRIED V_new, accepted or not (:430-431, :443)
+        if (now_obj) *now_obj = obj;
+        if (info) { info[0] = cg_iters; info[1] = tries; info[2] = accepted; }
+        return PCR_OK;
+    }
+
+    int launch_ustep() {
+        ProfScope ps(this, "ustep");
+        HIPCHK(hipMemsetAsync(d_counters.p, 0, 4 * sizeof(unsigned long long), st));
+        for (auto& b : bins) {
+            if (b.users.empty()) continue;
+            const int nus = (int)b.users.size();
+            const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
+            const size_t lds = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + (b.big ? 0 : ustep_big_bytes<T>(cap_pad, rsc, 4));
+            const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
+#define LU(BL, BG) hipLaunchKernelGGL((k_ustep<T, BL, BG>), dim3(grid), dim3(BL), lds, st, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, strict(), strict(), cap_pad, rsc, d_scratch.p, scratch_stride, d_counters.p)
+            if (b.big) LU(1024, true);
+            else if (b.block == 64) LU(64, false);
+            else if (b.block == 256) LU(256, false);
+            else LU(1024, false);
+#undef LU
+        }
+        HIPCHK(hipGetLastError());
+        return PCR_OK;
+    }
+
+    // pcrpp.cpp:818-838
+    int update_U(double* now_obj, int64_t* info) override {
+        RC(need_sorted());
+        RC(launch_ustep());
+        unorm_valid = false;
+        have_sorted = false;                                        // U changed: m is stale
+        RC(reduce_sum(d_objp.p, n_users, 0));                       // sum_i obj_u(i)
+        RC(allreduce_f64(d_scal.p, 1));
+        RC(norm2(d_V.p, (int64_t)d2 * geo.ld, 2));
+        HIPCHK(hipMemcpyAsync(h_counters, d_counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        RC(fetch_scal(4));
+        if (now_obj) *now_obj = h_scal[0] + prm.lambda / 2.0 * h_scal[2];   // :835
+        if (info) { info[0] = (int64_t)h_counters[0]; info[1] = (int64_t)h_counters[1]; }
+        return PCR_OK;
+    }
+
+    // util.cpp:434-542
+    int evaluate(int which, int ndcg_k, double* err, double* ndcg) override {
+        if (which != 0 && which != 1) { pcr_set_error("which must be 0 (train) or 1 (test)"); return PCR_ERR_ARG; }
+        if (ndcg_k < 1) { pcr_set_error("ndcg_k must be >= 1"); return PCR_ERR_ARG; }
+        EvalSet& es = ev[which];
+        if (es.idcg_k != ndcg_k) {
+            // ideal DCG and discounts with the reference's arithmetic (util.cpp:505-524)
+            std::vector<double> idcg(n_users), disc(ndcg_k), tmp;
+            for (int k = 1; k <= ndcg_k; ++k) disc[k - 1] = 1.0 / log2((double)k + 1.0);
+            for (int64_t u = 0; u < n_users; ++u) {
+                tmp.assign(es.h_val.begin() + es.h_uptr[u], es.h_val.begin() + es.h_uptr[u + 1]);
+                std::sort(tmp.begin(), tmp.end(), [](double a, double b) { return a > b; });
+                int64_t nowk = std::min<int64_t>(ndcg_k, (int64_t)tmp.size());
+                double m = 0.0;
+                for (int64_t k = 1; k <= nowk; ++k) m += (pow(2.0, tmp[k - 1]) - 1.0) / log2((double)k + 1.0);
+                idcg[u] = m;
+            }
+            if (n_users) HIPCHK(hipMemcpy(es.idcg.p, idcg.data(), n_users * sizeof(double), hipMemcpyHostToDevice));
+            RC(es.disc.upload(disc, st));
+            HIPCHK(hipStreamSynchronize(st));
+            es.idcg_k = ndcg_k;
+        }
+        // dcg uses gain/discount products in the reference's order: gain / log2(k+1); keep the division exact
+        {
+            ProfScope ps(this, "eval");
+            const int64_t* up = which == 0 ? d_uptr.p : es.uptr.p;
+            const int32_t* it = which == 0 ? d_item.p : es.item.p;
+            for (auto& b : es.bins) {
+                if (b.users.empty()) continue;
+                const int nus = (int)b.users.size();
+                const size_t smallb = small_common(b.block) + carve_bytes(b.block / PCR_WAVE + 1, sizeof(T)) + carve_bytes(b.block / PCR_WAVE + 1, 4);
+                const size_t lds = smallb + (b.big ? 0 : eval_bytes<T>(b.cap));
+                const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
+#define LE(BL, BG) hipLaunchKernelGGL((k_eval<T, BL, BG>), dim3(grid), dim3(BL), lds, st, up, it, es.val.p, es.gain.p, es.idcg.p, es.disc.p, ndcg_k, b.d_users.p, nus, d_U.p, d_V.p, geo, d_out4.p, b.cap, d_scratch.p, scratch_stride)
+                if (b.big) LE(1024, true);
+                else if (b.block == 64) LE(64, false);
+                else if (b.block == 256) LE(256, false);
+                else LE(1024, false);
+#undef LE
+            }
+            const int nb = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv(n_users, 2048)));
+            const int per = cdiv(std::max<int64_t>(n_users, 1), nb);
+            hipLaunchKernelGGL(k_sum4_stage1, dim3(nb), dim3(PCR_EW_BLOCK), 0, st, d_out4.p, n_users, per, d_partA.p);
+            hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + 16);
+            HIPCHK(hipGetLastError());
+        }
+        RC(allreduce_f64(d_scal.p + 16, 4));
+        HIPCHK(hipMemcpyAsync(h_scal + 16, d_scal.p + 16, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (err) *err = h_scal[16] / h_scal[17];                    // util.cpp:537
+        if (ndcg) *ndcg = h_scal[18] / h_scal[19];
+        return PCR_OK;
+    }
+
+    // pcrpp.cpp:841-901 / pcr.cpp:616-704
+    int train(pcr_log_fn log, void* ctx, pcr_iter_stats* hist) override {
+        char line[512];
+        auto emit = [&](const char* s) { if (rank != 0) return; if (log) log(ctx, s); else { fputs(s, stdout); fputc('\n', stdout); fflush(stdout); } };
+        const bool pp = prm.solver_type == PCR_SOLVER_PCRPP;
+        snprintf(line, sizeof line, "running %s ndcg_k is %d", pp ? "PrimalCR++" : "PrimalCR", prm.ndcg_k); emit(line);
+        snprintf(line, sizeof line, "using %d threads. ", prm.threads); emit(line);
+        pcr_iter_stats cur;
+        memset(&cur, 0, sizeof cur);
+        auto do_eval = [&](pcr_iter_stats& rec) -> int {
+            if (!prm.do_predict) return PCR_OK;
+            RC(evaluate(0, prm.ndcg_k, &rec.train_err, &rec.train_ndcg));
+            snprintf(line, sizeof line, "(Training) pairwise error is %g and ndcg is %g", rec.train_err, rec.train_ndcg); emit(line);
+            if (tnnz_file != 0) {
+                RC(evaluate(1, prm.ndcg_k, &rec.test_err, &rec.test_ndcg));
+                snprintf(line, sizeof line, "(Testing) pairwise error is %g and ndcg is %g", rec.test_err, rec.test_ndcg); emit(line);
+            }
+            return PCR_OK;
+        };
+        double now_obj = 0.0;
+        RC(launch_prepare(d_V.p, nullptr));                          // :857
+        RC(full_objective(d_V.p, &now_obj));                         // :858
+        cur.obj = now_obj;
+        snprintf(line, sizeof line, "Iter 0 time 0 obj %g", now_obj); emit(line);
+        RC(do_eval(cur));
+        if (hist) hist[0] = cur;
+        double total_time = 0.0;
+        for (int iter = 1; iter <= prm.maxiter; ++iter) {
+            auto t0 = std::chrono::steady_clock::now();
+            int vinfo[3] = {0, 0, 0};
+            int64_t uinfo[2] = {0, 0};
+            RC(update_V(&now_obj, vinfo));                           // :877
+            RC(update_U(&now_obj, uinfo));                           // :878
+            HIPCHK(hipStreamSynchronize(st));
+            total_time += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            memset(&cur, 0, sizeof cur);
+            cur.obj = now_obj; cur.seconds = total_time;
+            cur.cg_v = vinfo[0]; cur.ls_v = vinfo[1]; cur.cg_u = uinfo[0]; cur.ls_u = uinfo[1];
+            snprintf(line, sizeof line, "Iter %d time %g obj %g", iter, total_time, now_obj); emit(line);
+            RC(do_eval(cur));
+            if (hist) hist[iter] = cur;
+        }
+        return PCR_OK;
+    }
+
+    int comm_init(const void* id) override {
+        if (nranks == 1) return PCR_OK;
+        ncclUniqueId uid;
+        memcpy(&uid, id, sizeof uid);
+        HIPCHK(hipSetDevice(prm.device));
+        NCCLCHK(ncclCommInitRank(&comm, nranks, uid, rank));
+        return PCR_OK;
+    }
+    int sync() override { HIPCHK(hipStreamSynchronize(st)); return PCR_OK; }
+};
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int pcr_solver_create(const pcr_dataset* ds, const pcr_params* p, int rank, int nranks, pcr_solver** out) {
+    if (!ds || !p || !out || nranks < 1 || rank < 0 || rank >= nranks) { pcr_set_error("pcr_solver_create: bad argument"); return PCR_ERR_ARG; }
+    if (p->solver_type != PCR_SOLVER_PCR && p->solver_type != PCR_SOLVER_PCRPP) {
+        pcr_set_error("wrong solver type (" + std::to_string(p->solver_type) + "): 1 = PrimalCR, 2 = PrimalCR++");
+        return PCR_ERR_ARG;
+    }
+    int rc;
+    if (p->precision == PCR_F64) {
+        auto* s = new Solver<double>();
+        rc = s->init(ds, p, rank, nranks);
+        if (rc != PCR_OK) { delete s; return rc; }
+        *out = s;
+    } else if (p->precision == PCR_F32) {
+        auto* s = new Solver<float>();
+        rc = s->init(ds, p, rank, nranks);
+        if (rc != PCR_OK) { delete s; return rc; }
+        *out = s;
+    } else {
+        pcr_set_error("precision must be PCR_F32 or PCR_F64");
+        return PCR_ERR_ARG;
+    }
+    return PCR_OK;
+}
+void pcr_solver_destroy(pcr_solver* s) { delete s; }
+
+int pcr_comm_unique_id(void* id128) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    if (!id128) { pcr_set_error("null id"); return PCR_ERR_ARG; }
+    ncclUniqueId id;
+    NCCLCHK(ncclGetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return PCR_OK;
+}
+#define S_OR_ARG if (!s) { pcr_set_error("null solver"); return PCR_ERR_ARG; }
+int pcr_solver_comm_init(pcr_solver* s, const void* id128) { S_OR_ARG; return s->comm_init(id128); }
+int pcr_solver_shard(const pcr_solver* s, int64_t* first_user, int64_t* n_users, int64_t* nnz_local) {
+    S_OR_ARG;
+    if (first_user) *first_user = s->first_user;
+    if (n_users) *n_users = s->n_users;
+    if (nnz_local) *nnz_local = s->nnz_local;
+    return PCR_OK;
+}
+int pcr_solver_set_factors(pcr_solver* s, const double* U, const double* V) { S_OR_ARG; return s->set_factors(U, V); }
+int pcr_solver_get_factors(pcr_solver* s, double* U, double* V) { S_OR_ARG; return s->get_factors(U, V); }
+int pcr_comp_m(pcr_solver* s, double* m_out) { S_OR_ARG; return s->comp_m(m_out); }
+int pcr_objective(pcr_solver* s, double* obj) { S_OR_ARG; return s->objective(obj); }
+int pcr_obtain_g(pcr_solver* s, double* g) { S_OR_ARG; return s->obtain_g(g); }
+int pcr_compute_Ha(pcr_solver* s, const double* a, double* Ha) { S_OR_ARG; return s->compute_Ha(a, Ha); }
+int pcr_solve_delta(pcr_solver* s, const double* g, double* delta, int* it) { S_OR_ARG; return s->solve_delta(g, delta, it); }
+int pcr_update_V(pcr_solver* s, double* now_obj, int* info) { S_OR_ARG; return s->update_V(now_obj, info); }
+int pcr_update_U(pcr_solver* s, double* now_obj, int64_t* info) { S_OR_ARG; return s->update_U(now_obj, info); }
+int pcr_evaluate(pcr_solver* s, int which, int ndcg_k, double* e, double* n) { S_OR_ARG; return s->evaluate(which, ndcg_k, e, n); }
+int pcr_train(pcr_solver* s, pcr_log_fn log, void* ctx, pcr_iter_stats* hist) { S_OR_ARG; return s->train(log, ctx, hist); }
+int pcr_solver_sync(pcr_solver* s) { S_OR_ARG; return s->sync(); }
+
+int pcr_profile_enable(pcr_solver* s, int on) { S_OR_ARG; s->prof_on = on != 0; return PCR_OK; }
+int pcr_profile_reset(pcr_solver* s) {
+    S_OR_ARG;
+    s->sync(); s->prof_resolve();
+    for (auto& kv : s->prof) { kv.second.ms = 0.0; kv.second.n = 0; }
+    return PCR_OK;
+}
+int pcr_profile_get(pcr_solver* s, const char* name, double* total_ms, int64_t* launches) {
+    S_OR_ARG;
+    s->sync(); s->prof_resolve();
+    auto it = s->prof.find(name ? name : "");
+    if (total_ms) *total_ms = it == s->prof.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == s->prof.end() ? 0 : it->second.n;
+    return PCR_OK;
+}
+
+int pcr_predict(const double* U, int64_t d1, const double* V, int64_t d2, int64_t k, int64_t n,
+                const int32_t* user, const int32_t* item, double* pred, int device) {
+    if (!U || !V || k < 1 || n < 0 || (n > 0 && (!user || !item || !pred))) { pcr_set_error("pcr_predict: bad argument"); return PCR_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { pcr_set_error("no HIP device available"); return PCR_ERR_DEVICE; }
+    HIPCHK(hipSetDevice(device));
+    for (int64_t z = 0; z < n; ++z)
+        if (user[z] < 0 || user[z] >= d1 || item[z] < 0 || item[z] >= d2) { pcr_set_error("pair " + std::to_string(z) + " outside the model"); return PCR_ERR_ARG; }
+    Geo geo;
+    geo.r = (int)k; geo.ld = ((int)k + 3) & ~3; geo.nchunk = geo.ld / 2; geo.G = std::min(64, host_pow2(geo.nchunk));
+    if (geo.nchunk > 64 * PCR_KMAX) { pcr_set_error("rank too large"); return PCR_ERR_UNSUPPORTED; }
+    // the model file holds fp64 factors: score in fp64 like pmf-predict.cpp:58-62
+    std::vector<double> Up((size_t)d1 * geo.ld, 0.0), Vp((size_t)d2 * geo.ld, 0.0);
+    for (int64_t i = 0; i < d1; ++i) for (int64_t j = 0; j < k; ++j) Up[i * geo.ld + j] = U[i * k + j];
+    for (int64_t i = 0; i < d2; ++i) for (int64_t j = 0; j < k; ++j) Vp[i * geo.ld + j] = V[i * k + j];
+    DBuf<double> dU, dV, dP;
+    DBuf<int32_t> du, di;
+    hipStream_t st = nullptr;
+    RC(dU.upload(Up, st)); RC(dV.upload(Vp, st)); RC(dP.alloc(n));
+    std::vector<int32_t> hu(user, user + n), hi(item, item + n);
+    RC(du.upload(hu, st)); RC(di.upload(hi, st));
+    if (n > 0) {
+        const int gpb = 256 / geo.G;
+        hipLaunchKernelGGL((k_predict<double>), dim3(cdiv(n, gpb)), dim3(256), 0, st, dU.p, dV.p, du.p, di.p, n, geo, dP.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(pred, dP.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return PCR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+"""CPU tests of the product's host side: the C-ABI library loads, exports every symbol declared in
+include/primalcr.h, and its loader / CSR conversion / initial() / model I/O / partitioner agree with
+the oracle and the golden vectors.  No GPU compute is called here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import primalcr_amd as pcr
+from conftest import GOLDEN_CASES, ROOT, load_golden
+from primalcr_amd import synth
+
+
+def test_every_declared_symbol_is_exported():
+    hdr = open(os.path.join(ROOT, "include", "primalcr.h")).read()
+    names = set(re.findall(r"\b(pcr_[a-z0-9_]+)\s*\(", hdr)) - {"pcr_log_fn"}
+    assert len(names) >= 30
+    L = pcr.lib()
+    for n in sorted(names):
+        assert hasattr(L, n), f"{n} declared in include/primalcr.h but not exported"
+    assert b"gfx950" in L.pcr_version()
+
+
+def test_parameter_defaults_match_pmf_h():
+    p = pcr.Parameter()       # pmf.h:27-48
+    assert (p.solver_type, p.k, p.threads, p.maxiter, p.lambda_, p.do_predict, p.stepsize, p.ndcg_k) == \
+           (2, 10, 4, 10, 5000.0, 1, 1.0, 10)
+
+
+def test_initial_matches_reference_stream(oracle):
+    X = pcr.initial(50, 7)
+    assert X[0, 0] == -0.12196578414159691 and X[0, 1] == -1.0868180442613573
+    assert np.array_equal(X, oracle.initial(50, 7))
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_loader_and_convert_match_reference(name, tmp_path):
+    g, _ = load_golden(name)
+    R = synth.Ratings(int(g["d1"]), int(g["d2"]), g["user"], g["item"], g["val"], g["tuser"], g["titem"], g["tval"])
+    d = synth.write_dir(R, str(tmp_path / "data"))
+    ds = pcr.Dataset.load(d)
+    assert ds.dims() == (R.d1, R.d2, R.nnz, len(g["tcsr_item"]))
+    idx, item, val = ds.csr(0)
+    assert np.array_equal(idx, g["csr_idx"]) and np.array_equal(item, g["csr_item"]) and np.array_equal(val, g["csr_val"])
+    tidx, titem, tval = ds.csr(1)
+    assert np.array_equal(tidx, g["tcsr_idx"]) and np.array_equal(titem, g["tcsr_item"]) and np.array_equal(tval, g["tcsr_val"])
+    assert ds.count_pairs() == int(g["n_pairs"])
+    # shuffled triplets give the same CSR (training file may be in any order, util.h:240)
+    perm = np.random.default_rng(0).permutation(R.nnz)
+    ds2 = pcr.Dataset.from_triplets(R.d1, R.d2, R.user[perm], R.item[perm], R.val[perm])
+    idx2, item2, val2 = ds2.csr(0)
+    assert np.array_equal(idx2, idx) and np.array_equal(item2, item) and np.array_equal(val2, val)
+
+
+def test_loader_errors(tmp_path):
+    with pytest.raises(pcr.PcrError):
+        pcr.Dataset.load(str(tmp_path / "nope"))
+    d = tmp_path / "bad"; d.mkdir()
+    (d / "meta").write_text("3 3\n5 training.ratings\n")
+    (d / "training.ratings").write_text("1 1 3\n2 2 4\n")
+    with pytest.raises(pcr.PcrError):
+        pcr.Dataset.load(str(d))               # fewer ratings than meta promises
+    with pytest.raises(pcr.PcrError):
+        pcr.Dataset.from_triplets(2, 2, [0, 5], [0, 1], [1.0, 2.0])   # id outside the dimensions
+
+
+def test_model_file_roundtrip_and_reference_bytes(tmp_path):
+    g, meta = load_golden("edge5")
+    U, V = g["cli_U_s2"], g["cli_V_s2"]
+    p = str(tmp_path / "m.model")
+    pcr.model_save(p, U, V)
+    assert os.path.getsize(p) == meta["model_bytes_s2"] == 2 * 16 + 8 * U.shape[1] * (U.shape[0] + V.shape[0])
+    U2, V2 = pcr.model_load(p)
+    assert np.array_equal(U, U2) and np.array_equal(V, V2)
+    raw = open(p, "rb").read()
+    assert np.frombuffer(raw[:16], np.int64).tolist() == [U.shape[0], U.shape[1]]
+
+
+def test_partition_users_is_nnz_balanced():
+    R = synth.generate("small")
+    ds = pcr.Dataset.from_ratings(R)
+    idx, _, _ = ds.csr(0)
+    for n in (1, 2, 3, 8):
+        b = pcr.partition_users(idx, n)
+        assert b[0] == 0 and b[-1] == R.d1 and np.all(np.diff(b) >= 0)
+        loads = np.diff(idx[b])
+        assert loads.sum() == R.nnz and loads.max() <= R.nnz / n + np.diff(idx).max()
+
+
+def test_training_entry_points_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ds = pcr.Dataset.from_ratings(synth.generate("tiny"))
+    with pytest.raises(pcr.PcrError, match="(?i)no HIP device|hip"):
+        pcr.Solver(ds, pcr.Parameter())
