@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement (BASELINE.json): PrimalCR++ pairwise-comparisons/sec
++ NDCG@10 on ml1m-shaped synthetic ratings, rank 100, lambda 5000, on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one outer iteration of pcrpp() (pcrpp.cpp:873-881): one truncated-Newton step on V
+(gradient, <=10 CG Hessian-vector products, line search) and one Newton step per user on U -- the
+same clock scope as the reference's "Iter k time" (no load, no init, no evaluation).  Inputs
+(ratings, factors) are resident in HBM before the timed region starts.
+
+value = #Omega * K / seconds, #Omega = #{(i,j,k): R_ij > R_ik} = the ordered pairs the objective
+sums over.  N > 1 is WEAK scaling: each rank owns 6040 more users of the same item catalogue
+(user-sharded; V-gradient and every Hessian-vector product are all-reduced over RCCL).
+
+The JSON line also carries
+  roofline      the kernel with the largest share of the timed region: algorithmic bytes per launch
+                 / its average duration from HIP events recorded on the
+                solver's stream during the timed region, against the 8 TB/s HBM3E peak
+  cpu_baseline  the reference's own OpenMP path (oracle/_ref/omp-pmf-train, built from the unmodified
+                reference) on the same data on this host's cores, 2 iterations (rank 0, N = 1 only);
+                falls back to the single-thread C restatement on a user sample when _ref is absent.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+USERS_PER_GPU = 6040
+D2, NNZ_PER_GPU = 3952, 939809
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def algorithmic_bytes(slot, nnz_b, nu_b, d2, r, esz):
+    """Compulsory HBM bytes of ONE launch of a per-user kernel over a length bin holding nnz_b
+    ratings of nu_b users (ideal caching: every operand crosses HBM once).  DESIGN.md section 4."""
+    F_U = nu_b * r * esz           # the bin's user factors
+    F_V = d2 * r * esz             # one item-side matrix
+    cls = slot.split("/")[0]
+    if cls == "prepare":           # comp_m + sort + objective: read item,lvl,cpos,uptr,U,V; write ms,sitem,slvl,scsc,objp
+        return nnz_b * (4 + 2 + 4) + nu_b * 16 + F_U + F_V + nnz_b * (esz + 4 + 2 + 4) + nu_b * 8
+    if cls == "vgrad":             # read ms,slvl,scsc; write c
+        return nnz_b * (esz + 2 + 4) + nu_b * 16 + nnz_b * esz
+    if cls == "vhv":               # read ms,sitem,slvl,scsc,U,a; write c
+        return nnz_b * (esz + 4 + 2 + 4) + nu_b * 16 + F_U + F_V + nnz_b * esz
+    if cls == "ustep":             # read ms,sitem,slvl,U,V; write U,objp
+        return nnz_b * (esz + 4 + 2) + nu_b * 16 + 2 * F_U + F_V + nu_b * 8
+    if cls == "spmm":              # read c,cuser,crow,U; read+write out
+        return nnz_b * (esz + 4 + 4) + F_U + 2 * F_V
+    return 0
+
+
+def host_cores():
+    """CPU cores this process may actually use: the cgroup quota when there is one (a GPU box hands
+    each GPU a 16-core share of a 256-thread host), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(R, n_pairs, r, lam):
+    """Reference OpenMP path on this host (kind "reference"), else the C restatement (kind "port")."""
+    from oracle import oracle_py
+    cores = host_cores()
+    if os.path.exists(oracle_py.REF_TRAIN):
+        from primalcr_amd import synth
+        iters = 2
+        with tempfile.TemporaryDirectory() as td:
+            d = synth.write_dir(R, os.path.join(td, "data"))
+            t0 = time.time()
+            out = subprocess.run([oracle_py.REF_TRAIN, "-s", "2", "-k", str(r), "-l", repr(lam), "-t", str(iters),
+                                  "-p", "0", "-n", str(cores), d, os.path.join(td, "m.model")],
+                                 cwd=td, capture_output=True, text=True, check=True).stdout
+            wall = time.time() - t0
+        times = [float(x) for x in re.findall(r"^Iter \d+ time (\S+) obj", out, re.M)]
+        secs = times[-1]
+        log(f"[cpu_baseline] reference omp-pmf-train -n {cores}: {secs:.2f}s for {iters} iterations (wall {wall:.1f}s)")
+        return {"value": n_pairs * iters / secs, "unit": "pairs/s", "cores": cores, "kind": "reference",
+                "sample": f"omp-pmf-train -s 2 -k {r} -l {lam:g} -t {iters} -p 0 -n {cores} on the full ml1m-shaped set; "
+                          f"'Iter {iters} time' = {secs:.3f} s", "s_per_iter": secs / iters}
+    orc = oracle_py.Oracle()
+    nu = 400
+    keep = R.user < nu
+    X = orc.build_csr(nu, R.d2, R.user[keep], R.item[keep], R.val[keep])
+    U, V = orc.initial(nu, r), orc.initial(R.d2, r)
+    _, _, recs = orc.train(X, U, V, lam, 1, do_predict=0)
+    secs = recs[1]["seconds"]
+    pairs = orc.count_pairs(X)
+    return {"value": pairs / secs, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": f"C restatement, first {nu} users ({int(keep.sum())} ratings, {pairs} pairs), 1 iteration = {secs:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rank-k", type=int, default=100, help="factor rank (BASELINE: 100)")
+    ap.add_argument("--lam", type=float, default=5000.0)
+    ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    N = args.gpus
+    if world != N:
+        if world == 1 and N > 1:
+            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        N = world
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the training path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if N > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import primalcr_amd as pcr
+    from primalcr_amd import synth
+
+    r, lam = args.rank_k, args.lam
+    t0 = time.time()
+    R = synth.generate("ml1m", d1=USERS_PER_GPU * N, nnz=NNZ_PER_GPU * N)
+    ds = pcr.Dataset.from_ratings(R)
+    n_pairs = ds.count_pairs()
+    if rank == 0:
+        log(f"[data] ml1m-shaped x{N}: {R.d1} users x {R.d2} items, {R.nnz} ratings, {n_pairs} ordered pairs, "
+            f"{len(R.tuser)} test ratings ({time.time() - t0:.1f}s)")
+    prec = pcr.PCR_F32 if args.precision == "f32" else pcr.PCR_F64
+    p = pcr.Parameter(k=r, precision=prec, device=local_rank, do_predict=0, maxiter=1, **{"lambda": lam})
+    s = pcr.Solver(ds, p, rank, N)
+    if N > 1:
+        ids = [pcr.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        s.comm_init(ids[0])
+    U0, V0 = pcr.initial(R.d1, r), pcr.initial(R.d2, r)      # the reference's init stream (util.cpp:80)
+    s.set_factors(U0, V0)
+
+    def barrier():
+        s.sync()
+        torch.cuda.synchronize()
+        if N > 1:
+            dist.barrier()
+
+    objs = []
+    for _ in range(args.warmup):
+        s.update_V(); o, _ = s.update_U(); objs.append(o)
+    if not args.no_profile:
+        s.profile(True)
+        s.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    inner = {"cg_v": 0, "ls_v": 0, "cg_u": 0, "ls_u": 0}
+    for _ in range(args.steps):
+        _, vi = s.update_V()
+        o, ui = s.update_U()
+        objs.append(o)
+        inner["cg_v"] += vi["cg"]; inner["ls_v"] += vi["ls"]; inner["cg_u"] += ui["cg"]; inner["ls_u"] += ui["ls"]
+    barrier()
+    secs = time.perf_counter() - t0
+    if N > 1:
+        tt = torch.tensor([secs], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        secs = float(tt.item())
+    prof = {} if args.no_profile else s.profile_all()
+    s.profile(False)
+    # quality after warmup+steps outer iterations (NDCG@10 / pairwise error on the held-out ratings)
+    te_err, te_ndcg = s.evaluate(1, 10)
+    tr_err, tr_ndcg = s.evaluate(0, 10)
+
+    if rank != 0:
+        if N > 1:
+            dist.barrier(); dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (rank 0's shard)
+    roof = None
+    if prof:
+        idx, _, _ = ds.csr(0)
+        lens = np.diff(idx)[s.first_user:s.first_user + s.n_users]
+        bins = {"64": lens <= 256, "256": (lens > 256) & (lens <= 1024), "1024": (lens > 1024) & (lens <= 4096), "1024g": lens > 4096}
+        esz = 4 if prec == pcr.PCR_F32 else 8
+        total_ms = sum(v[0] for v in prof.values())
+        if args.verbose:
+            for k, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+                log(f"  {k:14s} {ms:9.3f} ms  {n:6d} launches  {1e3 * ms / max(n, 1):9.1f} us/launch  {100 * ms / total_ms:5.1f} %")
+        name, (ms, n) = max(((k, v) for k, v in prof.items() if k.split("/")[0] in ("prepare", "vgrad", "vhv", "ustep", "spmm")),
+                            key=lambda kv: kv[1][0])
+        if "/" in name:
+            sel = bins[name.split("/")[1]]
+            nnz_b, nu_b = int(lens[sel].sum()), int(sel.sum())
+        else:
+            nnz_b, nu_b = int(lens.sum()), int(lens.shape[0])
+        ab = algorithmic_bytes(name, nnz_b, nu_b, R.d2, r, esz)
+        avg_s = ms / n / 1e3
+        ach = ab / avg_s / 1e9
+        roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                "launches": int(n), "algorithmic_bytes_per_launch": int(ab),
+                "share_of_kernel_time": round(ms / total_ms, 3)}
+    cpu = None
+    if N == 1 and not args.no_cpu:
+        cpu = cpu_baseline(R, n_pairs, r, lam)
+
+    value = n_pairs * args.steps / secs
+    out = {
+        "metric": "pairwise-comparisons/sec", "value": value, "unit": "pairs/s", "n_gpus": N, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32" if prec == pcr.PCR_F32 else "f64", "data": "synthetic",
+        "config": {"workload": f"ml1m-shaped PrimalCR++ -k {r} -l {lam:g} (configs[1]); {R.d1} users x {R.d2} items, "
+                               f"{R.nnz} ratings, {n_pairs} ordered pairs; 1 step = 1 outer iteration (V step + U step)",
+                   "solver": "PrimalCR++", "rank": r, "lambda": lam, "parallelism": f"user-sharded x{N}",
+                   "accumulation": "f64"},
+        "ndcg10_test": te_ndcg, "pairwise_error_test": te_err, "ndcg10_train": tr_ndcg, "pairwise_error_train": tr_err,
+        "outer_iterations_run": args.warmup + args.steps, "objective": objs[-1],
+        "inner_per_step": {k: v / args.steps for k, v in inner.items()},
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    if cpu:
+        out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+    print(json.dumps(out), flush=True)
+    if N > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

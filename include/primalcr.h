@@ -180,9 +180,12 @@ int pcr_predict(const double *U, int64_t d1, const double *V, int64_t d2, int64_
                 int64_t n, const int32_t *user, const int32_t *item, double *pred,
                 int device);                                               /* [device] */
 
-/* per-kernel-class device timing (HIP events on the solver's stream).
- * names: "prepare", "vgrad", "vhv", "spmm", "cg", "ustep", "eval", "allreduce" */
+/* per-kernel device timing (HIP events on the solver's stream, one pair per launch).
+ * slot names: "<class>/<workgroup size>[g]" for the per-user kernels (classes prepare,
+ * vgrad, vhv, ustep; g = global-scratch variant), and "spmm", "cg", "eval", "allreduce".
+ * pcr_profile_list writes the comma-separated names of the slots seen so far. */
 int pcr_profile_enable(pcr_solver *s, int on);
+int pcr_profile_list(pcr_solver *s, char *buf, int64_t cap);
 int pcr_profile_get(pcr_solver *s, const char *name, double *total_ms, int64_t *launches);
 int pcr_profile_reset(pcr_solver *s);
 /* blocks until the solver's stream is idle */

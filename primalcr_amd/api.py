@@ -95,6 +95,7 @@ def lib():
     L.pcr_profile_enable.argtypes = [vp, ci]
     L.pcr_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(cd), C.POINTER(i64)]
     L.pcr_profile_reset.argtypes = [vp]
+    L.pcr_profile_list.argtypes = [vp, C.c_char_p, i64]
     L.pcr_solver_sync.argtypes = [vp]
     _lib = L
     return L
@@ -295,6 +296,13 @@ class Solver:
         ms, n = C.c_double(), C.c_int64()
         _chk(lib().pcr_profile_get(self._h, name.encode(), ms, n))
         return ms.value, n.value
+
+    def profile_all(self):
+        """{slot name: (total ms, launches)} of every kernel timed so far."""
+        buf = C.create_string_buffer(4096)
+        _chk(lib().pcr_profile_list(self._h, buf, 4096))
+        names = [n for n in buf.value.decode().split(",") if n]
+        return {n: self.profile_get(n) for n in names}
 
     def sync(self):
         _chk(lib().pcr_solver_sync(self._h))

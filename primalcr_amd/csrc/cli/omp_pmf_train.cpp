@@ -1,0 +1,119 @@
+// omp-pmf-train -- drop-in replacement of the reference's training CLI (pmf-train.cpp) on top of
+// the C ABI of libprimalcr (MI355X).  Same flags, defaults, positional rules, default model name,
+// log lines, model file and U.txt / V.txt side files (pmf-train.cpp:8-27, 29-135, 247-314).
+//
+// Extensions use long options the reference would reject anyway (unknown option -> usage, exit 1):
+//   --f64          fp64 storage on the device (default: fp32 storage, fp64 accumulation)
+//   --device N     HIP device ordinal
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "primalcr.h"
+
+static void exit_with_help() {
+    printf(
+        "Usage: omp-pmf-train [options] data_dir [model_filename]\n"
+        "options:\n"
+        "    -s type : set type of solver (default 2)\n"
+        "    	 1 -- PirmalCR\n"
+        "    	 2 -- PrimalCR++\n"
+        "    -k rank : set the rank (default 10)\n"
+        "    -n threads : set the number of threads (default 4)\n"
+        "    -l lambda : set the regularization parameter lambda (default 5000)\n"
+        "    -t max_iter: set the number of iterations (default 10)\n"
+        "    -p do_predict: compute training/testing error & NDCG at each iteration or not (default 1)\n"
+        "    --f64 : keep U, V in fp64 on the GPU (default fp32 storage, fp64 accumulation)\n"
+        "    --device id : GPU to use (default 0)\n");
+    exit(1);
+}
+
+static void die(const char* what) {
+    fprintf(stderr, "%s: %s\n", what, pcr_last_error());
+    exit(1);
+}
+
+int main(int argc, char** argv) {
+    pcr_params param;
+    pcr_params_default(&param);
+    int i;
+    for (i = 1; i < argc; i++) {                       // pmf-train.cpp:36-108
+        if (argv[i][0] != '-') break;
+        if (!strcmp(argv[i], "--f64")) { param.precision = PCR_F64; continue; }
+        if (++i >= argc) exit_with_help();
+        if (!strcmp(argv[i - 1], "--device")) { param.device = atoi(argv[i]); continue; }
+        switch (argv[i - 1][1]) {
+            case 's': param.solver_type = atoi(argv[i]); break;
+            case 'k': param.k = atoi(argv[i]); break;
+            case 'n': param.threads = atoi(argv[i]); break;
+            case 'l': param.lambda = atof(argv[i]); break;
+            case 't': param.maxiter = atoi(argv[i]); break;
+            case 'p': param.do_predict = atoi(argv[i]); break;
+            case 'q': param.verbose = atoi(argv[i]); break;
+            // parsed-but-unused by the PCR/PCR++ path in the reference (pmf-train.cpp:59-102)
+            case 'r': case 'T': case 'e': case 'B': case 'm': case 'u': case 'd': case 'N': break;
+            default:
+                fprintf(stderr, "unknown option: -%c\n", argv[i - 1][1]);
+                exit_with_help();
+        }
+    }
+    if (param.do_predict != 0) param.verbose = 1;
+    if (i >= argc) exit_with_help();
+    std::string input = argv[i], model;
+    if (i < argc - 1) model = argv[i + 1];
+    else {                                             // pmf-train.cpp:120-133
+        std::string d = input;
+        while (!d.empty() && d.back() == '/') d.pop_back();
+        size_t p = d.rfind('/');
+        model = (p == std::string::npos ? d : d.substr(p + 1)) + ".model";
+    }
+    if (param.solver_type != PCR_SOLVER_PCR && param.solver_type != PCR_SOLVER_PCRPP) {
+        fprintf(stderr, "Error: wrong solver type (%d)!\n", param.solver_type);   // pmf-train.cpp:331-333
+        return 0;
+    }
+    // the reference opens the model file BEFORE training (pmf-train.cpp:252-259)
+    FILE* fp = fopen(model.c_str(), "wb");
+    if (!fp) { fprintf(stderr, "can't open output file %s\n", model.c_str()); return 1; }
+    fclose(fp);
+
+    pcr_dataset* ds = nullptr;
+    if (pcr_dataset_load(input.c_str(), &ds) != PCR_OK) die("load");
+    int64_t d1, d2, nnz, tnnz;
+    pcr_dataset_dims(ds, &d1, &d2, &nnz, &tnnz);
+    const int k = param.k;
+    std::vector<double> U((size_t)d1 * k), V((size_t)d2 * k);
+    pcr_initial(U.data(), d1, k);                      // pmf-train.cpp:264-266
+    pcr_initial(V.data(), d2, k);
+    std::cout << "the rank is " << k << std::endl;
+    std::cout << "the number of rows is " << d1 << " and the number of cols is " << d2 << std::endl;
+    if (param.solver_type == PCR_SOLVER_PCRPP) { std::cout << nnz << std::endl; std::cout << "starts!" << std::endl; }
+    else std::cout << "nnz: " << nnz << std::endl;
+
+    auto t0 = std::chrono::steady_clock::now();
+    pcr_solver* s = nullptr;
+    if (pcr_solver_create(ds, &param, 0, 1, &s) != PCR_OK) die("solver");
+    if (pcr_solver_set_factors(s, U.data(), V.data()) != PCR_OK) die("set_factors");
+    if (pcr_train(s, nullptr, nullptr, nullptr) != PCR_OK) die("train");
+    if (pcr_solver_get_factors(s, U.data(), V.data()) != PCR_OK) die("get_factors");
+    printf("Wall-time: %lg secs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+
+    // side files (pmf-train.cpp:208-227, 276-295)
+    std::string suffix = param.solver_type == PCR_SOLVER_PCR ? std::to_string(static_cast<int>(param.lambda)) : "";
+    auto dump = [&](const char* name, const std::vector<double>& M, int64_t rows) {
+        std::cout << name << " matrix of size " << rows << ", " << k << std::endl;
+        std::ofstream f(std::string(name) + suffix + ".txt");
+        for (int64_t a = 0; a < rows; ++a)
+            for (int b = 0; b < k; ++b) { f << M[a * k + b]; f << (b < k - 1 ? " " : "\n"); }
+    };
+    dump("U", U, d1);
+    dump("V", V, d2);
+    if (pcr_model_save(model.c_str(), U.data(), d1, V.data(), d2, k) != PCR_OK) die("model");
+    pcr_solver_destroy(s);
+    pcr_dataset_free(ds);
+    return 0;
+}

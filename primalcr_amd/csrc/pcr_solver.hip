@@ -165,7 +165,7 @@ struct Solver final : pcr_solver {
     // ------------------------------------------------------------------------------ profiling
     struct ProfScope {
         Solver* s; ProfSlot* slot = nullptr; hipEvent_t a = nullptr, b = nullptr;
-        ProfScope(Solver* s_, const char* name) : s(s_) {
+        ProfScope(Solver* s_, const std::string& name) : s(s_) {
             if (!s->prof_on) return;
             slot = &s->prof[name];
             (void)hipEventCreate(&a); (void)hipEventCreate(&b);
@@ -347,15 +347,17 @@ struct Solver final : pcr_solver {
         return PCR_OK;
     }
 
+    // profile slot of one kernel launch: "<class>/<workgroup size>[g]" (g = global-scratch variant)
+    static std::string pname(const char* cls, const Bin& b) { return std::string(cls) + "/" + std::to_string(b.block) + (b.big ? "g" : ""); }
     size_t small_common(int block) const { return carve_bytes(geo.ld, sizeof(T)) + carve_bytes(block / PCR_WAVE + 1, 8); }
     int strict() const { return prm.solver_type == PCR_SOLVER_PCR ? 1 : 0; }
 
     // ------------------------------------------------------------------------------ launches
     // m = V_I u, sort, per-user loss -> objp.  Vm = matrix the scores are taken against.
     int launch_prepare(const T* Vm, T* m_csr) {
-        ProfScope ps(this, "prepare");
         for (auto& b : bins) {
             if (b.users.empty()) continue;
+            ProfScope ps(this, pname("prepare", b));
             const int nus = (int)b.users.size();
             const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
             const size_t bigb = prepare_bytes<T>(cap_pad, rsc, b.big ? 8 : 4);
@@ -374,9 +376,9 @@ struct Solver final : pcr_solver {
     }
 
     int launch_vsweep(bool hv, const T* A) {
-        ProfScope ps(this, hv ? "vhv" : "vgrad");
         for (auto& b : bins) {
             if (b.users.empty()) continue;
+            ProfScope ps(this, pname(hv ? "vhv" : "vgrad", b));
             const int nus = (int)b.users.size();
             const int rsc = b.max_lev + 2;
             const size_t bigb = vsweep_bytes<T>(b.cap, rsc);
@@ -626,10 +628,10 @@ struct Solver final : pcr_solver {
     }
 
     int launch_ustep() {
-        ProfScope ps(this, "ustep");
         HIPCHK(hipMemsetAsync(d_counters.p, 0, 4 * sizeof(unsigned long long), st));
         for (auto& b : bins) {
             if (b.users.empty()) continue;
+            ProfScope ps(this, pname("ustep", b));
             const int nus = (int)b.users.size();
             const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
             const size_t lds = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + (b.big ? 0 : ustep_big_bytes<T>(cap_pad, rsc, 4));
@@ -836,6 +838,14 @@ int pcr_profile_reset(pcr_solver* s) {
     S_OR_ARG;
     s->sync(); s->prof_resolve();
     for (auto& kv : s->prof) { kv.second.ms = 0.0; kv.second.n = 0; }
+    return PCR_OK;
+}
+int pcr_profile_list(pcr_solver* s, char* buf, int64_t cap) {
+    S_OR_ARG;
+    std::string all;
+    for (auto& kv : s->prof) { if (!all.empty()) all += ","; all += kv.first; }
+    if (!buf || cap < (int64_t)all.size() + 1) { pcr_set_error("buffer too small"); return PCR_ERR_ARG; }
+    memcpy(buf, all.c_str(), all.size() + 1);
     return PCR_OK;
 }
 int pcr_profile_get(pcr_solver* s, const char* name, double* total_ms, int64_t* launches) {
