@@ -61,6 +61,8 @@ def algorithmic_bytes(slot, nnz_b, nu_b, d2, r, esz):
         return nnz_b * (esz + 4 + 2) + nu_b * 16 + 2 * F_U + F_V + nu_b * 8
     if cls == "spmm":              # read c,cuser,crow,U; read+write out
         return nnz_b * (esz + 4 + 4) + F_U + 2 * F_V
+    if cls == "sddmm":             # read item,ruser,U,M; write one score per rating
+        return nnz_b * (4 + 4 + esz) + F_U + F_V
     return 0
 
 
@@ -170,7 +172,7 @@ def main():
     for _ in range(args.warmup):
         s.update_V(); o, _ = s.update_U(); objs.append(o)
     if not args.no_profile:
-        s.profile(True)
+        s.profile(True, period=4)       # sampled: every 4th launch of each kernel carries an event pair
         s.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -202,13 +204,13 @@ def main():
     if prof:
         idx, _, _ = ds.csr(0)
         lens = np.diff(idx)[s.first_user:s.first_user + s.n_users]
-        bins = {"64": lens <= 256, "256": (lens > 256) & (lens <= 1024), "1024": (lens > 1024) & (lens <= 4096), "1024g": lens > 4096}
+        bins = {"64": lens <= 128, "256": (lens > 128) & (lens <= 512), "512": (lens > 512) & (lens <= 4096), "512g": lens > 4096}
         esz = 4 if prec == pcr.PCR_F32 else 8
         total_ms = sum(v[0] for v in prof.values())
         if args.verbose:
             for k, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
                 log(f"  {k:14s} {ms:9.3f} ms  {n:6d} launches  {1e3 * ms / max(n, 1):9.1f} us/launch  {100 * ms / total_ms:5.1f} %")
-        name, (ms, n) = max(((k, v) for k, v in prof.items() if k.split("/")[0] in ("prepare", "vgrad", "vhv", "ustep", "spmm")),
+        name, (ms, n) = max(((k, v) for k, v in prof.items() if k.split("/")[0] in ("prepare", "vgrad", "vhv", "ustep", "spmm", "sddmm")),
                             key=lambda kv: kv[1][0])
         if "/" in name:
             sel = bins[name.split("/")[1]]

@@ -183,7 +183,10 @@ int pcr_predict(const double *U, int64_t d1, const double *V, int64_t d2, int64_
 /* per-kernel device timing (HIP events on the solver's stream, one pair per launch).
  * slot names: "<class>/<workgroup size>[g]" for the per-user kernels (classes prepare,
  * vgrad, vhv, ustep; g = global-scratch variant), and "spmm", "cg", "eval", "allreduce".
- * pcr_profile_list writes the comma-separated names of the slots seen so far. */
+ * pcr_profile_list writes the comma-separated names of the slots seen so far.
+ * pcr_profile_enable(s, n): n = 0 off, 1 time every launch, n > 1 time every n-th launch of each
+ * slot (an event pair costs ~3 us of queue time, so sampling keeps the timed region honest);
+ * pcr_profile_get returns the summed time and the number of TIMED launches. */
 int pcr_profile_enable(pcr_solver *s, int on);
 int pcr_profile_list(pcr_solver *s, char *buf, int64_t cap);
 int pcr_profile_get(pcr_solver *s, const char *name, double *total_ms, int64_t *launches);

@@ -286,8 +286,9 @@ class Solver:
         recs = [{k: getattr(h, k) for k, _ in IterStats._fields_} for h in hist]
         return recs, lines
 
-    def profile(self, on=True):
-        _chk(lib().pcr_profile_enable(self._h, int(on)))
+    def profile(self, on=True, period=1):
+        """Per-kernel HIP-event timing; period > 1 times every period-th launch of each kernel."""
+        _chk(lib().pcr_profile_enable(self._h, (period if period > 1 else 1) if on else 0))
 
     def profile_reset(self):
         _chk(lib().pcr_profile_reset(self._h))

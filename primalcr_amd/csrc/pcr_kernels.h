@@ -25,7 +25,6 @@
 #include <stdint.h>
 
 #define PCR_WAVE 64
-#define PCR_KMAX 4          // row chunks per lane: supports ld/VEC <= 256
 
 template <typename T> struct VecOf;
 template <> struct VecOf<float>  { typedef float4 type;  static constexpr int N = 4; };
@@ -231,40 +230,77 @@ __device__ __forceinline__ double block_objective(const T* ms, LevF levf, const 
 }
 
 // out[p] = vec . M[rows[p]]  for p in [0, n)   (SDDMM of one user; pcrpp.cpp:28-31, :266-271,
-// :592-594, :735-742).  vecT: LDS, ld entries of T.  rows: LDS or global.  G lanes per row.
+// :592-594, :735-742).  vecT: LDS, ld entries of T.  rows: item ids, staged in LDS by the caller
+// (no dependent global index load in front of the row load).  G lanes per row; PCR_UNR rows are
+// in flight per lane group (memory-level parallelism: the gathers are latency-bound).  Rows longer
+// than G chunks are handled by an outer pass per chunk set.
+#define PCR_UNR 8
+
+// Sum 8 per-lane values over the G lanes of each lane group (G = 8, 16, 32 or 64) with 9-10
+// constant-offset shuffles instead of 8 * log2(G): at xor 1, 2, 4 each lane keeps half of its
+// values and sends the other half, so after three steps it owns ONE row's partial; the remaining
+// steps are plain butterflies.  Returns the total of row rho(g) = 4*(g&1) + (g&2) + ((g>>2)&1),
+// identical in the G/8 lanes that share g&7.
+template <typename T>
+__device__ __forceinline__ T group_reduce8(const T (&a)[8], int g, int G) {
+    T b[4], c[2], d;
+    const bool b0 = g & 1, b1 = g & 2, b2 = g & 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const T send = b0 ? a[i] : a[i + 4], keep = b0 ? a[i + 4] : a[i];
+        b[i] = keep + __shfl_xor(send, 1);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const T send = b1 ? b[i] : b[i + 2], keep = b1 ? b[i + 2] : b[i];
+        c[i] = keep + __shfl_xor(send, 2);
+    }
+    {
+        const T send = b2 ? c[0] : c[1], keep = b2 ? c[1] : c[0];
+        d = keep + __shfl_xor(send, 4);
+    }
+    if (G > 8) d += __shfl_xor(d, 8);
+    if (G > 16) d += __shfl_xor(d, 16);
+    if (G > 32) d += __shfl_xor(d, 32);
+    return d;
+}
+
 template <typename T, int BLOCK>
 __device__ __forceinline__ void block_sddmm(const T* __restrict__ M, const T* vecT, const int32_t* rows, int n,
                                             T* out, const Geo& geo) {
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     const int G = geo.G, g = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = BLOCK / G;
-    V uv[PCR_KMAX];
-#pragma unroll
-    for (int k = 0; k < PCR_KMAX; ++k) {
+    const int rho = 4 * (g & 1) + (g & 2) + ((g >> 2) & 1);
+    for (int k = 0; k * G < geo.nchunk; ++k) {
         const int ch = g + k * G;
-        if (ch < geo.nchunk) uv[k] = *reinterpret_cast<const V*>(vecT + ch * VEC);
-    }
-    for (int base = grp; base < n; base += ngrp * 4) {
-        T acc[4];
+        const bool act = ch < geo.nchunk;
+        V uv;
+        if (act) uv = *reinterpret_cast<const V*>(vecT + ch * VEC);
+        for (int base = grp; base < n; base += ngrp * PCR_UNR) {
+            V rv[PCR_UNR];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = base + q * ngrp;
-            acc[q] = (T)0;
-            if (row < n) {
-                const T* rp = M + (size_t)rows[row] * geo.ld;
+            for (int q = 0; q < PCR_UNR; ++q) {
+                const int row = base + q * ngrp;
+                if (row < n && act) rv[q] = *reinterpret_cast<const V*>(M + (size_t)rows[row] * geo.ld + ch * VEC);
+            }
+            T part[PCR_UNR];
 #pragma unroll
-                for (int k = 0; k < PCR_KMAX; ++k) {
-                    const int ch = g + k * G;
-                    if (ch < geo.nchunk) acc[q] += vdot(*reinterpret_cast<const V*>(rp + ch * VEC), uv[k]);
+            for (int q = 0; q < PCR_UNR; ++q) part[q] = (act && base + q * ngrp < n) ? vdot(rv[q], uv) : (T)0;
+            if (G >= 8) {
+                const T tot = group_reduce8<T>(part, g, G);          // whole lane groups are active here
+                const int row = base + rho * ngrp;
+                if (g < 8 && row < n) out[row] = (k == 0) ? tot : out[row] + tot;
+            } else {
+#pragma unroll
+                for (int q = 0; q < PCR_UNR; ++q) {
+                    T v = part[q];
+                    if (G > 2) v += __shfl_xor(v, 2);
+                    if (G > 1) v += __shfl_xor(v, 1);
+                    const int row = base + q * ngrp;
+                    if (g == 0 && row < n) out[row] = (k == 0) ? v : out[row] + v;
                 }
             }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            T v = acc[q];
-            for (int off = G >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            const int row = base + q * ngrp;
-            if (g == 0 && row < n) out[row] = v;
         }
     }
 }
@@ -277,67 +313,50 @@ __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     const int G = geo.G, g = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = BLOCK / G;
-    double acc[PCR_KMAX][VEC];
-#pragma unroll
-    for (int k = 0; k < PCR_KMAX; ++k)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[k][e] = 0.0;
-    for (int base = grp; base < n; base += ngrp * 4) {
-        V rv[4][PCR_KMAX];
-        double cc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = base + q * ngrp;
-            cc[q] = 0.0;
-            if (row < n) {
-                cc[q] = (double)c[row];
-                const T* rp = M + (size_t)rows[row] * geo.ld;
-#pragma unroll
-                for (int k = 0; k < PCR_KMAX; ++k) {
-                    const int ch = g + k * G;
-                    if (ch < geo.nchunk) rv[q][k] = *reinterpret_cast<const V*>(rp + ch * VEC);
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = base + q * ngrp;
-            if (row < n) {
-#pragma unroll
-                for (int k = 0; k < PCR_KMAX; ++k) {
-                    const int ch = g + k * G;
-                    if (ch < geo.nchunk) {
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) acc[k][e] += cc[q] * (double)velem(rv[q][k], e);
-                    }
-                }
-            }
-        }
-    }
-    // groups of one wave -> one vector
-    for (int off = G; off < PCR_WAVE; off <<= 1) {
-#pragma unroll
-        for (int k = 0; k < PCR_KMAX; ++k)
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[k][e] += __shfl_xor(acc[k][e], off);
-    }
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __syncthreads();
-    if (lane < G) {
+    for (int k = 0; k * G < geo.nchunk; ++k) {
+        const int ch = g + k * G;
+        const bool act = ch < geo.nchunk;
+        double acc[VEC];
 #pragma unroll
-        for (int k = 0; k < PCR_KMAX; ++k) {
-            const int ch = g + k * G;
-            if (ch < geo.nchunk) {
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
+        for (int base = grp; base < n; base += ngrp * PCR_UNR) {
+            V rv[PCR_UNR];
+            double cc[PCR_UNR];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) wbuf[wid * geo.ld + ch * VEC + e] = acc[k][e];
+            for (int q = 0; q < PCR_UNR; ++q) {
+                const int row = base + q * ngrp;
+                cc[q] = 0.0;
+                if (row < n && act) {
+                    cc[q] = (double)c[row];
+                    rv[q] = *reinterpret_cast<const V*>(M + (size_t)rows[row] * geo.ld + ch * VEC);
+                }
             }
+#pragma unroll
+            for (int q = 0; q < PCR_UNR; ++q) {
+                const int row = base + q * ngrp;
+                if (row < n && act) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] += cc[q] * (double)velem(rv[q], e);
+                }
+            }
+        }
+        // groups of one wave -> one vector
+        for (int off = G; off < PCR_WAVE; off <<= 1) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] += __shfl_xor(acc[e], off);
+        }
+        if (k == 0) __syncthreads();
+        if (lane < G && act) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) wbuf[wid * geo.ld + ch * VEC + e] = acc[e];
         }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < geo.ld; t += BLOCK) {
-        double s = 0.0;
-        for (int w = 0; w < BLOCK / PCR_WAVE; ++w) s += wbuf[w * geo.ld + t];
-        outvec[t] += s;
+        double sum = 0.0;
+        for (int w = 0; w < BLOCK / PCR_WAVE; ++w) sum += wbuf[w * geo.ld + t];
+        outvec[t] += sum;
     }
     __syncthreads();
 }
@@ -357,7 +376,72 @@ static inline size_t carve_bytes(size_t n, size_t elt) { return (n * elt + 15) &
 __device__ __forceinline__ int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 // ---------------------------------------------------------------------------------------
-// k_prepare: m = V_I u_i, sort by (level, m), per-user loss.   One workgroup per user.
+// k_sddmm: out[z] = U[ruser[z]] . M[rows[z]] for every rating z (pcrpp.cpp:24-33, :266-271).
+// Rating-parallel and perfectly balanced whatever the user-length skew: a workgroup owns
+// (BLOCK/G) * tile consecutive ratings, stages their (user, item) ids in LDS, and each lane group
+// walks `tile` consecutive ratings 8 at a time (8 rows of M in flight per group).  Consecutive
+// ratings share their user, so the u_i chunk stays in registers and is reloaded only at a user
+// boundary.
+// ---------------------------------------------------------------------------------------
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_sddmm(const T* __restrict__ U, const T* __restrict__ M,
+                                                 const int32_t* __restrict__ ruser, const int32_t* __restrict__ rows,
+                                                 int64_t nnz, T* __restrict__ out, Geo geo, int tile, const int* skip) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VEC = VecOf<T>::N;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    const int G = geo.G, g = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = BLOCK / G;
+    const int span = ngrp * tile;
+    int32_t* s_row = reinterpret_cast<int32_t*>(smem);
+    int32_t* s_usr = s_row + span;
+    const int64_t b0 = (int64_t)blockIdx.x * span;
+    const int nb = (int)((nnz - b0 < span) ? (nnz - b0) : span);
+    for (int t = threadIdx.x; t < nb; t += BLOCK) { s_row[t] = rows[b0 + t]; s_usr[t] = ruser[b0 + t]; }
+    __syncthreads();
+    const int l0 = grp * tile;
+    const int l1 = (l0 + tile < nb) ? l0 + tile : nb;
+    const int rho = 4 * (g & 1) + (g & 2) + ((g >> 2) & 1);
+    for (int k = 0; k * G < geo.nchunk; ++k) {
+        const int ch = g + k * G;
+        const bool act = ch < geo.nchunk;
+        int cur = -1;
+        V uv;
+        for (int q0 = l0; q0 < l1; q0 += PCR_UNR) {
+            V rv[PCR_UNR];
+#pragma unroll
+            for (int e = 0; e < PCR_UNR; ++e)
+                if (q0 + e < l1 && act) rv[e] = *reinterpret_cast<const V*>(M + (size_t)s_row[q0 + e] * geo.ld + ch * VEC);
+            T part[PCR_UNR];
+#pragma unroll
+            for (int e = 0; e < PCR_UNR; ++e) {
+                part[e] = (T)0;
+                if (q0 + e < l1) {                                  // uniform inside a lane group
+                    const int uu = s_usr[q0 + e];
+                    if (uu != cur) { cur = uu; if (act) uv = *reinterpret_cast<const V*>(U + (size_t)uu * geo.ld + ch * VEC); }
+                    if (act) part[e] = vdot(rv[e], uv);
+                }
+            }
+            if (G >= 8) {
+                const T tot = group_reduce8<T>(part, g, G);
+                const int q = q0 + rho;
+                if (g < 8 && q < l1) out[b0 + q] = (k == 0) ? tot : out[b0 + q] + tot;
+            } else {
+#pragma unroll
+                for (int e = 0; e < PCR_UNR; ++e) {
+                    T v = part[e];
+                    if (G > 2) v += __shfl_xor(v, 2);
+                    if (G > 1) v += __shfl_xor(v, 1);
+                    if (g == 0 && q0 + e < l1) out[b0 + q0 + e] = (k == 0) ? v : out[b0 + q0 + e] + v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_prepare: sort one user's scores (m_in, CSR order, from k_sddmm) by (level, m), write the sorted
+// state, per-user loss.   One workgroup per user.
 //   BIG = false: n-sized arrays in LDS;  BIG = true: in a per-workgroup global scratch slice.
 // ---------------------------------------------------------------------------------------
 template <typename T, bool BIG> struct LiSel { typedef uint32_t type; };
@@ -370,12 +454,11 @@ static inline size_t prepare_bytes(int cap_pad, int rs_cap, int li_bytes) {
 
 template <typename T, int BLOCK, bool BIG>
 __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
-                                                   const T* __restrict__ U, const T* __restrict__ Vm, T* __restrict__ m_csr,
+                                                   const T* __restrict__ m_in,
                                                    int cap_pad, int rs_cap, char* scratch, size_t stride, int strict) {
     typedef typename LiSel<T, BIG>::type LI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Carver small(smem);
-    T* vecT = small.take<T>(geo.ld);
     double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
     Carver big(BIG ? scratch + (size_t)blockIdx.x * stride : small.p);
     T* key = big.take<T>(cap_pad);
@@ -393,17 +476,13 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const in
             if (tid == 0) S.objp[u] = 0.0;
             continue;
         }
-        for (int t = tid; t < geo.ld; t += BLOCK) vecT[t] = U[(size_t)u * geo.ld + t];
         for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
-        __syncthreads();
-        block_sddmm<T, BLOCK>(Vm, vecT, S.item + s0, n, key, geo);
         const int npad = next_pow2(n);
         for (int p = tid; p < npad; p += BLOCK) {
-            if (p < n) li[p] = LiOps<LI>::pack(S.lvl[s0 + p], (unsigned)p);
+            if (p < n) { li[p] = LiOps<LI>::pack(S.lvl[s0 + p], (unsigned)p); key[p] = m_in[s0 + p]; }
             else { li[p] = LiOps<LI>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
         }
         __syncthreads();
-        if (m_csr) for (int p = tid; p < n; p += BLOCK) m_csr[s0 + p] = key[p];
         bitonic_sort<T, LI, BLOCK>(key, li, npad);
         for (int p = tid; p < n; p += BLOCK) {
             const LI x = li[p];
@@ -422,7 +501,7 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const in
 // ---------------------------------------------------------------------------------------
 // k_vsweep: per-user sweep coefficients for the V side, scattered to CSC order.
 //   HV = false: gradient (x = m, shift 1)           pcrpp.cpp:214-238
-//   HV = true : Hessian-vector (x = u_i . a_item)   pcrpp.cpp:266-271, 294-318
+//   HV = true : Hessian-vector (x = b = u_i . a_item, computed by k_sddmm)   pcrpp.cpp:294-318
 // ---------------------------------------------------------------------------------------
 template <typename T>
 static inline size_t vsweep_bytes(int cap, int rs_cap) {
@@ -431,11 +510,11 @@ static inline size_t vsweep_bytes(int cap, int rs_cap) {
 
 template <typename T, int BLOCK, bool BIG, bool HV>
 __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
-                                                  const T* __restrict__ U, const T* __restrict__ A, T* __restrict__ c_csc,
-                                                  int cap, int rs_cap, char* scratch, size_t stride, int strict) {
+                                                  const T* __restrict__ bsrc, T* __restrict__ c_csc,
+                                                  int cap, int rs_cap, char* scratch, size_t stride, int strict, const int* skip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
     Carver small(smem);
-    T* vecT = small.take<T>(geo.ld);
     double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
     Carver big(BIG ? scratch + (size_t)blockIdx.x * stride : small.p);
     T* ms = big.take<T>(cap);
@@ -454,9 +533,7 @@ __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int
         for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
         const T* xs = ms;
         if (HV) {
-            for (int t = tid; t < geo.ld; t += BLOCK) vecT[t] = U[(size_t)u * geo.ld + t];
-            __syncthreads();
-            block_sddmm<T, BLOCK>(A, vecT, S.sitem + s0, n, x, geo);
+            for (int p = tid; p < n; p += BLOCK) x[p] = bsrc[s0 + p];      // b = u_i . a_item, from k_sddmm
             xs = x;
         }
         __syncthreads();
@@ -480,74 +557,64 @@ __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int
 template <typename T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const int32_t* __restrict__ cuser,
                                                 const int32_t* __restrict__ crow, int64_t nnz, const T* __restrict__ U,
-                                                T* __restrict__ out, Geo geo, int chunk) {
+                                                T* __restrict__ out, Geo geo, int chunk, const int* skip) {
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
+    if (skip && *skip) return;
     const int G = geo.G, g = threadIdx.x & (G - 1);
     const int64_t gid = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / G;
     const int64_t z0 = gid * chunk;
     if (z0 >= nnz) return;
     const int64_t z1 = (z0 + chunk < nnz) ? z0 + chunk : nnz;
-    double acc[PCR_KMAX][VEC];
+    for (int k = 0; k * G < geo.nchunk; ++k) {
+        const int ch = g + k * G;
+        const bool act = ch < geo.nchunk;
+        double acc[VEC];
 #pragma unroll
-    for (int k = 0; k < PCR_KMAX; ++k)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[k][e] = 0.0;
-    int cur = crow[z0];
-    auto flush = [&](int j) {
-#pragma unroll
-        for (int k = 0; k < PCR_KMAX; ++k) {
-            const int ch = g + k * G;
-            if (ch < geo.nchunk) {
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
+        int cur = crow[z0];
+        auto flush = [&](int j) {
+            if (act) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    atomicAdd(out + (size_t)j * geo.ld + ch * VEC + e, (T)acc[k][e]);
-                    acc[k][e] = 0.0;
+                    atomicAdd(out + (size_t)j * geo.ld + ch * VEC + e, (T)acc[e]);
+                    acc[e] = 0.0;
                 }
             }
-        }
-    };
-    for (int64_t zb = z0; zb < z1; zb += G) {
-        const int64_t zi = zb + g;
-        T cr = (T)0;
-        int ur = 0, jr = 0;
-        if (zi < z1) { cr = c[zi]; ur = cuser[zi]; jr = crow[zi]; }
-        const int cnt = (int)((z1 - zb < G) ? (z1 - zb) : G);
-        for (int q = 0; q < cnt; q += 4) {
-            V rv[4][PCR_KMAX];
-            double cc[4];
-            int jj[4];
+        };
+        for (int64_t zb = z0; zb < z1; zb += G) {
+            const int64_t zi = zb + g;
+            T cr = (T)0;
+            int ur = 0, jr = 0;
+            if (zi < z1) { cr = c[zi]; ur = cuser[zi]; jr = crow[zi]; }
+            const int cnt = (int)((z1 - zb < G) ? (z1 - zb) : G);
+            for (int q = 0; q < cnt; q += PCR_UNR) {
+                V rv[PCR_UNR];
+                double cc[PCR_UNR];
+                int jj[PCR_UNR];
 #pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-                if (q + e4 < cnt) {
-                    cc[e4] = (double)__shfl(cr, q + e4, G);
-                    const int uu = __shfl(ur, q + e4, G);
-                    jj[e4] = __shfl(jr, q + e4, G);
-                    const T* rp = U + (size_t)uu * geo.ld;
-#pragma unroll
-                    for (int k = 0; k < PCR_KMAX; ++k) {
-                        const int ch = g + k * G;
-                        if (ch < geo.nchunk) rv[e4][k] = *reinterpret_cast<const V*>(rp + ch * VEC);
+                for (int e8 = 0; e8 < PCR_UNR; ++e8) {
+                    if (q + e8 < cnt) {
+                        cc[e8] = (double)__shfl(cr, q + e8, G);
+                        const int uu = __shfl(ur, q + e8, G);
+                        jj[e8] = __shfl(jr, q + e8, G);
+                        if (act) rv[e8] = *reinterpret_cast<const V*>(U + (size_t)uu * geo.ld + ch * VEC);
                     }
                 }
-            }
 #pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-                if (q + e4 < cnt) {
-                    if (jj[e4] != cur) { flush(cur); cur = jj[e4]; }
+                for (int e8 = 0; e8 < PCR_UNR; ++e8) {
+                    if (q + e8 < cnt) {
+                        if (jj[e8] != cur) { flush(cur); cur = jj[e8]; }
+                        if (act) {
 #pragma unroll
-                    for (int k = 0; k < PCR_KMAX; ++k) {
-                        const int ch = g + k * G;
-                        if (ch < geo.nchunk) {
-#pragma unroll
-                            for (int e = 0; e < VEC; ++e) acc[k][e] += cc[e4] * (double)velem(rv[e4][k], e);
+                            for (int e = 0; e < VEC; ++e) acc[e] += cc[e8] * (double)velem(rv[e8], e);
                         }
                     }
                 }
             }
         }
+        flush(cur);
     }
-    flush(cur);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -661,7 +728,7 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_a(const T* __restrict__ p, 
                                                         double lam_add, int64_t n, int per_block, double* __restrict__ part,
                                                         CGState* st) {
     __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
-    if (st->done) return;
+    if (st->done) return;     // CG already converged: later iterations are queued but idle
     const int64_t lo = (int64_t)blockIdx.x * per_block;
     const int64_t hi = (lo + per_block < n) ? lo + per_block : n;
     double x = 0.0, y = 0.0;
@@ -683,7 +750,7 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_b(const T* __restrict__ p, 
                                                         T* __restrict__ delta, int64_t n, int per_block, int nblk,
                                                         const double* __restrict__ partA, double* __restrict__ partB, CGState* st) {
     __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
-    if (st->done) return;
+    if (st->done) return;     // CG already converged: later iterations are queued but idle
     double pHp, rp;
     reduce_partials2(partA, nblk, &pHp, &rp, red);
     const double alpha = -1.0 * rp / pHp;
@@ -712,7 +779,7 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_c(T* __restrict__ p, T* __r
                                                         double hp_scale, int64_t n, int per_block, int nblk,
                                                         const double* __restrict__ partB, CGState* st) {
     __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
-    if (st->done) return;
+    if (st->done) return;     // CG already converged: later iterations are queued but idle
     double rr2, rHp;
     reduce_partials2(partB, nblk, &rr2, &rHp, red);
     const bool conv = sqrt(rr2) < st->err;                 // pcrpp.cpp:350
@@ -726,13 +793,10 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_c(T* __restrict__ p, T* __r
             Hp[i] = (T)(hp_scale * (double)pn);
         }
     }
-    // st->done is only written after every block has passed its `if (st->done)` read above:
-    // the flag is consumed by LATER kernels on the stream, never by blocks of this launch.
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { st->rr2 = rr2; st->rHp = rHp; st->beta = beta; }
-}
-// sets done after k_cg_c so that no block of k_cg_c can observe a half-updated flag
-__global__ void k_cg_mark(CGState* st) {
-    if (threadIdx.x == 0 && blockIdx.x == 0 && !st->done && sqrt(st->rr2) < st->err) st->done = 1;
+    // The host queues all 10 iterations without waiting; once `done` is set every later kernel of
+    // the solve returns at once.  Blocks of THIS launch may see the flag early: harmless, because a
+    // converged k_cg_c changes nothing anyway (conv is the same in every block).
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { st->rr2 = rr2; st->rHp = rHp; st->beta = beta; if (conv) st->done = 1; }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -896,7 +960,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
 // out4[u] = {err ratio, has pairs, ndcg, has ratings}
 // ---------------------------------------------------------------------------------------
 template <typename T>
-static inline size_t eval_bytes(int cap) { return carve_bytes(cap, sizeof(T)) + carve_bytes(cap, 8); }
+static inline size_t eval_bytes(int cap) { return carve_bytes(cap, sizeof(T)) + carve_bytes(cap, 8) + carve_bytes(cap, 4); }
 
 template <typename T, int BLOCK, bool BIG>
 __global__ __launch_bounds__(BLOCK) void k_eval(const int64_t* __restrict__ uptr, const int32_t* __restrict__ item,
@@ -914,6 +978,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval(const int64_t* __restrict__ uptr
     Carver big(BIG ? scratch + (size_t)blockIdx.x * stride : small.p);
     T* sc = big.take<T>(cap);
     double* vv = big.take<double>(cap);
+    int32_t* itm = big.take<int32_t>(cap);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
     for (int ui = blockIdx.x; ui < nusers; ui += gridDim.x) {
@@ -925,9 +990,9 @@ __global__ __launch_bounds__(BLOCK) void k_eval(const int64_t* __restrict__ uptr
             continue;
         }
         for (int t = tid; t < geo.ld; t += BLOCK) vecT[t] = U[(size_t)u * geo.ld + t];
-        for (int p = tid; p < n; p += BLOCK) vv[p] = val[s0 + p];
+        for (int p = tid; p < n; p += BLOCK) { vv[p] = val[s0 + p]; itm[p] = item[s0 + p]; }
         __syncthreads();
-        block_sddmm<T, BLOCK>(Vm, vecT, item + s0, n, sc, geo);
+        block_sddmm<T, BLOCK>(Vm, vecT, itm, n, sc, geo);
         __syncthreads();
         // ---- pairwise error
         unsigned long long bad = 0;
@@ -1020,11 +1085,8 @@ __global__ __launch_bounds__(256) void k_predict(const T* __restrict__ U, const 
     const T* up = U + (size_t)user[z] * geo.ld;
     const T* vp = Vm + (size_t)item[z] * geo.ld;
     T acc = (T)0;
-#pragma unroll
-    for (int k = 0; k < PCR_KMAX; ++k) {
-        const int ch = g + k * G;
-        if (ch < geo.nchunk) acc += vdot(*reinterpret_cast<const V*>(up + ch * VEC), *reinterpret_cast<const V*>(vp + ch * VEC));
-    }
+    for (int ch = g; ch < geo.nchunk; ch += G)
+        acc += vdot(*reinterpret_cast<const V*>(up + ch * VEC), *reinterpret_cast<const V*>(vp + ch * VEC));
     for (int off = G >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if (g == 0) pred[z] = (double)acc;
 }

@@ -75,10 +75,14 @@ struct Bin {
     std::vector<int32_t> users;
     DBuf<int32_t> d_users;
 };
-static const int BIN_LIMIT[3] = {256, 1024, 4096};
-static const int BIN_BLOCK[4] = {64, 256, 1024, 1024};
+// length classes: one wave for short users, 256 threads up to 512 ratings, 512 threads up to 4096
+// (all with the user's block in LDS), longer users through global scratch.  512 rather than 1024
+// threads for the top classes: k_ustep needs more than the 128 VGPRs a 512-thread block may use.
+static const int BIN_LIMIT[3] = {128, 512, 4096};
+static const int BIN_BLOCK[4] = {64, 256, 512, 512};
 
 struct ProfSlot {
+    int64_t seen = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double ms = 0.0;
     int64_t n = 0;
@@ -101,8 +105,10 @@ struct pcr_solver {
     virtual int sync() = 0;
     int64_t first_user = 0, n_users = 0, nnz_local = 0;
     bool prof_on = false;
+    int prof_period = 1;          // time every prof_period-th launch of each slot
     std::map<std::string, ProfSlot> prof;
     virtual int prof_resolve() = 0;
+    virtual void prof_prewarm(int n) = 0;
 };
 
 template <typename T>
@@ -112,15 +118,17 @@ struct Solver final : pcr_solver {
     int64_t d1 = 0, d2 = 0, tnnz_file = 0;
     Geo geo;
     hipStream_t st = nullptr;
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // length bins run concurrently
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     ncclComm_t comm = nullptr;
     int ncu = 256;
 
     // ---- training shard
     Shard<T> sh;
     DBuf<int64_t> d_uptr, d_runofs;
-    DBuf<int32_t> d_item, d_cpos, d_runstart, d_sitem, d_scsc, d_cuser, d_crow;
+    DBuf<int32_t> d_item, d_cpos, d_runstart, d_sitem, d_scsc, d_cuser, d_crow, d_ruser;
     DBuf<uint16_t> d_lvl, d_slvl;
-    DBuf<T> d_ms, d_c, d_mcsr;
+    DBuf<T> d_ms, d_c, d_mcsr, d_b;
     DBuf<double> d_objp;
     std::vector<Bin> bins;
     // ---- eval data (0 = train, 1 = test)
@@ -155,36 +163,51 @@ struct Solver final : pcr_solver {
     ~Solver() override {
         if (st) (void)hipStreamSynchronize(st);
         prof_resolve();
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         if (comm) ncclCommDestroy(comm);
         if (h_scal) (void)hipHostFree(h_scal);
         if (h_cg) (void)hipHostFree(h_cg);
         if (h_counters) (void)hipHostFree(h_counters);
+        for (int i = 0; i < 4; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (st) (void)hipStreamDestroy(st);
     }
 
     // ------------------------------------------------------------------------------ profiling
     struct ProfScope {
-        Solver* s; ProfSlot* slot = nullptr; hipEvent_t a = nullptr, b = nullptr;
-        ProfScope(Solver* s_, const std::string& name) : s(s_) {
+        Solver* s; ProfSlot* slot = nullptr; hipEvent_t a = nullptr, b = nullptr; hipStream_t q;
+        ProfScope(Solver* s_, const std::string& name, hipStream_t q_ = nullptr) : s(s_), q(q_ ? q_ : s_->st) {
             if (!s->prof_on) return;
-            slot = &s->prof[name];
-            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-            (void)hipEventRecord(a, s->st);
+            ProfSlot* sl = &s->prof[name];
+            if ((sl->seen++ % s->prof_period) != 0) return;       // sampled: an event pair costs ~3 us of queue time
+            slot = sl;
+            a = s->ev_get(); b = s->ev_get();
+            (void)hipEventRecord(a, q);
         }
         ~ProfScope() {
             if (!slot) return;
-            (void)hipEventRecord(b, s->st);
+            (void)hipEventRecord(b, q);
             slot->pending.emplace_back(a, b);
             slot->n += 1;
         }
     };
+    std::vector<hipEvent_t> ev_pool;      // timing events are recycled: creating one per launch costs more than the launch
+    hipEvent_t ev_get() {
+        if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void prof_prewarm(int n) override {
+        while ((int)ev_pool.size() < n) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) break; ev_pool.push_back(e); }
+    }
     int prof_resolve() override {
         for (auto& kv : prof) {
             for (auto& pr : kv.second.pending) {
                 float ms = 0.f;
                 (void)hipEventSynchronize(pr.second);
                 if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) kv.second.ms += ms;
-                (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+                ev_pool.push_back(pr.first); ev_pool.push_back(pr.second);
             }
             kv.second.pending.clear();
         }
@@ -222,6 +245,11 @@ struct Solver final : pcr_solver {
         HIPCHK(hipGetDeviceProperties(&prop, prm.device));
         ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < 4; ++i) {
+            HIPCHK(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+        }
 
         const PcrCsr& X = ds->train;
         d1 = X.d1; d2 = X.d2; tnnz_file = ds->tnnz_file;
@@ -231,7 +259,6 @@ struct Solver final : pcr_solver {
         geo.ld = (prm.k + 3) & ~3;
         geo.nchunk = geo.ld / VecOf<T>::N;
         geo.G = std::min(64, host_pow2(geo.nchunk));
-        if (geo.nchunk > 64 * PCR_KMAX) { pcr_set_error("rank too large for this build (ld/VEC > 256)"); return PCR_ERR_UNSUPPORTED; }
 
         std::vector<int64_t> bounds(nranks + 1);
         RC(pcr_partition_users(X.index.data(), d1, nranks, bounds.data()));
@@ -254,7 +281,9 @@ struct Solver final : pcr_solver {
         std::vector<int64_t> cptr(d2 + 1, 0);
         for (int64_t z = 0; z < nnz_local; ++z) cptr[item[z] + 1]++;
         for (int64_t j = 0; j < d2; ++j) cptr[j + 1] += cptr[j];
-        std::vector<int32_t> cpos(nnz_local), cuser(nnz_local), crow(nnz_local);
+        std::vector<int32_t> cpos(nnz_local), cuser(nnz_local), crow(nnz_local), ruser(nnz_local);
+        for (int64_t u = 0; u < nu; ++u)
+            for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) ruser[z] = (int32_t)u;
         {
             std::vector<int64_t> cur(cptr.begin(), cptr.end() - 1);
             for (int64_t u = 0; u < nu; ++u)
@@ -267,10 +296,10 @@ struct Solver final : pcr_solver {
         for (auto& b : bins) RC(b.d_users.upload(b.users, st));
 
         RC(d_uptr.upload(uptr, st)); RC(d_item.upload(item, st)); RC(d_lvl.upload(lv.level, st));
-        RC(d_cpos.upload(cpos, st)); RC(d_cuser.upload(cuser, st)); RC(d_crow.upload(crow, st));
+        RC(d_cpos.upload(cpos, st)); RC(d_cuser.upload(cuser, st)); RC(d_crow.upload(crow, st)); RC(d_ruser.upload(ruser, st));
         RC(d_runofs.upload(lv.run_ofs, st)); RC(d_runstart.upload(lv.run_start, st));
         RC(d_ms.alloc(nnz_local)); RC(d_sitem.alloc(nnz_local)); RC(d_slvl.alloc(nnz_local)); RC(d_scsc.alloc(nnz_local));
-        RC(d_c.alloc(nnz_local)); RC(d_objp.alloc(nu));
+        RC(d_c.alloc(nnz_local)); RC(d_objp.alloc(nu)); RC(d_mcsr.alloc(nnz_local)); RC(d_b.alloc(nnz_local));
         sh.nu = nu; sh.nnz = nnz_local; sh.d2 = (int)d2;
         sh.uptr = d_uptr.p; sh.item = d_item.p; sh.lvl = d_lvl.p; sh.cpos = d_cpos.p;
         sh.runofs = d_runofs.p; sh.runstart = d_runstart.p;
@@ -306,7 +335,7 @@ struct Solver final : pcr_solver {
         HIPCHK(hipMemsetAsync(d_U.p, 0, std::max<size_t>(nU, 1) * sizeof(T), st));
         HIPCHK(hipMemsetAsync(d_V.p, 0, std::max<size_t>(nV, 1) * sizeof(T), st));
         RC(d_cg.alloc(1));
-        ew_blocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, cdiv((int64_t)nV, 4096)));
+        ew_blocks = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv((int64_t)nV, 4096)));
         ew_per_block = cdiv((int64_t)nV, ew_blocks);
         RC(d_partA.alloc(4 * 2048)); RC(d_partB.alloc(4 * 2048)); RC(d_scal.alloc(64));
         RC(d_counters.alloc(4));
@@ -336,17 +365,39 @@ struct Solver final : pcr_solver {
         return PCR_OK;
     }
 
-    // opt in to > 64 KiB dynamic LDS for the 1024-thread instantiations
+    // opt in to > 64 KiB dynamic LDS for the 512-thread instantiations
     int set_lds_limits() {
         const int lim = 160 * 1024;
-        HIPCHK(hipFuncSetAttribute((const void*)k_prepare<T, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 1024, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        HIPCHK(hipFuncSetAttribute((const void*)k_eval<T, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_prepare<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 512, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 512, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_eval<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         return PCR_OK;
     }
 
+    // Launch one kernel per non-empty length bin, the bins concurrently: the largest bin stays on
+    // the solver's stream, the others fork to side streams and join back (events, no host sync).
+    template <class F>
+    int for_bins(std::vector<Bin>& bs, const char* cls, F launch) {
+        int main_bin = -1;
+        size_t most = 0;
+        for (size_t i = 0; i < bs.size(); ++i) if (bs[i].users.size() > most) { most = bs[i].users.size(); main_bin = (int)i; }
+        if (main_bin < 0) return PCR_OK;
+        bool forked = false;
+        for (size_t i = 0; i < bs.size(); ++i) {
+            if (bs[i].users.empty() || (int)i == main_bin) continue;
+            if (!forked) { HIPCHK(hipEventRecord(ev_fork, st)); forked = true; }
+            HIPCHK(hipStreamWaitEvent(side[i], ev_fork, 0));
+            { ProfScope ps(this, pname(cls, bs[i]), side[i]); launch(bs[i], side[i]); }
+            HIPCHK(hipEventRecord(ev_join[i], side[i]));
+        }
+        { ProfScope ps(this, pname(cls, bs[main_bin]), st); launch(bs[main_bin], st); }
+        for (size_t i = 0; i < bs.size(); ++i)
+            if (!bs[i].users.empty() && (int)i != main_bin) HIPCHK(hipStreamWaitEvent(st, ev_join[i], 0));
+        HIPCHK(hipGetLastError());
+        return PCR_OK;
+    }
     // profile slot of one kernel launch: "<class>/<workgroup size>[g]" (g = global-scratch variant)
     static std::string pname(const char* cls, const Bin& b) { return std::string(cls) + "/" + std::to_string(b.block) + (b.big ? "g" : ""); }
     size_t small_common(int block) const { return carve_bytes(geo.ld, sizeof(T)) + carve_bytes(block / PCR_WAVE + 1, 8); }
@@ -354,63 +405,72 @@ struct Solver final : pcr_solver {
 
     // ------------------------------------------------------------------------------ launches
     // m = V_I u, sort, per-user loss -> objp.  Vm = matrix the scores are taken against.
-    int launch_prepare(const T* Vm, T* m_csr) {
-        for (auto& b : bins) {
-            if (b.users.empty()) continue;
-            ProfScope ps(this, pname("prepare", b));
+    // out[z] = U[user(z)] . M[rows[z]] for all local ratings (rating-parallel, balanced)
+    int launch_sddmm(const T* M, const int32_t* rows, T* out, const int* skip = nullptr) {
+        if (nnz_local == 0) return PCR_OK;
+        ProfScope ps(this, "sddmm");
+        const int tile = 64, ngrp = 256 / geo.G, span = ngrp * tile;
+        const int grid = cdiv(nnz_local, span);
+        hipLaunchKernelGGL((k_sddmm<T, 256>), dim3(grid), dim3(256), (size_t)span * 8, st, d_U.p, M, d_ruser.p, rows, nnz_local, out, geo, tile, skip);
+        HIPCHK(hipGetLastError());
+        return PCR_OK;
+    }
+
+    int launch_prepare(const T* Vm) {
+        RC(launch_sddmm(Vm, d_item.p, d_mcsr.p));
+        auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
             const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
             const size_t bigb = prepare_bytes<T>(cap_pad, rsc, b.big ? 8 : 4);
             const size_t lds = small_common(b.block) + (b.big ? 0 : bigb);
             const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
-#define LP(BL, BG) hipLaunchKernelGGL((k_prepare<T, BL, BG>), dim3(grid), dim3(BL), lds, st, sh, geo, b.d_users.p, nus, d_U.p, Vm, m_csr, cap_pad, rsc, d_scratch.p, scratch_stride, strict())
-            if (b.big) LP(1024, true);
+#define LP(BL, BG) hipLaunchKernelGGL((k_prepare<T, BL, BG>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_mcsr.p, cap_pad, rsc, d_scratch.p, scratch_stride, strict())
+            if (b.big) LP(512, true);
             else if (b.block == 64) LP(64, false);
             else if (b.block == 256) LP(256, false);
-            else LP(1024, false);
+            else LP(512, false);
 #undef LP
-        }
-        HIPCHK(hipGetLastError());
+        };
+        RC(for_bins(bins, "prepare", fn));
         have_sorted = true;
         return PCR_OK;
     }
 
-    int launch_vsweep(bool hv, const T* A) {
-        for (auto& b : bins) {
-            if (b.users.empty()) continue;
-            ProfScope ps(this, pname(hv ? "vhv" : "vgrad", b));
+    int launch_vsweep(bool hv, const T* A, const int* skip = nullptr) {
+        if (hv) RC(launch_sddmm(A, d_sitem.p, d_b.p, skip));
+        auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
             const int rsc = b.max_lev + 2;
             const size_t bigb = vsweep_bytes<T>(b.cap, rsc);
             const size_t lds = small_common(b.block) + (b.big ? 0 : bigb);
             const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
-#define LV(BL, BG, HV) hipLaunchKernelGGL((k_vsweep<T, BL, BG, HV>), dim3(grid), dim3(BL), lds, st, sh, geo, b.d_users.p, nus, d_U.p, A, d_c.p, b.cap, rsc, d_scratch.p, scratch_stride, strict())
+#define LV(BL, BG, HV) hipLaunchKernelGGL((k_vsweep<T, BL, BG, HV>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, d_scratch.p, scratch_stride, strict(), skip)
             if (hv) {
-                if (b.big) LV(1024, true, true);
+                if (b.big) LV(512, true, true);
                 else if (b.block == 64) LV(64, false, true);
                 else if (b.block == 256) LV(256, false, true);
-                else LV(1024, false, true);
+                else LV(512, false, true);
             } else {
-                if (b.big) LV(1024, true, false);
+                if (b.big) LV(512, true, false);
                 else if (b.block == 64) LV(64, false, false);
                 else if (b.block == 256) LV(256, false, false);
-                else LV(1024, false, false);
+                else LV(512, false, false);
             }
 #undef LV
-        }
-        HIPCHK(hipGetLastError());
+        };
+        RC(for_bins(bins, hv ? "vhv" : "vgrad", fn));
         return PCR_OK;
     }
 
     // out += sum c * U-rows (item-major); out must hold its initial value already
-    int launch_spmm(T* out) {
+    int launch_spmm(T* out, const int* skip = nullptr) {
         ProfScope ps(this, "spmm");
         if (nnz_local > 0) {
             const int chunk = 128;
             const int64_t ngroups = (nnz_local + chunk - 1) / chunk;
             const int gpb = 256 / geo.G;
             const int grid = cdiv(ngroups, gpb);
-            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(grid), dim3(256), 0, st, d_c.p, d_cuser.p, d_crow.p, nnz_local, d_U.p, out, geo, chunk);
+            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(grid), dim3(256), 0, st, d_c.p, d_cuser.p, d_crow.p, nnz_local, d_U.p, out, geo, chunk, skip);
             HIPCHK(hipGetLastError());
         }
         return PCR_OK;
@@ -433,7 +493,7 @@ struct Solver final : pcr_solver {
 
     // deterministic sum of a double array into d_scal[slot] (two-stage)
     int reduce_sum(const double* in, int64_t n, int slot) {
-        const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, cdiv(n, 2048)));
+        const int nb = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv(n, 2048)));
         const int per = cdiv(std::max<int64_t>(n, 1), nb);
         hipLaunchKernelGGL(k_sum_stage1, dim3(nb), dim3(PCR_EW_BLOCK), 0, st, in, n, per, d_partA.p);
         hipLaunchKernelGGL(k_fin2, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + slot);
@@ -442,7 +502,7 @@ struct Solver final : pcr_solver {
     }
     // |a|^2 of a T array into d_scal[slot] (slot+1 receives dot(a,b) or 0)
     int norm2(const T* a, int64_t n, int slot) {
-        const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, cdiv(n, 4096)));
+        const int nb = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv(n, 4096)));
         const int per = cdiv(std::max<int64_t>(n, 1), nb);
         hipLaunchKernelGGL((k_dots<T>), dim3(nb), dim3(PCR_EW_BLOCK), 0, st, a, (const T*)nullptr, n, per, d_partB.p);
         hipLaunchKernelGGL(k_fin2, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partB.p, nb, d_scal.p + slot);
@@ -511,9 +571,8 @@ struct Solver final : pcr_solver {
 
     // ------------------------------------------------------------------------------ per-function ABI
     int comp_m(double* m_out) override {
-        T* mc = nullptr;
-        if (m_out) { if (d_mcsr.n < (size_t)nnz_local) RC(d_mcsr.alloc(nnz_local)); mc = d_mcsr.p; }
-        RC(launch_prepare(d_V.p, mc));
+        T* mc = d_mcsr.p;
+        RC(launch_prepare(d_V.p));
         if (m_out) {
             std::vector<T> tmp(nnz_local);
             if (nnz_local) HIPCHK(hipMemcpyAsync(tmp.data(), mc, nnz_local * sizeof(T), hipMemcpyDeviceToHost, st));
@@ -549,9 +608,9 @@ struct Solver final : pcr_solver {
         return download_mat(d_g.p, d2, g);
     }
     // Hp = lambda p + sum c(b) u, with Hp pre-initialised to hp_scale * p by the caller
-    int device_hv(const T* pvec, T* out) {
-        RC(launch_vsweep(true, pvec));
-        RC(launch_spmm(out));
+    int device_hv(const T* pvec, T* out, const int* skip = nullptr) {
+        RC(launch_vsweep(true, pvec, skip));
+        RC(launch_spmm(out, skip));
         RC(allreduce_T(out, (size_t)d2 * geo.ld));
         return PCR_OK;
     }
@@ -573,22 +632,21 @@ struct Solver final : pcr_solver {
             hipLaunchKernelGGL((k_cg_init<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_g.p, d_delta.p, d_rr.p, d_p.p, d_Hp.p, hp_scale, n, ew_per_block, d_partA.p);
             hipLaunchKernelGGL(k_cg_init_fin, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, ew_blocks, d_cg.p);
         }
-        int done = 0;
-        for (int k = 1; k <= 10 && !done; ++k) {
-            RC(device_hv(d_p.p, d_Hp.p));
+        // All 10 iterations are queued without a host round trip; once the device-side stop test
+        // (pcrpp.cpp:350) fires, the remaining kernels return immediately.  One sync at the end.
+        const int* skip = &d_cg.p->done;
+        for (int k = 1; k <= 10; ++k) {
+            RC(device_hv(d_p.p, d_Hp.p, skip));
             {
                 ProfScope ps(this, "cg");
                 hipLaunchKernelGGL((k_cg_a<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, 0.0, n, ew_per_block, d_partA.p, d_cg.p);
                 hipLaunchKernelGGL((k_cg_b<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, d_delta.p, n, ew_per_block, ew_blocks, d_partA.p, d_partB.p, d_cg.p);
                 hipLaunchKernelGGL((k_cg_c<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, hp_scale, n, ew_per_block, ew_blocks, d_partB.p, d_cg.p);
-                hipLaunchKernelGGL(k_cg_mark, dim3(1), dim3(64), 0, st, d_cg.p);
             }
             HIPCHK(hipGetLastError());
-            // the stop test needs the residual on the host; every rank sees the same replicated value
-            HIPCHK(hipMemcpyAsync(h_cg, d_cg.p, sizeof(CGState), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            done = h_cg->done;
         }
+        HIPCHK(hipMemcpyAsync(h_cg, d_cg.p, sizeof(CGState), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
         if (iters) *iters = h_cg->iters;
         return PCR_OK;
     }
@@ -602,7 +660,7 @@ struct Solver final : pcr_solver {
     // pcrpp.cpp:415-444
     int update_V(double* now_obj, int* info) override {
         int cg_iters = 0, tries = 0, accepted = 0;
-        RC(launch_prepare(d_V.p, nullptr));                        // comp_m_new (:417)
+        RC(launch_prepare(d_V.p));                        // comp_m_new (:417)
         double prev_obj = 0.0;
         RC(full_objective(d_V.p, &prev_obj));                      // objective_new(m, U, V) (:425); m is the same
         RC(device_gradient());                                     // obtain_g_new (:418)
@@ -611,7 +669,7 @@ struct Solver final : pcr_solver {
         const int64_t n = (int64_t)d2 * geo.ld;
         for (int it = 0; it < 20; ++it) {                          // :427-441
             hipLaunchKernelGGL((k_axpy_out<T>), dim3(cdiv(n, 256)), dim3(256), 0, st, d_Vnew.p, d_V.p, d_delta.p, -step, n);
-            RC(launch_prepare(d_Vnew.p, nullptr));
+            RC(launch_prepare(d_Vnew.p));
             RC(full_objective(d_Vnew.p, &obj));
             ++tries;
             if (obj < prev_obj) {
@@ -629,21 +687,19 @@ struct Solver final : pcr_solver {
 
     int launch_ustep() {
         HIPCHK(hipMemsetAsync(d_counters.p, 0, 4 * sizeof(unsigned long long), st));
-        for (auto& b : bins) {
-            if (b.users.empty()) continue;
-            ProfScope ps(this, pname("ustep", b));
+        auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
             const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
             const size_t lds = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + (b.big ? 0 : ustep_big_bytes<T>(cap_pad, rsc, 4));
             const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
-#define LU(BL, BG) hipLaunchKernelGGL((k_ustep<T, BL, BG>), dim3(grid), dim3(BL), lds, st, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, strict(), strict(), cap_pad, rsc, d_scratch.p, scratch_stride, d_counters.p)
-            if (b.big) LU(1024, true);
+#define LU(BL, BG) hipLaunchKernelGGL((k_ustep<T, BL, BG>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, strict(), strict(), cap_pad, rsc, d_scratch.p, scratch_stride, d_counters.p)
+            if (b.big) LU(512, true);
             else if (b.block == 64) LU(64, false);
             else if (b.block == 256) LU(256, false);
-            else LU(1024, false);
+            else LU(512, false);
 #undef LU
-        }
-        HIPCHK(hipGetLastError());
+        };
+        RC(for_bins(bins, "ustep", fn));
         return PCR_OK;
     }
 
@@ -687,22 +743,21 @@ struct Solver final : pcr_solver {
         }
         // dcg uses gain/discount products in the reference's order: gain / log2(k+1); keep the division exact
         {
-            ProfScope ps(this, "eval");
             const int64_t* up = which == 0 ? d_uptr.p : es.uptr.p;
             const int32_t* it = which == 0 ? d_item.p : es.item.p;
-            for (auto& b : es.bins) {
-                if (b.users.empty()) continue;
+            auto fn = [&](Bin& b, hipStream_t q) {
                 const int nus = (int)b.users.size();
                 const size_t smallb = small_common(b.block) + carve_bytes(b.block / PCR_WAVE + 1, sizeof(T)) + carve_bytes(b.block / PCR_WAVE + 1, 4);
                 const size_t lds = smallb + (b.big ? 0 : eval_bytes<T>(b.cap));
                 const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
-#define LE(BL, BG) hipLaunchKernelGGL((k_eval<T, BL, BG>), dim3(grid), dim3(BL), lds, st, up, it, es.val.p, es.gain.p, es.idcg.p, es.disc.p, ndcg_k, b.d_users.p, nus, d_U.p, d_V.p, geo, d_out4.p, b.cap, d_scratch.p, scratch_stride)
-                if (b.big) LE(1024, true);
+#define LE(BL, BG) hipLaunchKernelGGL((k_eval<T, BL, BG>), dim3(grid), dim3(BL), lds, q, up, it, es.val.p, es.gain.p, es.idcg.p, es.disc.p, ndcg_k, b.d_users.p, nus, d_U.p, d_V.p, geo, d_out4.p, b.cap, d_scratch.p, scratch_stride)
+                if (b.big) LE(512, true);
                 else if (b.block == 64) LE(64, false);
                 else if (b.block == 256) LE(256, false);
-                else LE(1024, false);
+                else LE(512, false);
 #undef LE
-            }
+            };
+            RC(for_bins(es.bins, "eval", fn));
             const int nb = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv(n_users, 2048)));
             const int per = cdiv(std::max<int64_t>(n_users, 1), nb);
             hipLaunchKernelGGL(k_sum4_stage1, dim3(nb), dim3(PCR_EW_BLOCK), 0, st, d_out4.p, n_users, per, d_partA.p);
@@ -737,7 +792,7 @@ struct Solver final : pcr_solver {
             return PCR_OK;
         };
         double now_obj = 0.0;
-        RC(launch_prepare(d_V.p, nullptr));                          // :857
+        RC(launch_prepare(d_V.p));                          // :857
         RC(full_objective(d_V.p, &now_obj));                         // :858
         cur.obj = now_obj;
         snprintf(line, sizeof line, "Iter 0 time 0 obj %g", now_obj); emit(line);
@@ -833,11 +888,11 @@ int pcr_evaluate(pcr_solver* s, int which, int ndcg_k, double* e, double* n) { S
 int pcr_train(pcr_solver* s, pcr_log_fn log, void* ctx, pcr_iter_stats* hist) { S_OR_ARG; return s->train(log, ctx, hist); }
 int pcr_solver_sync(pcr_solver* s) { S_OR_ARG; return s->sync(); }
 
-int pcr_profile_enable(pcr_solver* s, int on) { S_OR_ARG; s->prof_on = on != 0; return PCR_OK; }
+int pcr_profile_enable(pcr_solver* s, int on) { S_OR_ARG; s->prof_on = on != 0; s->prof_period = on > 1 ? on : 1; if (on) s->prof_prewarm(4096); return PCR_OK; }
 int pcr_profile_reset(pcr_solver* s) {
     S_OR_ARG;
     s->sync(); s->prof_resolve();
-    for (auto& kv : s->prof) { kv.second.ms = 0.0; kv.second.n = 0; }
+    for (auto& kv : s->prof) { kv.second.ms = 0.0; kv.second.n = 0; kv.second.seen = 0; }
     return PCR_OK;
 }
 int pcr_profile_list(pcr_solver* s, char* buf, int64_t cap) {
@@ -867,7 +922,6 @@ int pcr_predict(const double* U, int64_t d1, const double* V, int64_t d2, int64_
         if (user[z] < 0 || user[z] >= d1 || item[z] < 0 || item[z] >= d2) { pcr_set_error("pair " + std::to_string(z) + " outside the model"); return PCR_ERR_ARG; }
     Geo geo;
     geo.r = (int)k; geo.ld = ((int)k + 3) & ~3; geo.nchunk = geo.ld / 2; geo.G = std::min(64, host_pow2(geo.nchunk));
-    if (geo.nchunk > 64 * PCR_KMAX) { pcr_set_error("rank too large"); return PCR_ERR_UNSUPPORTED; }
     // the model file holds fp64 factors: score in fp64 like pmf-predict.cpp:58-62
     std::vector<double> Up((size_t)d1 * geo.ld, 0.0), Vp((size_t)d2 * geo.ld, 0.0);
     for (int64_t i = 0; i < d1; ++i) for (int64_t j = 0; j < k; ++j) Up[i * geo.ld + j] = U[i * k + j];

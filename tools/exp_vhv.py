@@ -1,0 +1,13 @@
+import sys, os, numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import primalcr_amd as pcr
+from primalcr_amd import synth
+R = synth.generate("ml1m"); ds = pcr.Dataset.from_ratings(R)
+s = pcr.Solver(ds, pcr.Parameter(k=100, **{"lambda": 5000.0}))
+s.set_factors(pcr.initial(R.d1,100), pcr.initial(R.d2,100))
+s.comp_m(want=False)
+a = np.random.default_rng(0).normal(size=(R.d2,100))
+s.compute_Ha(a)
+s.profile(True); s.profile_reset()
+for _ in range(10): s.compute_Ha(a)
+for k,(ms,n) in sorted(s.profile_all().items()): print(f"{os.environ.get('PCR_DBG','0'):>3s} {k:12s} {1e3*ms/n:8.1f} us")
