@@ -54,6 +54,13 @@ struct Shard {
     uint16_t* slvl;            // nnz
     int32_t* scsc;             // nnz    CSC position at sorted position
     double* objp;              // nu     per-user loss partial
+    // window cache: for sorted position p and every OTHER level l' (slot = l' < l ? l' : l'-1) the
+    // boundary index of the active prefix / suffix of run l'.  Depends on m only, so k_prepare
+    // finds it once and every sweep of the V step (gradient + <=10 Hessian-vector products) and of
+    // the U step (gradient, objective, CG) reuses it.  ws = slots per item (0 = cache disabled:
+    // too many levels; the sweeps then search).
+    uint32_t* win;             // nnz * ws
+    int ws;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -192,6 +199,60 @@ __device__ __forceinline__ double sweep_coeff(const T* ms, const double* S, cons
         }
     }
     return 2.0 * acc;
+}
+
+// boundaries of item (lev, mp) in every other run -> w[slot]
+template <typename T>
+__device__ __forceinline__ void find_windows(const T* ms, const int* rs, int nlev, int lev, T mp, int strict, uint32_t* w) {
+    const T lo = mp - (T)1, hi = mp + (T)1;
+    for (int l = 0; l < nlev; ++l) {
+        if (l == lev) continue;
+        const int s = rs[l], e = rs[l + 1];
+        if (l < lev) w[l] = (uint32_t)(strict ? ubound(ms, s, e, lo) : lbound(ms, s, e, lo));
+        else w[l - 1] = (uint32_t)(strict ? lbound(ms, s, e, hi) : ubound(ms, s, e, hi));
+    }
+}
+
+// sweep_coeff with cached boundaries (w: ws slots of this item)
+__device__ __forceinline__ double sweep_coeff_win(const uint32_t* __restrict__ w, const double* S, const int* rs, int nlev,
+                                                  int lev, double xp, double shift) {
+    double acc = 0.0;
+    for (int l = 0; l < lev; ++l) {
+        const int wi = (int)w[l], e = rs[l + 1];
+        acc += (double)(e - wi) * (xp - shift) - (S[e] - S[wi]);
+    }
+    for (int l = lev + 1; l < nlev; ++l) {
+        const int wi = (int)w[l - 1], s0 = rs[l];
+        acc += (double)(wi - s0) * (xp + shift) - (S[wi] - S[s0]);
+    }
+    return 2.0 * acc;
+}
+
+// block_objective with cached boundaries (win: the user's window rows, ws slots each)
+template <typename T, int BLOCK, class LevF>
+__device__ __forceinline__ double block_objective_win(const T* ms, LevF levf, const int* rs, int nlev, int n,
+                                                      const uint32_t* __restrict__ win, int ws, double* S, double* red) {
+    const int tid = threadIdx.x;
+    double part = 0.0;
+    block_excl_scan<BLOCK>([&](int i) { return (double)ms[i] - 1.0; }, S, n, red);
+    for (int p = tid; p < n; p += BLOCK) {
+        const int lev = levf(p);
+        const double m = (double)ms[p];
+        const uint32_t* w = win + (size_t)p * ws;
+        for (int l = lev + 1; l < nlev; ++l) {
+            const int s0 = rs[l], wi = (int)w[l - 1];
+            part += (double)(wi - s0) * m * m - 2.0 * m * (S[wi] - S[s0]);
+        }
+    }
+    __syncthreads();
+    block_excl_scan<BLOCK>([&](int i) { double d = (double)ms[i] - 1.0; return d * d; }, S, n, red);
+    for (int p = tid; p < n; p += BLOCK) {
+        const int lev = levf(p);
+        const uint32_t* w = win + (size_t)p * ws;
+        for (int l = lev + 1; l < nlev; ++l) part += S[w[l - 1]] - S[rs[l]];
+    }
+    __syncthreads();
+    return block_sum<BLOCK>(part, red);
 }
 
 // Loss of one user (pcrpp.cpp:392-407): sum over items p and higher levels l' of
@@ -492,7 +553,15 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const in
             S.sitem[s0 + p] = S.item[s0 + idx];
             S.scsc[s0 + p] = S.cpos[s0 + idx];
         }
-        double loss = block_objective<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, Sx, red, strict);
+        double loss;
+        if (S.ws) {
+            uint32_t* win = S.win + (size_t)s0 * S.ws;
+            for (int p = tid; p < n; p += BLOCK)
+                find_windows<T>(key, rs, nlev, (int)LiOps<LI>::lev(li[p]), key[p], strict, win + (size_t)p * S.ws);
+            loss = block_objective_win<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, win, S.ws, Sx, red);
+        } else {
+            loss = block_objective<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, Sx, red, strict);
+        }
         if (tid == 0) S.objp[u] = loss;
         __syncthreads();
     }
@@ -529,7 +598,7 @@ __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int
         const int n = (int)(S.uptr[u + 1] - s0);
         const int nlev = (int)(S.runofs[u + 1] - S.runofs[u]) - 1;
         if (n == 0) continue;
-        for (int p = tid; p < n; p += BLOCK) ms[p] = S.ms[s0 + p];
+        if (!HV || !S.ws) for (int p = tid; p < n; p += BLOCK) ms[p] = S.ms[s0 + p];
         for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
         const T* xs = ms;
         if (HV) {
@@ -540,7 +609,9 @@ __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int
         block_excl_scan<BLOCK>([&](int i) { return (double)xs[i]; }, Sx, n, red);
         for (int p = tid; p < n; p += BLOCK) {
             const int lev = S.slvl[s0 + p];
-            const double c = sweep_coeff<T>(ms, Sx, rs, nlev, lev, ms[p], (double)xs[p], HV ? 0.0 : 1.0, strict);
+            const double c = S.ws
+                ? sweep_coeff_win(S.win + (size_t)(s0 + p) * S.ws, Sx, rs, nlev, lev, (double)xs[p], HV ? 0.0 : 1.0)
+                : sweep_coeff<T>(ms, Sx, rs, nlev, lev, ms[p], (double)xs[p], HV ? 0.0 : 1.0, strict);
             c_csc[S.scsc[s0 + p]] = (T)c;
         }
         __syncthreads();
@@ -855,8 +926,10 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         __syncthreads();
         // ---- gradient coefficients, obtain_g_u_new (pcrpp.cpp:506-535)
         block_excl_scan<BLOCK>([&](int i) { return (double)ms0[i]; }, Sx, n, red);
+        const uint32_t* win = S.ws ? S.win + (size_t)s0 * S.ws : nullptr;       // windows of the gradient point
         for (int p = tid; p < n; p += BLOCK)
-            key[p] = (T)sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)ms0[p], 1.0, strict);
+            key[p] = (T)(win ? sweep_coeff_win(win + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)ms0[p], 1.0)
+                             : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)ms0[p], 1.0, strict));
         for (int t = tid; t < ld; t += BLOCK) gvec[t] = (n == 0) ? 0.0 : uvec[t] * lambda;   // :495-498
         __syncthreads();
         block_gather_axpy<T, T, BLOCK>(Vm, itm, key, n, gvec, wbuf, geo);
@@ -866,7 +939,8 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         gn2 = block_sum<BLOCK>(gn2, red);
         // ---- prev_obj, objective_u_new (pcrpp.cpp:542-573)
         const double prev_obj = lambda / 2.0 * un2 +
-            block_objective<T, BLOCK>(ms0, [&](int p) { return (int)lv0[p]; }, rs, nlev, n, Sx, red, strict);
+            (win ? block_objective_win<T, BLOCK>(ms0, [&](int p) { return (int)lv0[p]; }, rs, nlev, n, win, S.ws, Sx, red)
+                 : block_objective<T, BLOCK>(ms0, [&](int p) { return (int)lv0[p]; }, rs, nlev, n, Sx, red, strict));
         double obj_new = prev_obj;
         int n_cg = 0, n_ls = 0;
         // pcrpp.cpp:787-790; PrimalCR additionally keeps u when no comparable pair exists
@@ -886,7 +960,8 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                 __syncthreads();
                 block_excl_scan<BLOCK>([&](int i) { return (double)key[i]; }, Sx, n, red);
                 for (int p = tid; p < n; p += BLOCK)
-                    key[p] = (T)sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)key[p], 0.0, strict);
+                    key[p] = (T)(win ? sweep_coeff_win(win + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)key[p], 0.0)
+                                     : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)key[p], 0.0, strict));
                 __syncthreads();
                 block_gather_axpy<T, T, BLOCK>(Vm, itm, key, n, Hp, wbuf, geo);
                 ++n_cg;

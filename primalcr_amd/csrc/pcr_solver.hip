@@ -128,6 +128,7 @@ struct Solver final : pcr_solver {
     DBuf<int64_t> d_uptr, d_runofs;
     DBuf<int32_t> d_item, d_cpos, d_runstart, d_sitem, d_scsc, d_cuser, d_crow, d_ruser;
     DBuf<uint16_t> d_lvl, d_slvl;
+    DBuf<uint32_t> d_win;
     DBuf<T> d_ms, d_c, d_mcsr, d_b;
     DBuf<double> d_objp;
     std::vector<Bin> bins;
@@ -304,6 +305,11 @@ struct Solver final : pcr_solver {
         sh.uptr = d_uptr.p; sh.item = d_item.p; sh.lvl = d_lvl.p; sh.cpos = d_cpos.p;
         sh.runofs = d_runofs.p; sh.runstart = d_runstart.p;
         sh.ms = d_ms.p; sh.sitem = d_sitem.p; sh.slvl = d_slvl.p; sh.scsc = d_scsc.p; sh.objp = d_objp.p;
+        // window cache (pcr_kernels.h, Shard::win): one slot per other level, up to 9 levels
+        sh.ws = (lv.max_levels >= 2 && lv.max_levels <= 9) ? lv.max_levels - 1 : 0;
+        if (const char* e = getenv("PCR_NO_WINDOW_CACHE")) if (atoi(e)) sh.ws = 0;
+        RC(d_win.alloc((size_t)nnz_local * sh.ws));
+        sh.win = d_win.p;
 
         // ---- eval sets (train shard, test shard)
         for (int w = 0; w < 2; ++w) {
