@@ -128,6 +128,11 @@ void pcr_solver_destroy(pcr_solver *s);
  * (128 bytes), the host application broadcasts it, every rank calls comm_init. */
 int pcr_comm_unique_id(void *id128);                                       /* [device] */
 int pcr_solver_comm_init(pcr_solver *s, const void *id128);                /* [device] */
+/* Shard-local mode for a solver created with nranks > 1 and no communicator: every collective
+ * becomes a no-op, so pcr_obtain_g / pcr_compute_Ha / pcr_objective return THIS SHARD'S PARTIAL
+ * (rank 0 carries the lambda term).  Lets a host application combine shards itself, and lets one
+ * process verify the sharding of N ranks on a single GPU. */
+int pcr_solver_set_local_only(pcr_solver *s, int on);
 
 /* first local user and number of local users of this rank's shard */
 int pcr_solver_shard(const pcr_solver *s, int64_t *first_user, int64_t *n_users, int64_t *nnz_local);

@@ -79,6 +79,7 @@ def lib():
     L.pcr_solver_destroy.argtypes = [vp]
     L.pcr_comm_unique_id.argtypes = [vp]
     L.pcr_solver_comm_init.argtypes = [vp, vp]
+    L.pcr_solver_set_local_only.argtypes = [vp, ci]
     L.pcr_solver_shard.argtypes = [vp] + [C.POINTER(i64)] * 3
     L.pcr_solver_set_factors.argtypes = [vp, vp, vp]
     L.pcr_solver_get_factors.argtypes = [vp, vp, vp]
@@ -218,6 +219,9 @@ class Solver:
     def comm_init(self, uid: bytes):
         buf = C.create_string_buffer(uid, 128)
         _chk(lib().pcr_solver_comm_init(self._h, buf))
+
+    def set_local_only(self, on=True):
+        _chk(lib().pcr_solver_set_local_only(self._h, int(on)))
 
     def set_factors(self, U=None, V=None):
         U = None if U is None else np.ascontiguousarray(U, np.float64)

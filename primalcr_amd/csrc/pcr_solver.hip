@@ -105,6 +105,7 @@ struct pcr_solver {
     virtual int sync() = 0;
     int64_t first_user = 0, n_users = 0, nnz_local = 0;
     bool prof_on = false;
+    bool local_only = false;      // nranks > 1 without a communicator: entry points return this shard's partials
     int prof_period = 1;          // time every prof_period-th launch of each slot
     std::map<std::string, ProfSlot> prof;
     virtual int prof_resolve() = 0;
@@ -483,14 +484,14 @@ struct Solver final : pcr_solver {
     }
 
     int allreduce_T(T* buf, size_t count) {
-        if (nranks == 1) return PCR_OK;
+        if (nranks == 1 || local_only) return PCR_OK;
         if (!comm) { pcr_set_error("nranks > 1 but pcr_solver_comm_init was not called"); return PCR_ERR_STATE; }
         ProfScope ps(this, "allreduce");
         NCCLCHK(ncclAllReduce(buf, buf, count, sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, comm, st));
         return PCR_OK;
     }
     int allreduce_f64(double* buf, size_t count) {
-        if (nranks == 1) return PCR_OK;
+        if (nranks == 1 || local_only) return PCR_OK;
         if (!comm) { pcr_set_error("nranks > 1 but pcr_solver_comm_init was not called"); return PCR_ERR_STATE; }
         ProfScope ps(this, "allreduce");
         NCCLCHK(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, st));
@@ -874,6 +875,7 @@ int pcr_comm_unique_id(void* id128) {
 }
 #define S_OR_ARG if (!s) { pcr_set_error("null solver"); return PCR_ERR_ARG; }
 int pcr_solver_comm_init(pcr_solver* s, const void* id128) { S_OR_ARG; return s->comm_init(id128); }
+int pcr_solver_set_local_only(pcr_solver* s, int on) { S_OR_ARG; s->local_only = on != 0; return PCR_OK; }
 int pcr_solver_shard(const pcr_solver* s, int64_t* first_user, int64_t* n_users, int64_t* nnz_local) {
     S_OR_ARG;
     if (first_user) *first_user = s->first_user;

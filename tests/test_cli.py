@@ -1,0 +1,109 @@
+"""The drop-in CLIs primalcr_amd/bin/omp-pmf-train and omp-pmf-predict (pmf-train.cpp, pmf-predict.cpp).
+
+CPU part: usage text, exit codes, option handling and I/O failures (nothing reaches the GPU).
+GPU part (-m gpu): end-to-end runs against the golden stdout / model / predictions of the unmodified
+reference on the same data directories.
+"""
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, ROOT, load_golden
+from primalcr_amd import synth
+
+TRAIN = os.path.join(ROOT, "primalcr_amd", "bin", "omp-pmf-train")
+PREDICT = os.path.join(ROOT, "primalcr_amd", "bin", "omp-pmf-predict")
+NUM = r"[-+]?(?:\d+\.?\d*|\.\d+)(?:e[-+]?\d+)?"
+
+
+def run(cmd, cwd):
+    return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True)
+
+
+def test_usage_and_exit_codes(tmp_path):
+    r = run([TRAIN], tmp_path)                                    # pmf-train.cpp:115-116
+    assert r.returncode == 1 and r.stdout.startswith("Usage: omp-pmf-train [options] data_dir [model_filename]")
+    for flag in ("-s type", "-k rank", "-n threads", "-l lambda", "-t max_iter", "-p do_predict"):
+        assert flag in r.stdout
+    r = run([TRAIN, "-z", "3", "dir"], tmp_path)                  # pmf-train.cpp:104-107
+    assert r.returncode == 1 and "unknown option: -z" in r.stderr
+    r = run([TRAIN, "-k"], tmp_path)                              # option without value
+    assert r.returncode == 1
+    r = run([TRAIN, "-s", "7", "dir"], tmp_path)                  # pmf-train.cpp:331-333: message, exit 0
+    assert r.returncode == 0 and "wrong solver type (7)" in r.stderr
+    r = run([TRAIN, str(tmp_path / "missing_dir"), "m.model"], tmp_path)
+    assert r.returncode == 1 and "can't open" in r.stderr          # the reference segfaults here (util.cpp:10)
+    r = run([TRAIN, "data", str(tmp_path / "no" / "such" / "m.model")], tmp_path)
+    assert r.returncode == 1 and "can't open output file" in r.stderr   # pmf-train.cpp:254-258
+    r = run([PREDICT], tmp_path)
+    assert r.returncode == 1 and r.stdout.startswith("Usage: omp-pmf-predict test_file model output_file")
+    r = run([PREDICT, "nope", "m", "o"], tmp_path)
+    assert r.returncode == 1 and "can't open test file nope" in r.stderr
+
+
+def test_default_model_name_rule(tmp_path):
+    """pmf-train.cpp:120-133: model = basename(data_dir) + '.model' in cwd, trailing slashes stripped;
+    the model file is opened before the data is read (pmf-train.cpp:252-259)."""
+    r = run([TRAIN, "some/dir/mydata///"], tmp_path)
+    assert r.returncode == 1                                       # data dir does not exist ...
+    assert (tmp_path / "mydata.model").exists()                    # ... but the model file was created first
+
+
+def golden_dir(name, tmp_path):
+    g, meta = load_golden(name)
+    R = synth.Ratings(int(g["d1"]), int(g["d2"]), g["user"], g["item"], g["val"], g["tuser"], g["titem"], g["tval"])
+    return g, meta, synth.write_dir(R, str(tmp_path / "data"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", [2, 1])
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_train_cli_matches_reference_end_to_end(name, solver, tmp_path):
+    g, meta, d = golden_dir(name, tmp_path)
+    lam, r = float(g["lam"]), int(g["r"])
+    out = run([TRAIN, "-s", str(solver), "-k", str(r), "-n", "1", "-l", repr(lam), "-t", str(meta["iters"]), "--f64",
+               d, "m.model"], tmp_path)
+    assert out.returncode == 0, out.stderr
+    ours = [re.sub(r"time \S+", "time T", l) for l in out.stdout.strip().split("\n") if not l.startswith("Wall-time")]
+    theirs = [re.sub(r"time \S+", "time T", l) for l in meta[f"stdout_s{solver}"].strip().split("\n") if not l.startswith("Wall-time")]
+    assert len(ours) == len(theirs)
+    for a, b in zip(ours, theirs):
+        if a != b:
+            assert re.sub(NUM, "#", a) == re.sub(NUM, "#", b), (a, b)
+            assert np.allclose([float(x) for x in re.findall(NUM, a)], [float(x) for x in re.findall(NUM, b)], rtol=2e-5, atol=2e-6)
+    raw = open(tmp_path / "m.model", "rb").read()
+    assert len(raw) == meta[f"model_bytes_s{solver}"]
+    d1, k = struct.unpack("ll", raw[:16])
+    U = np.frombuffer(raw, np.float64, d1 * k, 16).reshape(d1, k)
+    off = 16 + 8 * d1 * k
+    d2, k2 = struct.unpack("ll", raw[off:off + 16])
+    V = np.frombuffer(raw, np.float64, d2 * k2, off + 16).reshape(d2, k2)
+    assert np.abs(U - g[f"cli_U_s{solver}"]).max() < 1e-6 * np.abs(U).max()
+    assert np.abs(V - g[f"cli_V_s{solver}"]).max() < 1e-6 * np.abs(V).max()
+    side = "U.txt" if solver == 2 else f"U{int(lam)}.txt"            # pmf-train.cpp:208, 277
+    assert (tmp_path / side).exists() and (tmp_path / side.replace("U", "V")).exists()
+    assert len(open(tmp_path / side).read().strip().split("\n")) == d1
+    # predict: one "%lf" per test line (pmf-predict.cpp:63)
+    p = run([PREDICT, os.path.join(d, "test.ratings"), "m.model", "pred.txt"], tmp_path)
+    assert p.returncode == 0, p.stderr
+    ours_p = np.array([float(x) for x in open(tmp_path / "pred.txt").read().split()])
+    ref_p = np.array([float(x) for x in meta[f"predict_s{solver}"].split()])
+    assert ours_p.shape == ref_p.shape and np.abs(ours_p - ref_p).max() < 2e-6
+
+
+@pytest.mark.gpu
+def test_train_cli_default_precision_quality(tmp_path):
+    """Default (fp32 storage) CLI run: NDCG / pairwise error lines within 1e-3 of the reference's."""
+    g, meta, d = golden_dir("mid5", tmp_path)
+    out = run([TRAIN, "-k", str(int(g["r"])), "-l", repr(float(g["lam"])), "-t", str(meta["iters"]), d], tmp_path)
+    assert out.returncode == 0, out.stderr
+    assert (tmp_path / "data.model").exists()
+    pat = r"^\((Training|Testing)\) pairwise error is (\S+) and ndcg is (\S+)$"
+    a = re.findall(pat, out.stdout, re.M); b = re.findall(pat, meta["stdout_s2"], re.M)
+    assert len(a) == len(b) > 0
+    for (t1, e1, n1), (t2, e2, n2) in zip(a, b):
+        assert t1 == t2 and abs(float(e1) - float(e2)) < 1e-3 and abs(float(n1) - float(n2)) < 1e-3

@@ -182,3 +182,64 @@ def test_real_valued_levels_and_zero_model(oracle):
     s.set_factors(np.zeros((R.d1, 8)), np.zeros((R.d2, 8)))
     s.comp_m(want=False)
     assert s.objective() == float(oracle.count_pairs(X)) == float(ds.count_pairs())
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_user_sharding_on_one_gpu(oracle, nranks):
+    """The N-rank user sharding verified in ONE process on one GPU (shard-local mode, host-side sums
+    stand in for the RCCL all-reduce): shard partials of m, objective, g, Ha add up to the single-rank
+    result, and every shard's U step reproduces its rows of the single-rank U step."""
+    R = synth.generate("small", seed=9)
+    r, lam = 12, 40.0
+    ds = pcr.Dataset.from_ratings(R)
+    U0, V0 = pcr.initial(R.d1, r) * 0.5, pcr.initial(R.d2, r) * 0.5
+    par = dict(k=r, precision=pcr.PCR_F64, **{"lambda": lam})
+    full = pcr.Solver(ds, pcr.Parameter(**par))
+    full.set_factors(U0, V0)
+    m_full = full.comp_m(); obj_full = full.objective(); g_full = full.obtain_g()
+    a = np.random.default_rng(1).normal(size=V0.shape)
+    Ha_full = full.compute_Ha(a)
+    full.update_U()
+    U_full, _ = full.get_factors()
+    shards = [pcr.Solver(ds, pcr.Parameter(**par), rank=q, nranks=nranks) for q in range(nranks)]
+    idx, _, _ = ds.csr(0)
+    bounds = pcr.partition_users(idx, nranks)
+    m_parts, g_sum, Ha_sum, obj_sum = [], 0.0, 0.0, 0.0
+    U_sh = np.zeros_like(U0)
+    for q, s in enumerate(shards):
+        assert (s.first_user, s.n_users) == (bounds[q], bounds[q + 1] - bounds[q])
+        s.set_local_only(True)
+        s.set_factors(U0, V0)
+        m_parts.append(s.comp_m())
+        obj_sum += s.objective()
+        g_sum = g_sum + s.obtain_g()
+        Ha_sum = Ha_sum + s.compute_Ha(a)
+        s.update_U()
+        Uq, _ = s.get_factors()
+        U_sh[s.first_user:s.first_user + s.n_users] = Uq[s.first_user:s.first_user + s.n_users]
+    assert np.array_equal(np.concatenate(m_parts), m_full)
+    # every shard adds lambda/2 |V|^2 to its local objective; count it once
+    obj_sum -= (nranks - 1) * lam / 2.0 * float((V0 ** 2).sum())
+    assert abs(obj_sum / obj_full - 1) < 1e-12
+    assert rel(g_sum, g_full) < 1e-12 and rel(Ha_sum, Ha_full) < 1e-12
+    assert rel(U_sh, U_full) < 1e-12
+
+
+def test_fp32_training_matches_reference_quality(oracle):
+    """North star: NDCG@10 / pairwise error of the fp32 path match the reference (its fp64 restatement,
+    same init, same iteration count) within fp32 tolerance -- 1e-3 -- and the objective
+    trajectory within 1e-3 relative."""
+    R = synth.generate("small", seed=17, d1=1500, d2=800, nnz=120000, mu=4.0, sigma=0.9)
+    r, lam, iters = 32, 200.0, 3
+    X = oracle.build_csr(R.d1, R.d2, R.user, R.item, R.val)
+    XT = oracle.build_csr_test(R.d1, R.d2, R.tuser, R.titem, R.tval)
+    U0, V0 = pcr.initial(R.d1, r), pcr.initial(R.d2, r)
+    _, _, ref = oracle.train(X, U0, V0, lam, iters, XT)
+    s = pcr.Solver(pcr.Dataset.from_ratings(R), pcr.Parameter(k=r, maxiter=iters, precision=pcr.PCR_F32, **{"lambda": lam}))
+    s.set_factors(U0, V0)
+    recs, _ = s.train()
+    for a, b in zip(recs, ref):
+        assert abs(a["obj"] / b["obj"] - 1) < 1e-3
+        for key in ("train_err", "train_ndcg", "test_err", "test_ndcg"):
+            assert abs(a[key] - b[key]) < 1e-3, (key, a[key], b[key])
+    assert [a["cg_v"] for a in recs] == [b["cg_v"] for b in ref]
