@@ -328,7 +328,7 @@ __device__ __forceinline__ T group_reduce8(const T (&a)[8], int g, int G) {
 
 template <typename T, int BLOCK>
 __device__ __forceinline__ void block_sddmm(const T* __restrict__ M, const T* vecT, const int32_t* rows, int n,
-                                            T* out, const Geo& geo) {
+                                            T* out, const Geo& geo, int r0 = 0) {      // rows [r0, n)
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     const int G = geo.G, g = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = BLOCK / G;
@@ -338,7 +338,7 @@ __device__ __forceinline__ void block_sddmm(const T* __restrict__ M, const T* ve
         const bool act = ch < geo.nchunk;
         V uv;
         if (act) uv = *reinterpret_cast<const V*>(vecT + ch * VEC);
-        for (int base = grp; base < n; base += ngrp * PCR_UNR) {
+        for (int base = r0 + grp; base < n; base += ngrp * PCR_UNR) {
             V rv[PCR_UNR];
 #pragma unroll
             for (int q = 0; q < PCR_UNR; ++q) {
@@ -366,11 +366,12 @@ __device__ __forceinline__ void block_sddmm(const T* __restrict__ M, const T* ve
     }
 }
 
-// outvec[0..ld) += sum_p c[p] * M[rows[p]]   (pcrpp.cpp:536, :622).  fp64 accumulation.
+// outvec[0..ld) += sum_{p in [r0,n)} c[p] * M[rows[p]]   (pcrpp.cpp:536, :622).  fp64 accumulation.
 // wbuf: LDS, (BLOCK/64) * ld doubles.  Ends with a barrier; outvec valid for all threads.
+// assign = true: outvec = sum (a partial, for the multi-workgroup exchange) instead of +=.
 template <typename T, typename CT, int BLOCK>
 __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const int32_t* rows, const CT* c, int n,
-                                                  double* outvec, double* wbuf, const Geo& geo) {
+                                                  double* outvec, double* wbuf, const Geo& geo, int r0 = 0, bool assign = false) {
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     const int G = geo.G, g = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = BLOCK / G;
@@ -381,7 +382,7 @@ __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const
         double acc[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
-        for (int base = grp; base < n; base += ngrp * PCR_UNR) {
+        for (int base = r0 + grp; base < n; base += ngrp * PCR_UNR) {
             V rv[PCR_UNR];
             double cc[PCR_UNR];
 #pragma unroll
@@ -417,7 +418,7 @@ __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const
     for (int t = threadIdx.x; t < geo.ld; t += BLOCK) {
         double sum = 0.0;
         for (int w = 0; w < BLOCK / PCR_WAVE; ++w) sum += wbuf[w * geo.ld + t];
-        outvec[t] += sum;
+        outvec[t] = assign ? sum : outvec[t] + sum;
     }
     __syncthreads();
 }
@@ -509,14 +510,15 @@ template <typename T, bool BIG> struct LiSel { typedef uint32_t type; };
 template <typename T> struct LiSel<T, true> { typedef uint64_t type; };
 
 template <typename T>
-static inline size_t prepare_bytes(int cap_pad, int rs_cap, int li_bytes) {
-    return carve_bytes(cap_pad, sizeof(T)) + carve_bytes(cap_pad, li_bytes) + carve_bytes(cap_pad + 1, 8) + carve_bytes(rs_cap, 4);
+static inline size_t prepare_bytes(int cap, int cap_pad, int rs_cap, int li_bytes) {
+    // only the sort arrays need the power-of-two padding
+    return carve_bytes(cap_pad, sizeof(T)) + carve_bytes(cap_pad, li_bytes) + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
 }
 
 template <typename T, int BLOCK, bool BIG>
 __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                    const T* __restrict__ m_in,
-                                                   int cap_pad, int rs_cap, char* scratch, size_t stride, int strict) {
+                                                   int cap, int cap_pad, int rs_cap, char* scratch, size_t stride, int strict) {
     typedef typename LiSel<T, BIG>::type LI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Carver small(smem);
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const in
     Carver big(BIG ? scratch + (size_t)blockIdx.x * stride : small.p);
     T* key = big.take<T>(cap_pad);
     LI* li = big.take<LI>(cap_pad);
-    double* Sx = big.take<double>(cap_pad + 1);
+    double* Sx = big.take<double>(cap + 1);
     int* rs = big.take<int>(rs_cap);
     const int tid = threadIdx.x;
 
@@ -871,26 +873,74 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_c(T* __restrict__ p, T* __r
 }
 
 // ---------------------------------------------------------------------------------------
+// Workgroup clusters for long users.  One workgroup is bound by one CU's gather bandwidth
+// (~50-70 GB/s), so a user with thousands of ratings is given K workgroups (on K CUs): every member
+// runs the SAME per-user program on the same data (scan, sweep, CG scalars, sort, line-search
+// decisions are recomputed redundantly and are bitwise identical, so the members never have to
+// agree on control flow), but each member gathers only its 1/K slice of the rows; slices of scores
+// and partial r-vectors are exchanged through global memory.
+// Hand-off protocol (cdna_hip_programming.md Guideline 16): plain stores -> every wave
+// s_waitcnt vmcnt(0) -> workgroup barrier -> lane 0: agent-scope release, vmcnt(0), relaxed agent
+// atomic add on the cluster's arrival counter -> relaxed poll (bounded, with s_sleep) -> agent-scope
+// acquire, vmcnt(0) -> workgroup barrier -> plain loads.  Placement-independent; the launch keeps
+// the grid <= one workgroup per CU so all members are co-resident.
+// ---------------------------------------------------------------------------------------
+struct ClusterBufs {
+    unsigned* bar;          // one arrival counter per cluster (zeroed before every launch)
+    char* xch;              // per cluster: 2 x cap_pad scores (T) + 2 x K x ld doubles
+    size_t xch_stride;
+};
+
+template <int K>
+__device__ __forceinline__ void cluster_barrier(unsigned* bar, unsigned& phase, unsigned long long* err) {
+    if (K == 1) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    phase += 1;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = phase * K;
+        unsigned spins = 0;
+        // bounded wait: a cluster that lost a member reports an error instead of hanging the GPU,
+        // and once any cluster has failed nobody waits any more
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+            if (spins > (1u << 21)) { atomicAdd(err, 1ull); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------
 // k_ustep: the whole per-user Newton step of update_u_new (pcrpp.cpp:779-815) in one
 // workgroup: gradient (obtain_g_u_new :493), objective (:542), <=10 CG iterations with
 // obtain_Hs_new (:576, :628), <=20 line-search evaluations each with a fresh sort (:794-813).
 // r-vectors live in LDS as fp64; the user's sorted item block lives in LDS (or scratch).
 // ---------------------------------------------------------------------------------------
 template <typename T>
-static inline size_t ustep_big_bytes(int cap_pad, int rs_cap, int li_bytes) {
-    return carve_bytes(cap_pad, sizeof(T)) * 2 + carve_bytes(cap_pad, 2) + carve_bytes(cap_pad, 4) + carve_bytes(cap_pad, li_bytes) +
-           carve_bytes(cap_pad + 1, 8) + carve_bytes(rs_cap, 4);
+static inline size_t ustep_big_bytes(int cap, int cap_pad, int rs_cap, int li_bytes) {
+    return carve_bytes(cap, sizeof(T)) + carve_bytes(cap_pad, sizeof(T)) + carve_bytes(cap, 2) + carve_bytes(cap, 4) +
+           carve_bytes(cap_pad, li_bytes) + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
 }
 static inline size_t ustep_small_bytes(int ld, int block, size_t elt) {
-    return carve_bytes(ld, elt) + carve_bytes(block / PCR_WAVE + 1, 8) + 7 * carve_bytes(ld, 8) +
+    return carve_bytes(ld, elt) + carve_bytes(block / PCR_WAVE + 1, 8) + 8 * carve_bytes(ld, 8) +
            carve_bytes((size_t)(block / PCR_WAVE) * ld, 8);
 }
+template <typename T>
+static inline size_t ustep_xch_bytes(int cap_pad, int ld, int K) {
+    return 2 * carve_bytes(cap_pad, sizeof(T)) + 2 * carve_bytes((size_t)K * ld, 8);
+}
 
-template <typename T, int BLOCK, bool BIG>
+template <typename T, int BLOCK, bool BIG, int K>
 __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                  T* __restrict__ U, const T* __restrict__ Vm, double lambda, double stepsize0,
-                                                 int strict, int solver1, int cap_pad, int rs_cap, char* scratch, size_t stride,
-                                                 unsigned long long* counters) {
+                                                 int strict, int solver1, int cap, int cap_pad, int rs_cap, char* scratch, size_t stride,
+                                                 unsigned long long* counters, ClusterBufs cb) {
     typedef typename LiSel<T, BIG>::type LI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Carver small(smem);
@@ -903,23 +953,61 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
     double* pv = small.take<double>(geo.ld);
     double* Hp = small.take<double>(geo.ld);
     double* unew = small.take<double>(geo.ld);
+    double* part = small.take<double>(geo.ld);
     double* wbuf = small.take<double>((size_t)(BLOCK / PCR_WAVE) * geo.ld);
     Carver big(BIG ? scratch + (size_t)blockIdx.x * stride : small.p);
-    T* ms0 = big.take<T>(cap_pad);
+    T* ms0 = big.take<T>(cap);
     T* key = big.take<T>(cap_pad);
-    uint16_t* lv0 = big.take<uint16_t>(cap_pad);
-    int32_t* itm = big.take<int32_t>(cap_pad);
+    uint16_t* lv0 = big.take<uint16_t>(cap);
+    int32_t* itm = big.take<int32_t>(cap);
     LI* li = big.take<LI>(cap_pad);
-    double* Sx = big.take<double>(cap_pad + 1);
+    double* Sx = big.take<double>(cap + 1);
     int* rs = big.take<int>(rs_cap);
     const int tid = threadIdx.x;
     const int ld = geo.ld;
+    // cluster geometry: member j of cluster cid gathers rows [r0, r1) of every user it works on
+    const int cid = blockIdx.x / K, mem = blockIdx.x % K, nclus = gridDim.x / K;
+    unsigned phase = 0, xs_par = 0, xv_par = 0;
+    unsigned* bar = (K > 1) ? cb.bar + cid : nullptr;
+    T *xs0 = nullptr, *xs1 = nullptr;
+    double *xv0 = nullptr, *xv1 = nullptr;
+    if (K > 1) {
+        Carver xc(cb.xch + (size_t)cid * cb.xch_stride);
+        xs0 = xc.take<T>(cap_pad); xs1 = xc.take<T>(cap_pad);
+        xv0 = xc.take<double>((size_t)K * ld); xv1 = xc.take<double>((size_t)K * ld);
+    }
+    // all members end up with the full score vector in key[0, n)
+    auto exchange_scores = [&](T* key, int n, int r0, int r1) {
+        if (K == 1) return;
+        T* buf = (xs_par & 1) ? xs1 : xs0; xs_par += 1;
+        // exchange buffers are re-used, and the per-XCD L2s are not coherent with each other: every
+        // store and load of handed-off bytes is agent-scope (sc1: write-through / L2-revalidated)
+        for (int p = r0 + tid; p < r1; p += BLOCK) __hip_atomic_store(buf + p, key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cluster_barrier<K>(bar, phase, counters + 3);
+        for (int p = tid; p < n; p += BLOCK) key[p] = __hip_atomic_load(buf + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    };
+    // vec += sum over members (fixed order) of their partial r-vectors
+    auto exchange_vector = [&](double* vec) {
+        if (K == 1) return;
+        double* buf = (xv_par & 1) ? xv1 : xv0; xv_par += 1;
+        for (int t = tid; t < ld; t += BLOCK)
+            __hip_atomic_store(buf + (size_t)mem * ld + t, part[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cluster_barrier<K>(bar, phase, counters + 3);
+        for (int t = tid; t < ld; t += BLOCK) {
+            double sum = 0.0;
+            for (int j = 0; j < K; ++j) sum += __hip_atomic_load(buf + (size_t)j * ld + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            vec[t] += sum;
+        }
+        __syncthreads();
+    };
 
-    for (int ui = blockIdx.x; ui < nusers; ui += gridDim.x) {
+    for (int ui = cid; ui < nusers; ui += nclus) {
         const int u = users[ui];
         const int64_t s0 = S.uptr[u];
         const int n = (int)(S.uptr[u + 1] - s0);
         const int nlev = (int)(S.runofs[u + 1] - S.runofs[u]) - 1;
+        const int r0 = (int)((int64_t)n * mem / K), r1 = (int)((int64_t)n * (mem + 1) / K);
         for (int t = tid; t < ld; t += BLOCK) uvec[t] = (double)U[(size_t)u * ld + t];
         for (int p = tid; p < n; p += BLOCK) { ms0[p] = S.ms[s0 + p]; lv0[p] = S.slvl[s0 + p]; itm[p] = S.sitem[s0 + p]; }
         for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
@@ -932,7 +1020,8 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                              : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)ms0[p], 1.0, strict));
         for (int t = tid; t < ld; t += BLOCK) gvec[t] = (n == 0) ? 0.0 : uvec[t] * lambda;   // :495-498
         __syncthreads();
-        block_gather_axpy<T, T, BLOCK>(Vm, itm, key, n, gvec, wbuf, geo);
+        if (K == 1) block_gather_axpy<T, T, BLOCK>(Vm, itm, key, n, gvec, wbuf, geo);
+        else { block_gather_axpy<T, T, BLOCK>(Vm, itm, key, r1, part, wbuf, geo, r0, true); exchange_vector(gvec); }
         double un2 = 0.0, gn2 = 0.0;
         for (int t = tid; t < ld; t += BLOCK) { un2 += uvec[t] * uvec[t]; gn2 += gvec[t] * gvec[t]; }
         un2 = block_sum<BLOCK>(un2, red);
@@ -956,14 +1045,16 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
             for (int k = 1; k <= 10; ++k) {
                 for (int t = tid; t < ld; t += BLOCK) { vecT[t] = (T)pv[t]; Hp[t] = pv[t] * lambda; }
                 __syncthreads();
-                block_sddmm<T, BLOCK>(Vm, vecT, itm, n, key, geo);             // b = V_I p  (:592-594)
+                block_sddmm<T, BLOCK>(Vm, vecT, itm, (K == 1) ? n : r1, key, geo, (K == 1) ? 0 : r0);   // b = V_I p  (:592-594)
                 __syncthreads();
+                exchange_scores(key, n, r0, r1);
                 block_excl_scan<BLOCK>([&](int i) { return (double)key[i]; }, Sx, n, red);
                 for (int p = tid; p < n; p += BLOCK)
                     key[p] = (T)(win ? sweep_coeff_win(win + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)key[p], 0.0)
                                      : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)key[p], 0.0, strict));
                 __syncthreads();
-                block_gather_axpy<T, T, BLOCK>(Vm, itm, key, n, Hp, wbuf, geo);
+                if (K == 1) block_gather_axpy<T, T, BLOCK>(Vm, itm, key, n, Hp, wbuf, geo);
+                else { block_gather_axpy<T, T, BLOCK>(Vm, itm, key, r1, part, wbuf, geo, r0, true); exchange_vector(Hp); }
                 ++n_cg;
                 double a = 0.0, b = 0.0;
                 for (int t = tid; t < ld; t += BLOCK) { a += pv[t] * Hp[t]; b += rr[t] * pv[t]; }
@@ -999,7 +1090,8 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                 }
                 nn = block_sum<BLOCK>(nn, red);
                 __syncthreads();
-                block_sddmm<T, BLOCK>(Vm, vecT, itm, n, key, geo);             // compute_mm_old (:728-744)
+                block_sddmm<T, BLOCK>(Vm, vecT, itm, (K == 1) ? n : r1, key, geo, (K == 1) ? 0 : r0);   // compute_mm_old (:728-744)
+                if (K > 1) { __syncthreads(); exchange_scores(key, n, r0, r1); }
                 for (int p = tid; p < npad; p += BLOCK) {
                     if (p < n) li[p] = LiOps<LI>::pack(lv0[p], (unsigned)p);
                     else { li[p] = LiOps<LI>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
@@ -1014,8 +1106,8 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
             }
         }
         __syncthreads();
-        for (int t = tid; t < ld; t += BLOCK) U[(size_t)u * ld + t] = (T)unew[t];
-        if (tid == 0) {
+        if (mem == 0) for (int t = tid; t < ld; t += BLOCK) U[(size_t)u * ld + t] = (T)unew[t];
+        if (tid == 0 && mem == 0) {
             S.objp[u] = obj_new;
             if (n_cg) atomicAdd(counters + 0, (unsigned long long)n_cg);
             if (n_ls) atomicAdd(counters + 1, (unsigned long long)n_ls);

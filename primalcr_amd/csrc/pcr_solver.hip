@@ -70,6 +70,7 @@ struct DBuf {
 struct Bin {
     int block = 64;
     bool big = false;
+    int K = 1;           // workgroups per user (k_ustep clusters)
     int cap = 0;         // longest user in the bin
     int max_lev = 0;
     std::vector<int32_t> users;
@@ -119,8 +120,9 @@ struct Solver final : pcr_solver {
     int64_t d1 = 0, d2 = 0, tnnz_file = 0;
     Geo geo;
     hipStream_t st = nullptr;
-    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // length bins run concurrently
-    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int NSIDE = 6;
+    hipStream_t side[NSIDE] = {};                                 // length bins run concurrently
+    hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {};
     ncclComm_t comm = nullptr;
     int ncu = 256;
 
@@ -133,6 +135,11 @@ struct Solver final : pcr_solver {
     DBuf<T> d_ms, d_c, d_mcsr, d_b;
     DBuf<double> d_objp;
     std::vector<Bin> bins;
+    std::vector<Bin> ubins;                      // U-step bins: an extra class, long users get workgroup clusters
+    DBuf<unsigned> d_bar;
+    DBuf<char> d_xch;
+    size_t xch_stride = 0;
+    int max_clusters = 1;
     // ---- eval data (0 = train, 1 = test)
     struct EvalSet {
         int64_t nnz = 0;
@@ -170,7 +177,7 @@ struct Solver final : pcr_solver {
         if (h_scal) (void)hipHostFree(h_scal);
         if (h_cg) (void)hipHostFree(h_cg);
         if (h_counters) (void)hipHostFree(h_counters);
-        for (int i = 0; i < 4; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
+        for (int i = 0; i < NSIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (st) (void)hipStreamDestroy(st);
     }
@@ -217,13 +224,17 @@ struct Solver final : pcr_solver {
     }
 
     // ------------------------------------------------------------------------------ setup
-    static void make_bins(const std::vector<int64_t>& uptr, int64_t nu, const std::vector<int64_t>* runofs, std::vector<Bin>& out) {
+    static void make_bins(const std::vector<int64_t>& uptr, int64_t nu, const std::vector<int64_t>* runofs, std::vector<Bin>& out,
+                          const std::vector<int>& limits = {BIN_LIMIT[0], BIN_LIMIT[1], BIN_LIMIT[2]},
+                          const std::vector<int>& blocks = {BIN_BLOCK[0], BIN_BLOCK[1], BIN_BLOCK[2], BIN_BLOCK[3]}) {
+        const int nb = (int)limits.size() + 1;
         out.clear();
-        out.resize(4);
-        for (int b = 0; b < 4; ++b) { out[b].block = BIN_BLOCK[b]; out[b].big = (b == 3); }
+        out.resize(nb);
+        for (int b = 0; b < nb; ++b) { out[b].block = blocks[b]; out[b].big = (b == nb - 1); }
         for (int64_t u = 0; u < nu; ++u) {
             int64_t len = uptr[u + 1] - uptr[u];
-            int b = len <= BIN_LIMIT[0] ? 0 : len <= BIN_LIMIT[1] ? 1 : len <= BIN_LIMIT[2] ? 2 : 3;
+            int b = 0;
+            while (b < nb - 1 && len > limits[b]) ++b;
             out[b].users.push_back((int32_t)u);
             out[b].cap = std::max<int>(out[b].cap, (int)len);
             if (runofs) out[b].max_lev = std::max<int>(out[b].max_lev, (int)((*runofs)[u + 1] - (*runofs)[u]) - 1);
@@ -248,7 +259,7 @@ struct Solver final : pcr_solver {
         ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NSIDE; ++i) {
             HIPCHK(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
         }
@@ -296,6 +307,20 @@ struct Solver final : pcr_solver {
         }
         make_bins(uptr, nu, &lv.run_ofs, bins);
         for (auto& b : bins) RC(b.d_users.upload(b.users, st));
+        // U step: users with more than 1024 ratings are bound by one CU's gather bandwidth -> clusters of 4 workgroups
+        make_bins(uptr, nu, &lv.run_ofs, ubins, {128, 512, 1024, 4096}, {64, 256, 512, 512, 512});
+        const int cluster_k = getenv("PCR_CLUSTER_K") ? atoi(getenv("PCR_CLUSTER_K")) : 4;
+        if (cluster_k == 4) { ubins[3].K = 4; ubins[4].K = 4; }
+        max_clusters = std::max(1, ncu / 4);
+        for (auto& b : ubins) RC(b.d_users.upload(b.users, st));
+        {
+            size_t need_x = 0;
+            for (auto& b : ubins)
+                if (b.K > 1 && !b.users.empty()) need_x = std::max(need_x, ustep_xch_bytes<T>(host_pow2(b.cap), geo.ld, b.K));
+            xch_stride = (need_x + 255) & ~(size_t)255;
+            RC(d_bar.alloc((size_t)max_clusters * ubins.size()));      // the bins run concurrently: one set per bin
+            RC(d_xch.alloc(xch_stride * (size_t)max_clusters * ubins.size()));
+        }
 
         RC(d_uptr.upload(uptr, st)); RC(d_item.upload(item, st)); RC(d_lvl.upload(lv.level, st));
         RC(d_cpos.upload(cpos, st)); RC(d_cuser.upload(cuser, st)); RC(d_crow.upload(crow, st)); RC(d_ruser.upload(ruser, st));
@@ -354,9 +379,9 @@ struct Solver final : pcr_solver {
         size_t need = 0;
         if (!bins[3].users.empty()) {
             int cp = host_pow2(bins[3].cap), rsc = bins[3].max_lev + 2;
-            need = std::max(need, prepare_bytes<T>(cp, rsc, 8));   // LI is 8 bytes in scratch
+            need = std::max(need, prepare_bytes<T>(cp, cp, rsc, 8));   // LI is 8 bytes in scratch
             need = std::max(need, vsweep_bytes<T>(bins[3].cap, rsc));
-            need = std::max(need, ustep_big_bytes<T>(cp, rsc, 8));
+            need = std::max(need, ustep_big_bytes<T>(cp, cp, rsc, 8));
         }
         for (int w = 0; w < 2; ++w)
             if (!ev[w].bins[3].users.empty()) need = std::max(need, eval_bytes<T>(ev[w].bins[3].cap));
@@ -364,7 +389,7 @@ struct Solver final : pcr_solver {
             scratch_stride = (need + 255) & ~(size_t)255;
             size_t nbig = bins[3].users.size();
             for (int w = 0; w < 2; ++w) nbig = std::max(nbig, ev[w].bins[3].users.size());
-            scratch_blocks = (int)std::min<size_t>(nbig, (size_t)ncu * 2);
+            scratch_blocks = (int)std::min<size_t>(std::max<size_t>(nbig * 4, 1), (size_t)ncu * 2);
             RC(d_scratch.alloc(scratch_stride * (size_t)scratch_blocks));
         }
         RC(set_lds_limits());
@@ -378,7 +403,8 @@ struct Solver final : pcr_solver {
         HIPCHK(hipFuncSetAttribute((const void*)k_prepare<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 512, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 512, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_eval<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         return PCR_OK;
     }
@@ -406,7 +432,7 @@ struct Solver final : pcr_solver {
         return PCR_OK;
     }
     // profile slot of one kernel launch: "<class>/<workgroup size>[g]" (g = global-scratch variant)
-    static std::string pname(const char* cls, const Bin& b) { return std::string(cls) + "/" + std::to_string(b.block) + (b.big ? "g" : ""); }
+    static std::string pname(const char* cls, const Bin& b) { return std::string(cls) + "/" + std::to_string(b.block) + (b.big ? "g" : "") + (b.K > 1 ? "c" : ""); }
     size_t small_common(int block) const { return carve_bytes(geo.ld, sizeof(T)) + carve_bytes(block / PCR_WAVE + 1, 8); }
     int strict() const { return prm.solver_type == PCR_SOLVER_PCR ? 1 : 0; }
 
@@ -416,7 +442,8 @@ struct Solver final : pcr_solver {
     int launch_sddmm(const T* M, const int32_t* rows, T* out, const int* skip = nullptr) {
         if (nnz_local == 0) return PCR_OK;
         ProfScope ps(this, "sddmm");
-        const int tile = 64, ngrp = 256 / geo.G, span = ngrp * tile;
+        static const int tile = getenv("PCR_SDDMM_TILE") ? atoi(getenv("PCR_SDDMM_TILE")) : 64;
+        const int ngrp = 256 / geo.G, span = ngrp * tile;
         const int grid = cdiv(nnz_local, span);
         hipLaunchKernelGGL((k_sddmm<T, 256>), dim3(grid), dim3(256), (size_t)span * 8, st, d_U.p, M, d_ruser.p, rows, nnz_local, out, geo, tile, skip);
         HIPCHK(hipGetLastError());
@@ -428,10 +455,10 @@ struct Solver final : pcr_solver {
         auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
             const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
-            const size_t bigb = prepare_bytes<T>(cap_pad, rsc, b.big ? 8 : 4);
+            const size_t bigb = prepare_bytes<T>(b.cap, cap_pad, rsc, b.big ? 8 : 4);
             const size_t lds = small_common(b.block) + (b.big ? 0 : bigb);
             const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
-#define LP(BL, BG) hipLaunchKernelGGL((k_prepare<T, BL, BG>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_mcsr.p, cap_pad, rsc, d_scratch.p, scratch_stride, strict())
+#define LP(BL, BG) hipLaunchKernelGGL((k_prepare<T, BL, BG>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_mcsr.p, b.cap, cap_pad, rsc, d_scratch.p, scratch_stride, strict())
             if (b.big) LP(512, true);
             else if (b.block == 64) LP(64, false);
             else if (b.block == 256) LP(256, false);
@@ -473,7 +500,7 @@ struct Solver final : pcr_solver {
     int launch_spmm(T* out, const int* skip = nullptr) {
         ProfScope ps(this, "spmm");
         if (nnz_local > 0) {
-            const int chunk = 128;
+            static const int chunk = getenv("PCR_SPMM_CHUNK") ? atoi(getenv("PCR_SPMM_CHUNK")) : 128;
             const int64_t ngroups = (nnz_local + chunk - 1) / chunk;
             const int gpb = 256 / geo.G;
             const int grid = cdiv(ngroups, gpb);
@@ -694,19 +721,25 @@ struct Solver final : pcr_solver {
 
     int launch_ustep() {
         HIPCHK(hipMemsetAsync(d_counters.p, 0, 4 * sizeof(unsigned long long), st));
+        HIPCHK(hipMemsetAsync(d_bar.p, 0, (size_t)max_clusters * ubins.size() * sizeof(unsigned), st));
         auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
             const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
-            const size_t lds = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + (b.big ? 0 : ustep_big_bytes<T>(cap_pad, rsc, 4));
-            const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
-#define LU(BL, BG) hipLaunchKernelGGL((k_ustep<T, BL, BG>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, strict(), strict(), cap_pad, rsc, d_scratch.p, scratch_stride, d_counters.p)
-            if (b.big) LU(512, true);
-            else if (b.block == 64) LU(64, false);
-            else if (b.block == 256) LU(256, false);
-            else LU(512, false);
+            const size_t lds = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + (b.big ? 0 : ustep_big_bytes<T>(b.cap, cap_pad, rsc, 4));
+            const size_t bi = (size_t)(&b - &ubins[0]);
+            ClusterBufs cb{d_bar.p + bi * max_clusters, d_xch.p + bi * max_clusters * xch_stride, xch_stride};
+            // clusters: grid <= one workgroup per CU so that every member of every cluster is resident
+            const int nclus = std::min(nus, max_clusters);
+            const int grid = b.K > 1 ? nclus * b.K : (b.big ? std::min(nus, scratch_blocks) : nus);
+#define LU(BL, BG, KK) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, strict(), strict(), b.cap, cap_pad, rsc, d_scratch.p, scratch_stride, d_counters.p, cb)
+            if (b.big) { if (b.K > 1) LU(512, true, 4); else LU(512, true, 1); }
+            else if (b.block == 64) LU(64, false, 1);
+            else if (b.block == 256) LU(256, false, 1);
+            else if (b.K > 1) LU(512, false, 4);
+            else LU(512, false, 1);
 #undef LU
         };
-        RC(for_bins(bins, "ustep", fn));
+        RC(for_bins(ubins, "ustep", fn));
         return PCR_OK;
     }
 
@@ -722,6 +755,7 @@ struct Solver final : pcr_solver {
         HIPCHK(hipMemcpyAsync(h_counters, d_counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         RC(fetch_scal(4));
         if (now_obj) *now_obj = h_scal[0] + prm.lambda / 2.0 * h_scal[2];   // :835
+        if (h_counters[3] != 0) { pcr_set_error("k_ustep: a workgroup cluster timed out at a hand-off (members not co-resident?)"); return PCR_ERR_DEVICE; }
         if (info) { info[0] = (int64_t)h_counters[0]; info[1] = (int64_t)h_counters[1]; }
         return PCR_OK;
     }

@@ -1,5 +1,5 @@
 import sys, os, numpy as np
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import primalcr_amd as pcr
 from primalcr_amd import synth
 R = synth.generate("ml1m"); ds = pcr.Dataset.from_ratings(R)
@@ -9,5 +9,6 @@ s.comp_m(want=False)
 a = np.random.default_rng(0).normal(size=(R.d2,100))
 s.compute_Ha(a)
 s.profile(True); s.profile_reset()
-for _ in range(10): s.compute_Ha(a)
-for k,(ms,n) in sorted(s.profile_all().items()): print(f"{os.environ.get('PCR_DBG','0'):>3s} {k:12s} {1e3*ms/n:8.1f} us")
+for _ in range(20): s.compute_Ha(a)
+tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("PCR_"))
+print(tag, " ".join(f"{k}:{1e3*ms/n:.1f}" for k,(ms,n) in sorted(s.profile_all().items())))
