@@ -326,35 +326,59 @@ __device__ __forceinline__ T group_reduce8(const T (&a)[8], int g, int G) {
     return d;
 }
 
+// same for 4 values (G = 4 .. 64): returns the total of row rho4(g) = 2*(g&1) + ((g>>1)&1)
+template <typename T>
+__device__ __forceinline__ T group_reduce4(const T (&a)[4], int g, int G) {
+    T b[2], d;
+    const bool b0 = g & 1, b1 = g & 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const T send = b0 ? a[i] : a[i + 2], keep = b0 ? a[i + 2] : a[i];
+        b[i] = keep + __shfl_xor(send, 1);
+    }
+    {
+        const T send = b1 ? b[0] : b[1], keep = b1 ? b[1] : b[0];
+        d = keep + __shfl_xor(send, 2);
+    }
+    if (G > 4) d += __shfl_xor(d, 4);
+    if (G > 8) d += __shfl_xor(d, 8);
+    if (G > 16) d += __shfl_xor(d, 16);
+    if (G > 32) d += __shfl_xor(d, 32);
+    return d;
+}
+
+// The per-user (workgroup) primitives keep 4 rows in flight per lane group: k_ustep is register-bound
+// (occupancy), and its many resident waves provide the memory-level parallelism instead.
+#define PCR_BUNR 4
 template <typename T, int BLOCK>
 __device__ __forceinline__ void block_sddmm(const T* __restrict__ M, const T* vecT, const int32_t* rows, int n,
                                             T* out, const Geo& geo, int r0 = 0) {      // rows [r0, n)
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     const int G = geo.G, g = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = BLOCK / G;
-    const int rho = 4 * (g & 1) + (g & 2) + ((g >> 2) & 1);
+    const int rho = 2 * (g & 1) + ((g >> 1) & 1);
     for (int k = 0; k * G < geo.nchunk; ++k) {
         const int ch = g + k * G;
         const bool act = ch < geo.nchunk;
         V uv;
         if (act) uv = *reinterpret_cast<const V*>(vecT + ch * VEC);
-        for (int base = r0 + grp; base < n; base += ngrp * PCR_UNR) {
-            V rv[PCR_UNR];
+        for (int base = r0 + grp; base < n; base += ngrp * PCR_BUNR) {
+            V rv[PCR_BUNR];
 #pragma unroll
-            for (int q = 0; q < PCR_UNR; ++q) {
+            for (int q = 0; q < PCR_BUNR; ++q) {
                 const int row = base + q * ngrp;
                 if (row < n && act) rv[q] = *reinterpret_cast<const V*>(M + (size_t)rows[row] * geo.ld + ch * VEC);
             }
-            T part[PCR_UNR];
+            T part[PCR_BUNR];
 #pragma unroll
-            for (int q = 0; q < PCR_UNR; ++q) part[q] = (act && base + q * ngrp < n) ? vdot(rv[q], uv) : (T)0;
-            if (G >= 8) {
-                const T tot = group_reduce8<T>(part, g, G);          // whole lane groups are active here
+            for (int q = 0; q < PCR_BUNR; ++q) part[q] = (act && base + q * ngrp < n) ? vdot(rv[q], uv) : (T)0;
+            if (G >= 4) {
+                const T tot = group_reduce4<T>(part, g, G);          // whole lane groups are active here
                 const int row = base + rho * ngrp;
-                if (g < 8 && row < n) out[row] = (k == 0) ? tot : out[row] + tot;
+                if (g < 4 && row < n) out[row] = (k == 0) ? tot : out[row] + tot;
             } else {
 #pragma unroll
-                for (int q = 0; q < PCR_UNR; ++q) {
+                for (int q = 0; q < PCR_BUNR; ++q) {
                     T v = part[q];
                     if (G > 2) v += __shfl_xor(v, 2);
                     if (G > 1) v += __shfl_xor(v, 1);
@@ -382,11 +406,11 @@ __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const
         double acc[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
-        for (int base = r0 + grp; base < n; base += ngrp * PCR_UNR) {
-            V rv[PCR_UNR];
-            double cc[PCR_UNR];
+        for (int base = r0 + grp; base < n; base += ngrp * PCR_BUNR) {
+            V rv[PCR_BUNR];
+            double cc[PCR_BUNR];
 #pragma unroll
-            for (int q = 0; q < PCR_UNR; ++q) {
+            for (int q = 0; q < PCR_BUNR; ++q) {
                 const int row = base + q * ngrp;
                 cc[q] = 0.0;
                 if (row < n && act) {
@@ -395,7 +419,7 @@ __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const
                 }
             }
 #pragma unroll
-            for (int q = 0; q < PCR_UNR; ++q) {
+            for (int q = 0; q < PCR_BUNR; ++q) {
                 const int row = base + q * ngrp;
                 if (row < n && act) {
 #pragma unroll
