@@ -51,19 +51,47 @@ def algorithmic_bytes(slot, nnz_b, nu_b, d2, r, esz):
     F_U = nu_b * r * esz           # the bin's user factors
     F_V = d2 * r * esz             # one item-side matrix
     cls = slot.split("/")[0]
-    if cls == "prepare":           # comp_m + sort + objective: read item,lvl,cpos,uptr,U,V; write ms,sitem,slvl,scsc,objp
-        return nnz_b * (4 + 2 + 4) + nu_b * 16 + F_U + F_V + nnz_b * (esz + 4 + 2 + 4) + nu_b * 8
-    if cls == "vgrad":             # read ms,slvl,scsc; write c
-        return nnz_b * (esz + 2 + 4) + nu_b * 16 + nnz_b * esz
-    if cls == "vhv":               # read ms,sitem,slvl,scsc,U,a; write c
-        return nnz_b * (esz + 4 + 2 + 4) + nu_b * 16 + F_U + F_V + nnz_b * esz
-    if cls == "ustep":             # read ms,sitem,slvl,U,V; write U,objp
-        return nnz_b * (esz + 4 + 2) + nu_b * 16 + 2 * F_U + F_V + nu_b * 8
-    if cls == "spmm":              # read c,cuser,crow,U; read+write out
-        return nnz_b * (esz + 4 + 4) + F_U + 2 * F_V
-    if cls == "sddmm":             # read item,ruser,U,M; write one score per rating
+    if cls == "sddmm":             # k_sddmm: read item ids, user ids, U, one item-side matrix; write one score per rating
         return nnz_b * (4 + 4 + esz) + F_U + F_V
+    if cls == "prepare":           # k_prepare: read m,lvl,item,cpos; write ms,sitem,slvl,cinv; objp
+        return nnz_b * (esz + 2 + 4 + 4) + nnz_b * (esz + 4 + 2 + 4) + nu_b * 24
+    if cls == "vgrad":             # k_vsweep<GRAD>: read ms,slvl; write c
+        return nnz_b * (esz + 2 + esz) + nu_b * 16
+    if cls == "vhv":               # k_vsweep<HV>: read b,slvl; write c
+        return nnz_b * (esz + 2 + esz) + nu_b * 16
+    if cls == "spmm":              # k_spmm: read c (through cinv), cuser, crow, U rows; write the partial-row slab
+        return nnz_b * (esz + 4 + 4 + 4) + F_U + F_V
+    if cls == "spmm_fin":          # k_spmm_fin: read slab + base, write out
+        return 3 * F_V
+    if cls == "ustep":             # k_ustep: read ms,sitem,slvl,U,V; write U,objp
+        return nnz_b * (esz + 4 + 2) + nu_b * 24 + 2 * F_U + F_V
     return 0
+
+
+# HIP-event slot -> kernel symbol prefix in a rocprofv3 trace (profiles/, tools/pmc_traffic.py)
+SLOT_KERNEL = {"sddmm": "void k_sddmm<", "spmm": "void k_spmm<", "spmm_fin": "void k_spmm_fin<", "prepare": "void k_prepare<",
+               "vgrad": "void k_vsweep<", "vhv": "void k_vsweep<", "ustep": "void k_ustep<"}
+
+
+def slot_kernel_match(slot, kernel_name, prec):
+    """Does a rocprof kernel name belong to this HIP-event slot (class/workgroup size[g][c])?"""
+    cls, _, tag = slot.partition("/")
+    if not kernel_name.startswith(SLOT_KERNEL.get(cls, "\0")):
+        return False
+    args = kernel_name[kernel_name.index("<") + 1:kernel_name.index(">")].replace(" ", "").split(",")
+    if args[0] != ("float" if prec == "f32" else "double"):
+        return False
+    if not tag:
+        return True
+    block = tag.rstrip("gc")
+    big, clu = "g" in tag[len(block):], "c" in tag[len(block):]
+    if args[1] != block or (args[2] == "true") != big:
+        return False
+    if cls in ("vgrad", "vhv"):
+        return (args[3] == "true") == (cls == "vhv")
+    if cls == "ustep":
+        return (args[3] != "1") == clu
+    return True
 
 
 def host_cores():
@@ -114,8 +142,8 @@ def cpu_baseline(R, n_pairs, r, lam):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rank-k", type=int, default=100, help="factor rank (BASELINE: 100)")
     ap.add_argument("--lam", type=float, default=5000.0)
     ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
@@ -200,30 +228,48 @@ def main():
         return
 
     # ---- roofline of the dominant kernel (rank 0's shard)
-    roof = None
+    roof, kernels = None, {}
     if prof:
         idx, _, _ = ds.csr(0)
         lens = np.diff(idx)[s.first_user:s.first_user + s.n_users]
-        bins = {"64": lens <= 128, "256": (lens > 128) & (lens <= 512), "512": (lens > 512) & (lens <= 4096), "512g": lens > 4096}
+        vbins = {"64": lens <= 128, "256": (lens > 128) & (lens <= 512), "512": (lens > 512) & (lens <= 4096), "512g": lens > 4096}
+        ubins = {"64": lens <= 128, "256": (lens > 128) & (lens <= 512), "512": (lens > 512) & (lens <= 1024),
+                 "512c": (lens > 1024) & (lens <= 4096), "512gc": lens > 4096, "512g": lens > 4096}
         esz = 4 if prec == pcr.PCR_F32 else 8
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")      # PMC passes of this command (tools/pmc_traffic.py)
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath))
         total_ms = sum(v[0] for v in prof.values())
+        for name, (ms, n) in prof.items():
+            cls, _, tag = name.partition("/")
+            if cls not in SLOT_KERNEL or n == 0:
+                continue
+            sel = (ubins if cls == "ustep" else vbins)[tag] if tag else np.ones(lens.shape[0], bool)
+            nnz_b, nu_b = int(lens[sel].sum()), int(sel.sum())
+            ab = algorithmic_bytes(name, nnz_b, nu_b, R.d2, r, esz)
+            avg_s = ms / n / 1e3
+            tr = None
+            for kname, t in traffic.items():
+                if slot_kernel_match(name, kname, args.precision):
+                    # FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md): quote the raw
+                    # counter sum; the x2-corrected read side is in profiles/r01_traffic.json
+                    tr = int(t["fetch_bytes_per_launch_raw"] + t["write_bytes_per_launch"])
+            kernels[name] = {"avg_us": round(avg_s * 1e6, 2), "timed_launches": int(n), "share": round(ms / total_ms, 4),
+                             "algorithmic_bytes": int(ab), "achieved_GBs": round(ab / avg_s / 1e9, 2),
+                             "frac_hbm_peak": round(ab / avg_s / 1e9 / HBM_PEAK_GBS, 5), "traffic_bytes": tr}
         if args.verbose:
             for k, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
-                log(f"  {k:14s} {ms:9.3f} ms  {n:6d} launches  {1e3 * ms / max(n, 1):9.1f} us/launch  {100 * ms / total_ms:5.1f} %")
-        name, (ms, n) = max(((k, v) for k, v in prof.items() if k.split("/")[0] in ("prepare", "vgrad", "vhv", "ustep", "spmm", "sddmm")),
-                            key=lambda kv: kv[1][0])
-        if "/" in name:
-            sel = bins[name.split("/")[1]]
-            nnz_b, nu_b = int(lens[sel].sum()), int(sel.sum())
-        else:
-            nnz_b, nu_b = int(lens.sum()), int(lens.shape[0])
-        ab = algorithmic_bytes(name, nnz_b, nu_b, R.d2, r, esz)
-        avg_s = ms / n / 1e3
-        ach = ab / avg_s / 1e9
-        roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
-                "launches": int(n), "algorithmic_bytes_per_launch": int(ab),
-                "share_of_kernel_time": round(ms / total_ms, 3)}
+                extra = f"  alg {kernels[k]['achieved_GBs']:8.1f} GB/s" if k in kernels else ""
+                log(f"  {k:14s} {ms:9.3f} ms  {n:6d} timed  {1e3 * ms / max(n, 1):9.1f} us/launch  {100 * ms / total_ms:5.1f} %{extra}")
+        dom = max(kernels, key=lambda k: kernels[k]["share"])
+        kd = kernels[dom]
+        roof = {"bound": "hbm", "kernel": dom, "achieved": kd["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": kd["frac_hbm_peak"], "traffic": kd["traffic_bytes"], "avg_launch_us": kd["avg_us"],
+                "launches_timed": kd["timed_launches"], "algorithmic_bytes_per_launch": kd["algorithmic_bytes"],
+                "share_of_kernel_time": kd["share"],
+                "note": "event-timed every 4th launch; per-kernel table in 'kernels'; U-step kernels re-gather V rows from L2 "
+                        "inside their CG loops, so their compulsory-HBM fraction is tiny by construction (DESIGN.md 3.5)"}
     cpu = None
     if N == 1 and not args.no_cpu:
         cpu = cpu_baseline(R, n_pairs, r, lam)
@@ -240,7 +286,7 @@ def main():
         "ndcg10_test": te_ndcg, "pairwise_error_test": te_err, "ndcg10_train": tr_ndcg, "pairwise_error_train": tr_err,
         "outer_iterations_run": args.warmup + args.steps, "objective": objs[-1],
         "inner_per_step": {k: v / args.steps for k, v in inner.items()},
-        "roofline": roof, "cpu_baseline": cpu,
+        "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
     }
     if cpu:
         out["speedup_vs_cpu_baseline"] = value / cpu["value"]

@@ -52,7 +52,7 @@ struct Shard {
     T* ms;                     // nnz
     int32_t* sitem;            // nnz    item id at sorted position
     uint16_t* slvl;            // nnz
-    int32_t* scsc;             // nnz    CSC position at sorted position
+    int32_t* cinv;             // nnz    CSC entry -> sorted position (k_spmm reads c through it)
     double* objp;              // nu     per-user loss partial
     // window cache: for sorted position p and every OTHER level l' (slot = l' < l ? l' : l'-1) the
     // boundary index of the active prefix / suffix of run l'.  Depends on m only, so k_prepare
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const in
             S.ms[s0 + p] = key[p];
             S.slvl[s0 + p] = (uint16_t)LiOps<LI>::lev(x);
             S.sitem[s0 + p] = S.item[s0 + idx];
-            S.scsc[s0 + p] = S.cpos[s0 + idx];
+            S.cinv[S.cpos[s0 + idx]] = (int32_t)(s0 + p);
         }
         double loss;
         if (S.ws) {
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const in
 }
 
 // ---------------------------------------------------------------------------------------
-// k_vsweep: per-user sweep coefficients for the V side, scattered to CSC order.
+// k_vsweep: per-user sweep coefficients for the V side (written in sorted order).
 //   HV = false: gradient (x = m, shift 1)           pcrpp.cpp:214-238
 //   HV = true : Hessian-vector (x = b = u_i . a_item, computed by k_sddmm)   pcrpp.cpp:294-318
 // ---------------------------------------------------------------------------------------
@@ -605,7 +605,7 @@ static inline size_t vsweep_bytes(int cap, int rs_cap) {
 
 template <typename T, int BLOCK, bool BIG, bool HV>
 __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
-                                                  const T* __restrict__ bsrc, T* __restrict__ c_csc,
+                                                  const T* __restrict__ bsrc, T* __restrict__ c_out,
                                                   int cap, int rs_cap, char* scratch, size_t stride, int strict, const int* skip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (skip && *skip) return;
@@ -638,23 +638,27 @@ __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int
             const double c = S.ws
                 ? sweep_coeff_win(S.win + (size_t)(s0 + p) * S.ws, Sx, rs, nlev, lev, (double)xs[p], HV ? 0.0 : 1.0)
                 : sweep_coeff<T>(ms, Sx, rs, nlev, lev, ms[p], (double)xs[p], HV ? 0.0 : 1.0, strict);
-            c_csc[S.scsc[s0 + p]] = (T)c;
+            c_out[s0 + p] = (T)c;                 // sorted order: coalesced (k_spmm gathers it through cinv)
         }
         __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// k_spmm: out[j,:] += sum_{z in column j} c[z] * U[cuser[z],:]   (pcrpp.cpp:240-243, 323-327)
-// Item-major (CSC) gather instead of the reference's per-scalar atomics: the CSC nnz range is
-// cut into equal chunks (load balance independent of item popularity); a group of G lanes walks
-// one chunk, keeps the running row in fp64 registers and issues ONE row of float atomics per
-// item boundary (out is pre-initialised with lambda * base by the caller).
+// k_spmm + k_spmm_fin: out[j,:] = beta * base[j,:] + sum_{z in column j} c[z] * U[cuser[z],:]
+// (pcrpp.cpp:240-243, 323-327).  Item-major (CSC) gather instead of the reference's per-scalar
+// atomics, and NO atomics at all: the CSC nnz range is cut into equal chunks (load balance
+// independent of item popularity); a group of G lanes walks one chunk, keeps the running row in
+// fp64 registers and stores ONE partial row per (chunk, item) incidence with plain coalesced
+// stores into a slab whose slot numbering is static (slots of one item are consecutive).
+// k_spmm_fin then sums each item's slots in a fixed order -> bitwise reproducible.
+// c is read through cinv (CSC entry -> sorted position), so the sweeps write it coalesced.
 // ---------------------------------------------------------------------------------------
 template <typename T, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const int32_t* __restrict__ cuser,
-                                                const int32_t* __restrict__ crow, int64_t nnz, const T* __restrict__ U,
-                                                T* __restrict__ out, Geo geo, int chunk, const int* skip) {
+__global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const int32_t* __restrict__ cinv,
+                                                const int32_t* __restrict__ cuser, const int32_t* __restrict__ crow,
+                                                const int32_t* __restrict__ slot_base, int64_t nnz, const T* __restrict__ U,
+                                                T* __restrict__ slab, Geo geo, int chunk, const int* skip) {
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     if (skip && *skip) return;
@@ -670,20 +674,22 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const i
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
         int cur = crow[z0];
-        auto flush = [&](int j) {
+        int slot = slot_base[gid];
+        auto flush = [&]() {
             if (act) {
+                V o;
+                T* op = reinterpret_cast<T*>(&o);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    atomicAdd(out + (size_t)j * geo.ld + ch * VEC + e, (T)acc[e]);
-                    acc[e] = 0.0;
-                }
+                for (int e = 0; e < VEC; ++e) { op[e] = (T)acc[e]; acc[e] = 0.0; }
+                *reinterpret_cast<V*>(slab + (size_t)slot * geo.ld + ch * VEC) = o;
             }
+            slot += 1;
         };
         for (int64_t zb = z0; zb < z1; zb += G) {
             const int64_t zi = zb + g;
             T cr = (T)0;
             int ur = 0, jr = 0;
-            if (zi < z1) { cr = c[zi]; ur = cuser[zi]; jr = crow[zi]; }
+            if (zi < z1) { cr = c[cinv[zi]]; ur = cuser[zi]; jr = crow[zi]; }
             const int cnt = (int)((z1 - zb < G) ? (z1 - zb) : G);
             for (int q = 0; q < cnt; q += PCR_UNR) {
                 V rv[PCR_UNR];
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const i
 #pragma unroll
                 for (int e8 = 0; e8 < PCR_UNR; ++e8) {
                     if (q + e8 < cnt) {
-                        if (jj[e8] != cur) { flush(cur); cur = jj[e8]; }
+                        if (jj[e8] != cur) { flush(); cur = jj[e8]; }
                         if (act) {
 #pragma unroll
                             for (int e = 0; e < VEC; ++e) acc[e] += cc[e8] * (double)velem(rv[e8], e);
@@ -710,7 +716,37 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const i
                 }
             }
         }
-        flush(cur);
+        flush();
+    }
+}
+
+// out[j,:] = beta * base[j,:] + sum of the item's slab slots [item_slot[j], item_slot[j+1]); G lanes per item
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_spmm_fin(const T* __restrict__ slab, const int32_t* __restrict__ item_slot,
+                                                    const T* __restrict__ base, double beta, int d2, T* __restrict__ out,
+                                                    Geo geo, const int* skip) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VEC = VecOf<T>::N;
+    if (skip && *skip) return;
+    const int G = geo.G, g = threadIdx.x & (G - 1);
+    const int j = (int)(((int64_t)blockIdx.x * BLOCK + threadIdx.x) / G);
+    if (j >= d2) return;
+    const int s0 = item_slot[j], s1 = item_slot[j + 1];
+    for (int ch = g; ch < geo.nchunk; ch += G) {
+        double acc[VEC];
+        const V bv = *reinterpret_cast<const V*>(base + (size_t)j * geo.ld + ch * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = beta * (double)velem(bv, e);
+        for (int sl = s0; sl < s1; ++sl) {
+            const V pv = *reinterpret_cast<const V*>(slab + (size_t)sl * geo.ld + ch * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] += (double)velem(pv, e);
+        }
+        V o;
+        T* op = reinterpret_cast<T*>(&o);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) op[e] = (T)acc[e];
+        *reinterpret_cast<V*>(out + (size_t)j * geo.ld + ch * VEC) = o;
     }
 }
 
@@ -785,10 +821,10 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_sum_stage1(const double* __res
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = x; part[2 * blockIdx.x + 1] = 0.0; }
 }
 
-// CG start: delta = 0, rr = -g, p = g, Hp = hp_scale * p; partial |g|^2
+// CG start: delta = 0, rr = -g, p = g; partial |g|^2
 template <typename T>
 __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_init(const T* __restrict__ g, T* __restrict__ delta, T* __restrict__ rr,
-                                                           T* __restrict__ p, T* __restrict__ Hp, double hp_scale, int64_t n,
+                                                           T* __restrict__ p, int64_t n,
                                                            int per_block, double* __restrict__ part) {
     __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
     const int64_t lo = (int64_t)blockIdx.x * per_block;
@@ -799,7 +835,6 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_init(const T* __restrict__ 
         delta[i] = (T)0;
         rr[i] = -gv;
         p[i] = gv;
-        Hp[i] = (T)(hp_scale * (double)gv);
         x += (double)gv * (double)gv;
     }
     x = block_sum<PCR_EW_BLOCK>(x, red);
@@ -869,11 +904,10 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_b(const T* __restrict__ p, 
     if (threadIdx.x == 0) { partB[2 * blockIdx.x] = x; partB[2 * blockIdx.x + 1] = y; }
 }
 
-// C: stop if |rr| < err, else beta = (rr.Hp)/(p.Hp); p = -rr + beta p; Hp = hp_scale * p (the
-// SpMM's initial value for the next product)
+// C: stop if |rr| < err, else beta = (rr.Hp)/(p.Hp); p = -rr + beta p
 template <typename T>
-__global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_c(T* __restrict__ p, T* __restrict__ Hp, const T* __restrict__ rr,
-                                                        double hp_scale, int64_t n, int per_block, int nblk,
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_c(T* __restrict__ p, const T* __restrict__ rr,
+                                                        int64_t n, int per_block, int nblk,
                                                         const double* __restrict__ partB, CGState* st) {
     __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
     if (st->done) return;     // CG already converged: later iterations are queued but idle
@@ -887,7 +921,6 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_c(T* __restrict__ p, T* __r
         for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) {
             const T pn = (T)((double)rr[i] * -1.0 + (double)p[i] * beta);
             p[i] = pn;
-            Hp[i] = (T)(hp_scale * (double)pn);
         }
     }
     // The host queues all 10 iterations without waiting; once `done` is set every later kernel of

@@ -129,7 +129,9 @@ struct Solver final : pcr_solver {
     // ---- training shard
     Shard<T> sh;
     DBuf<int64_t> d_uptr, d_runofs;
-    DBuf<int32_t> d_item, d_cpos, d_runstart, d_sitem, d_scsc, d_cuser, d_crow, d_ruser;
+    DBuf<int32_t> d_item, d_cpos, d_runstart, d_sitem, d_cinv, d_cuser, d_crow, d_ruser, d_slot_base, d_item_slot;
+    DBuf<T> d_slab;                               // k_spmm partial rows, one per (chunk, item) incidence
+    int spmm_chunk = 128;
     DBuf<uint16_t> d_lvl, d_slvl;
     DBuf<uint32_t> d_win;
     DBuf<T> d_ms, d_c, d_mcsr, d_b;
@@ -305,6 +307,29 @@ struct Solver final : pcr_solver {
                     cpos[z] = (int32_t)q; cuser[q] = (int32_t)u; crow[q] = item[z];
                 }
         }
+        {   // static slot numbering of the SpMM slab: one slot per (chunk, item) incidence, in CSC order,
+            // so the slots of one item are consecutive (pcr_kernels.h, k_spmm / k_spmm_fin)
+            if (const char* e = getenv("PCR_SPMM_CHUNK")) spmm_chunk = std::max(8, atoi(e));
+            const int64_t nchunks = (nnz_local + spmm_chunk - 1) / spmm_chunk;
+            std::vector<int32_t> slot_base(nchunks + 1, 0), item_slot(d2 + 1, 0);
+            int64_t slot = 0;
+            int64_t next_item = 0;
+            for (int64_t c = 0; c < nchunks; ++c) {
+                slot_base[c] = (int32_t)slot;
+                const int64_t a = c * spmm_chunk, b2 = std::min<int64_t>(a + spmm_chunk, nnz_local);
+                for (int64_t z = a; z < b2; ++z)
+                    if (z == a || crow[z] != crow[z - 1]) {
+                        if (z == 0 || crow[z] != crow[z - 1]) {          // first slot of this item
+                            for (; next_item <= crow[z]; ++next_item) item_slot[next_item] = (int32_t)slot;
+                        }
+                        ++slot;
+                    }
+            }
+            slot_base[nchunks] = (int32_t)slot;
+            for (; next_item <= d2; ++next_item) item_slot[next_item] = (int32_t)slot;
+            RC(d_slot_base.upload(slot_base, st)); RC(d_item_slot.upload(item_slot, st));
+            RC(d_slab.alloc((size_t)std::max<int64_t>(slot, 1) * geo.ld));
+        }
         make_bins(uptr, nu, &lv.run_ofs, bins);
         for (auto& b : bins) RC(b.d_users.upload(b.users, st));
         // U step: users with more than 1024 ratings are bound by one CU's gather bandwidth -> clusters of 4 workgroups
@@ -325,12 +350,12 @@ struct Solver final : pcr_solver {
         RC(d_uptr.upload(uptr, st)); RC(d_item.upload(item, st)); RC(d_lvl.upload(lv.level, st));
         RC(d_cpos.upload(cpos, st)); RC(d_cuser.upload(cuser, st)); RC(d_crow.upload(crow, st)); RC(d_ruser.upload(ruser, st));
         RC(d_runofs.upload(lv.run_ofs, st)); RC(d_runstart.upload(lv.run_start, st));
-        RC(d_ms.alloc(nnz_local)); RC(d_sitem.alloc(nnz_local)); RC(d_slvl.alloc(nnz_local)); RC(d_scsc.alloc(nnz_local));
+        RC(d_ms.alloc(nnz_local)); RC(d_sitem.alloc(nnz_local)); RC(d_slvl.alloc(nnz_local)); RC(d_cinv.alloc(nnz_local));
         RC(d_c.alloc(nnz_local)); RC(d_objp.alloc(nu)); RC(d_mcsr.alloc(nnz_local)); RC(d_b.alloc(nnz_local));
         sh.nu = nu; sh.nnz = nnz_local; sh.d2 = (int)d2;
         sh.uptr = d_uptr.p; sh.item = d_item.p; sh.lvl = d_lvl.p; sh.cpos = d_cpos.p;
         sh.runofs = d_runofs.p; sh.runstart = d_runstart.p;
-        sh.ms = d_ms.p; sh.sitem = d_sitem.p; sh.slvl = d_slvl.p; sh.scsc = d_scsc.p; sh.objp = d_objp.p;
+        sh.ms = d_ms.p; sh.sitem = d_sitem.p; sh.slvl = d_slvl.p; sh.cinv = d_cinv.p; sh.objp = d_objp.p;
         // window cache (pcr_kernels.h, Shard::win): one slot per other level, up to 9 levels
         sh.ws = (lv.max_levels >= 2 && lv.max_levels <= 9) ? lv.max_levels - 1 : 0;
         if (const char* e = getenv("PCR_NO_WINDOW_CACHE")) if (atoi(e)) sh.ws = 0;
@@ -367,7 +392,7 @@ struct Solver final : pcr_solver {
         HIPCHK(hipMemsetAsync(d_U.p, 0, std::max<size_t>(nU, 1) * sizeof(T), st));
         HIPCHK(hipMemsetAsync(d_V.p, 0, std::max<size_t>(nV, 1) * sizeof(T), st));
         RC(d_cg.alloc(1));
-        ew_blocks = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv((int64_t)nV, 4096)));
+        ew_blocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, cdiv((int64_t)nV, 1024)));   // 4 elements per thread: these kernels are latency-bound
         ew_per_block = cdiv((int64_t)nV, ew_blocks);
         RC(d_partA.alloc(4 * 2048)); RC(d_partB.alloc(4 * 2048)); RC(d_scal.alloc(64));
         RC(d_counters.alloc(4));
@@ -496,17 +521,19 @@ struct Solver final : pcr_solver {
         return PCR_OK;
     }
 
-    // out += sum c * U-rows (item-major); out must hold its initial value already
-    int launch_spmm(T* out, const int* skip = nullptr) {
-        ProfScope ps(this, "spmm");
+    // out = beta * base + sum c * U-rows (item-major, deterministic slab reduction)
+    int launch_spmm(T* out, const T* base, double beta, const int* skip = nullptr) {
         if (nnz_local > 0) {
-            static const int chunk = getenv("PCR_SPMM_CHUNK") ? atoi(getenv("PCR_SPMM_CHUNK")) : 128;
-            const int64_t ngroups = (nnz_local + chunk - 1) / chunk;
+            ProfScope ps(this, "spmm");
+            const int64_t ngroups = (nnz_local + spmm_chunk - 1) / spmm_chunk;
             const int gpb = 256 / geo.G;
-            const int grid = cdiv(ngroups, gpb);
-            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(grid), dim3(256), 0, st, d_c.p, d_cuser.p, d_crow.p, nnz_local, d_U.p, out, geo, chunk, skip);
-            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(cdiv(ngroups, gpb)), dim3(256), 0, st, d_c.p, d_cinv.p, d_cuser.p, d_crow.p,
+                               d_slot_base.p, nnz_local, d_U.p, d_slab.p, geo, spmm_chunk, skip);
         }
+        ProfScope ps2(this, "spmm_fin");
+        const int gpb = 256 / geo.G;
+        hipLaunchKernelGGL((k_spmm_fin<T, 256>), dim3(cdiv(d2, gpb)), dim3(256), 0, st, d_slab.p, d_item_slot.p, base, beta, (int)d2, out, geo, skip);
+        HIPCHK(hipGetLastError());
         return PCR_OK;
     }
 
@@ -627,12 +654,7 @@ struct Solver final : pcr_solver {
     // g = lambda V + sum_i sum_j c_ij u_i   (pcrpp.cpp:140-249) into d_g
     int device_gradient() {
         RC(launch_vsweep(false, nullptr));
-        {
-            ProfScope ps(this, "cg");
-            const int64_t n = (int64_t)d2 * geo.ld;
-            hipLaunchKernelGGL((k_scale<T>), dim3(cdiv(n, 256)), dim3(256), 0, st, d_g.p, d_V.p, rank == 0 ? prm.lambda : 0.0, n);
-        }
-        RC(launch_spmm(d_g.p));
+        RC(launch_spmm(d_g.p, d_V.p, rank == 0 ? prm.lambda : 0.0));      // rank 0 carries the lambda*V term
         RC(allreduce_T(d_g.p, (size_t)d2 * geo.ld));
         return PCR_OK;
     }
@@ -641,18 +663,16 @@ struct Solver final : pcr_solver {
         RC(device_gradient());
         return download_mat(d_g.p, d2, g);
     }
-    // Hp = lambda p + sum c(b) u, with Hp pre-initialised to hp_scale * p by the caller
+    // out = lambda p + sum c(b) u   (the lambda term on rank 0 only; summed by the all-reduce)
     int device_hv(const T* pvec, T* out, const int* skip = nullptr) {
         RC(launch_vsweep(true, pvec, skip));
-        RC(launch_spmm(out, skip));
+        RC(launch_spmm(out, pvec, rank == 0 ? prm.lambda : 0.0, skip));
         RC(allreduce_T(out, (size_t)d2 * geo.ld));
         return PCR_OK;
     }
     int compute_Ha(const double* a, double* Ha) override {
         RC(need_sorted());
         RC(upload_mat(a, d2, d_p.p));
-        const int64_t n = (int64_t)d2 * geo.ld;
-        hipLaunchKernelGGL((k_scale<T>), dim3(cdiv(n, 256)), dim3(256), 0, st, d_Hp.p, d_p.p, rank == 0 ? prm.lambda : 0.0, n);
         RC(device_hv(d_p.p, d_Hp.p));
         return download_mat(d_Hp.p, d2, Ha);
     }
@@ -660,10 +680,9 @@ struct Solver final : pcr_solver {
     // CG on H delta = g with g in d_g (pcrpp.cpp:335-358); result in d_delta
     int device_cg(int* iters) {
         const int64_t n = (int64_t)d2 * geo.ld;
-        const double hp_scale = rank == 0 ? prm.lambda : 0.0;
         {
             ProfScope ps(this, "cg");
-            hipLaunchKernelGGL((k_cg_init<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_g.p, d_delta.p, d_rr.p, d_p.p, d_Hp.p, hp_scale, n, ew_per_block, d_partA.p);
+            hipLaunchKernelGGL((k_cg_init<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_g.p, d_delta.p, d_rr.p, d_p.p, n, ew_per_block, d_partA.p);
             hipLaunchKernelGGL(k_cg_init_fin, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, ew_blocks, d_cg.p);
         }
         // All 10 iterations are queued without a host round trip; once the device-side stop test
@@ -675,7 +694,7 @@ struct Solver final : pcr_solver {
                 ProfScope ps(this, "cg");
                 hipLaunchKernelGGL((k_cg_a<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, 0.0, n, ew_per_block, d_partA.p, d_cg.p);
                 hipLaunchKernelGGL((k_cg_b<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, d_delta.p, n, ew_per_block, ew_blocks, d_partA.p, d_partB.p, d_cg.p);
-                hipLaunchKernelGGL((k_cg_c<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, hp_scale, n, ew_per_block, ew_blocks, d_partB.p, d_cg.p);
+                hipLaunchKernelGGL((k_cg_c<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_rr.p, n, ew_per_block, ew_blocks, d_partB.p, d_cg.p);
             }
             HIPCHK(hipGetLastError());
         }
