@@ -233,6 +233,7 @@ def main():
         idx, _, _ = ds.csr(0)
         lens = np.diff(idx)[s.first_user:s.first_user + s.n_users]
         vbins = {"64": lens <= 128, "256": (lens > 128) & (lens <= 512), "512": (lens > 512) & (lens <= 4096), "512g": lens > 4096}
+        sbins = {"256": lens <= 512, "512": (lens > 512) & (lens <= 4096), "512g": lens > 4096}
         ubins = {"64": lens <= 128, "256": (lens > 128) & (lens <= 512), "512": (lens > 512) & (lens <= 1024),
                  "512c": (lens > 1024) & (lens <= 4096), "512gc": lens > 4096, "512g": lens > 4096}
         esz = 4 if prec == pcr.PCR_F32 else 8
@@ -245,7 +246,7 @@ def main():
             cls, _, tag = name.partition("/")
             if cls not in SLOT_KERNEL or n == 0:
                 continue
-            sel = (ubins if cls == "ustep" else vbins)[tag] if tag else np.ones(lens.shape[0], bool)
+            sel = (ubins if cls == "ustep" else sbins if cls in ("vgrad", "vhv") else vbins)[tag] if tag else np.ones(lens.shape[0], bool)
             nnz_b, nu_b = int(lens[sel].sum()), int(sel.sum())
             ab = algorithmic_bytes(name, nnz_b, nu_b, R.d2, r, esz)
             avg_s = ms / n / 1e3

@@ -137,6 +137,7 @@ struct Solver final : pcr_solver {
     DBuf<T> d_ms, d_c, d_mcsr, d_b;
     DBuf<double> d_objp;
     std::vector<Bin> bins;
+    std::vector<Bin> sbins;                      // sweep bins: the light V-side sweeps run back to back on one stream
     std::vector<Bin> ubins;                      // U-step bins: an extra class, long users get workgroup clusters
     DBuf<unsigned> d_bar;
     DBuf<char> d_xch;
@@ -332,6 +333,8 @@ struct Solver final : pcr_solver {
         }
         make_bins(uptr, nu, &lv.run_ofs, bins);
         for (auto& b : bins) RC(b.d_users.upload(b.users, st));
+        make_bins(uptr, nu, &lv.run_ofs, sbins, {512, 4096}, {256, 512, 512});
+        for (auto& b : sbins) RC(b.d_users.upload(b.users, st));
         // U step: users with more than 1024 ratings are bound by one CU's gather bandwidth -> clusters of 4 workgroups
         make_bins(uptr, nu, &lv.run_ofs, ubins, {128, 512, 1024, 4096}, {64, 256, 512, 512, 512});
         const int cluster_k = getenv("PCR_CLUSTER_K") ? atoi(getenv("PCR_CLUSTER_K")) : 4;
@@ -456,6 +459,17 @@ struct Solver final : pcr_solver {
         HIPCHK(hipGetLastError());
         return PCR_OK;
     }
+    // the same, back to back on the solver's stream (for kernels shorter than a fork/join round trip)
+    template <class F>
+    int for_bins_seq(std::vector<Bin>& bs, const char* cls, F launch) {
+        for (auto& b : bs) {
+            if (b.users.empty()) continue;
+            ProfScope ps(this, pname(cls, b), st);
+            launch(b, st);
+        }
+        HIPCHK(hipGetLastError());
+        return PCR_OK;
+    }
     // profile slot of one kernel launch: "<class>/<workgroup size>[g]" (g = global-scratch variant)
     static std::string pname(const char* cls, const Bin& b) { return std::string(cls) + "/" + std::to_string(b.block) + (b.big ? "g" : "") + (b.K > 1 ? "c" : ""); }
     size_t small_common(int block) const { return carve_bytes(geo.ld, sizeof(T)) + carve_bytes(block / PCR_WAVE + 1, 8); }
@@ -517,7 +531,7 @@ struct Solver final : pcr_solver {
             }
 #undef LV
         };
-        RC(for_bins(bins, hv ? "vhv" : "vgrad", fn));
+        RC(for_bins_seq(sbins, hv ? "vhv" : "vgrad", fn));
         return PCR_OK;
     }
 
