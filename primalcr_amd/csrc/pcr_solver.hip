@@ -337,9 +337,12 @@ struct Solver final : pcr_solver {
         for (auto& b : sbins) RC(b.d_users.upload(b.users, st));
         // U step: users with more than 1024 ratings are bound by one CU's gather bandwidth -> clusters of 4 workgroups
         make_bins(uptr, nu, &lv.run_ofs, ubins, {128, 512, 1024, 4096}, {64, 256, 512, 512, 512});
-        const int cluster_k = getenv("PCR_CLUSTER_K") ? atoi(getenv("PCR_CLUSTER_K")) : 4;
-        if (cluster_k == 4) { ubins[3].K = 4; ubins[4].K = 4; }
-        max_clusters = std::max(1, ncu / 4);
+        // cluster sizes per U-step bin: PCR_CLUSTER_K="k2,k3,k4" overrides (each 1, 2, 4 or 8)
+        int ck[3] = {1, 4, 4};
+        if (const char* e = getenv("PCR_CLUSTER_K")) sscanf(e, "%d,%d,%d", &ck[0], &ck[1], &ck[2]);
+        for (int q = 0; q < 3; ++q) if (ck[q] != 1 && ck[q] != 2 && ck[q] != 4 && ck[q] != 8) ck[q] = 1;
+        ubins[2].K = ck[0]; ubins[3].K = ck[1]; ubins[4].K = ck[2];
+        max_clusters = std::max(1, ncu / 2);
         for (auto& b : ubins) RC(b.d_users.upload(b.users, st));
         {
             size_t need_x = 0;
@@ -417,7 +420,7 @@ struct Solver final : pcr_solver {
             scratch_stride = (need + 255) & ~(size_t)255;
             size_t nbig = bins[3].users.size();
             for (int w = 0; w < 2; ++w) nbig = std::max(nbig, ev[w].bins[3].users.size());
-            scratch_blocks = (int)std::min<size_t>(std::max<size_t>(nbig * 4, 1), (size_t)ncu * 2);
+            scratch_blocks = (int)std::min<size_t>(std::max<size_t>(nbig * 8, 1), (size_t)ncu * 2);
             RC(d_scratch.alloc(scratch_stride * (size_t)scratch_blocks));
         }
         RC(set_lds_limits());
@@ -433,6 +436,8 @@ struct Solver final : pcr_solver {
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 512, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_eval<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         return PCR_OK;
     }
@@ -552,14 +557,14 @@ struct Solver final : pcr_solver {
     }
 
     int allreduce_T(T* buf, size_t count) {
-        if (nranks == 1 || local_only) return PCR_OK;
+        if ((nranks == 1 && !comm) || local_only) return PCR_OK;
         if (!comm) { pcr_set_error("nranks > 1 but pcr_solver_comm_init was not called"); return PCR_ERR_STATE; }
         ProfScope ps(this, "allreduce");
         NCCLCHK(ncclAllReduce(buf, buf, count, sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, comm, st));
         return PCR_OK;
     }
     int allreduce_f64(double* buf, size_t count) {
-        if (nranks == 1 || local_only) return PCR_OK;
+        if ((nranks == 1 && !comm) || local_only) return PCR_OK;
         if (!comm) { pcr_set_error("nranks > 1 but pcr_solver_comm_init was not called"); return PCR_ERR_STATE; }
         ProfScope ps(this, "allreduce");
         NCCLCHK(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, st));
@@ -762,13 +767,15 @@ struct Solver final : pcr_solver {
             const size_t bi = (size_t)(&b - &ubins[0]);
             ClusterBufs cb{d_bar.p + bi * max_clusters, d_xch.p + bi * max_clusters * xch_stride, xch_stride};
             // clusters: grid <= one workgroup per CU so that every member of every cluster is resident
-            const int nclus = std::min(nus, max_clusters);
+            const int nclus = std::min(nus, std::max(1, ncu / b.K));
             const int grid = b.K > 1 ? nclus * b.K : (b.big ? std::min(nus, scratch_blocks) : nus);
 #define LU(BL, BG, KK) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, strict(), strict(), b.cap, cap_pad, rsc, d_scratch.p, scratch_stride, d_counters.p, cb)
-            if (b.big) { if (b.K > 1) LU(512, true, 4); else LU(512, true, 1); }
+            if (b.big) { if (b.K == 8) LU(512, true, 8); else if (b.K == 4) LU(512, true, 4); else if (b.K == 2) LU(512, true, 2); else LU(512, true, 1); }
             else if (b.block == 64) LU(64, false, 1);
             else if (b.block == 256) LU(256, false, 1);
-            else if (b.K > 1) LU(512, false, 4);
+            else if (b.K == 8) LU(512, false, 8);
+            else if (b.K == 4) LU(512, false, 4);
+            else if (b.K == 2) LU(512, false, 2);
             else LU(512, false, 1);
 #undef LU
         };
@@ -892,7 +899,6 @@ struct Solver final : pcr_solver {
     }
 
     int comm_init(const void* id) override {
-        if (nranks == 1) return PCR_OK;
         ncclUniqueId uid;
         memcpy(&uid, id, sizeof uid);
         HIPCHK(hipSetDevice(prm.device));
