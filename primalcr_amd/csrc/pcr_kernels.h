@@ -349,36 +349,40 @@ __device__ __forceinline__ T group_reduce4(const T (&a)[4], int g, int G) {
 
 // The per-user (workgroup) primitives keep 4 rows in flight per lane group: k_ustep is register-bound
 // (occupancy), and its many resident waves provide the memory-level parallelism instead.
-#define PCR_BUNR 4
+// rows in flight per lane group of the per-user primitives: 4 in the one-wave / 256-thread kernels (register-bound:
+// occupancy provides the memory-level parallelism), 8 in the 512-thread kernels (one workgroup per CU anyway)
+#define PCR_BUNR (BLOCK >= 512 ? 8 : 4)
 template <typename T, int BLOCK>
 __device__ __forceinline__ void block_sddmm(const T* __restrict__ M, const T* vecT, const int32_t* rows, int n,
                                             T* out, const Geo& geo, int r0 = 0) {      // rows [r0, n)
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     const int G = geo.G, g = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = BLOCK / G;
-    const int rho = 2 * (g & 1) + ((g >> 1) & 1);
+    constexpr int UNR = PCR_BUNR;
+    const int rho = (UNR == 8) ? 4 * (g & 1) + (g & 2) + ((g >> 2) & 1) : 2 * (g & 1) + ((g >> 1) & 1);
     for (int k = 0; k * G < geo.nchunk; ++k) {
         const int ch = g + k * G;
         const bool act = ch < geo.nchunk;
         V uv;
         if (act) uv = *reinterpret_cast<const V*>(vecT + ch * VEC);
-        for (int base = r0 + grp; base < n; base += ngrp * PCR_BUNR) {
-            V rv[PCR_BUNR];
+        for (int base = r0 + grp; base < n; base += ngrp * UNR) {
+            V rv[UNR];
 #pragma unroll
-            for (int q = 0; q < PCR_BUNR; ++q) {
+            for (int q = 0; q < UNR; ++q) {
                 const int row = base + q * ngrp;
                 if (row < n && act) rv[q] = *reinterpret_cast<const V*>(M + (size_t)rows[row] * geo.ld + ch * VEC);
             }
-            T part[PCR_BUNR];
+            T part[UNR];
 #pragma unroll
-            for (int q = 0; q < PCR_BUNR; ++q) part[q] = (act && base + q * ngrp < n) ? vdot(rv[q], uv) : (T)0;
-            if (G >= 4) {
-                const T tot = group_reduce4<T>(part, g, G);          // whole lane groups are active here
+            for (int q = 0; q < UNR; ++q) part[q] = (act && base + q * ngrp < n) ? vdot(rv[q], uv) : (T)0;
+            if (G >= UNR) {
+                T tot;                                               // whole lane groups are active here
+                if constexpr (UNR == 8) tot = group_reduce8<T>(part, g, G); else tot = group_reduce4<T>(part, g, G);
                 const int row = base + rho * ngrp;
-                if (g < 4 && row < n) out[row] = (k == 0) ? tot : out[row] + tot;
+                if (g < UNR && row < n) out[row] = (k == 0) ? tot : out[row] + tot;
             } else {
 #pragma unroll
-                for (int q = 0; q < PCR_BUNR; ++q) {
+                for (int q = 0; q < UNR; ++q) {
                     T v = part[q];
                     if (G > 2) v += __shfl_xor(v, 2);
                     if (G > 1) v += __shfl_xor(v, 1);
@@ -400,17 +404,18 @@ __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const
     constexpr int VEC = VecOf<T>::N;
     const int G = geo.G, g = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = BLOCK / G;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int UNR = PCR_BUNR;
     for (int k = 0; k * G < geo.nchunk; ++k) {
         const int ch = g + k * G;
         const bool act = ch < geo.nchunk;
         double acc[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
-        for (int base = r0 + grp; base < n; base += ngrp * PCR_BUNR) {
-            V rv[PCR_BUNR];
-            double cc[PCR_BUNR];
+        for (int base = r0 + grp; base < n; base += ngrp * UNR) {
+            V rv[UNR];
+            double cc[UNR];
 #pragma unroll
-            for (int q = 0; q < PCR_BUNR; ++q) {
+            for (int q = 0; q < UNR; ++q) {
                 const int row = base + q * ngrp;
                 cc[q] = 0.0;
                 if (row < n && act) {
@@ -419,7 +424,7 @@ __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const
                 }
             }
 #pragma unroll
-            for (int q = 0; q < PCR_BUNR; ++q) {
+            for (int q = 0; q < UNR; ++q) {
                 const int row = base + q * ngrp;
                 if (row < n && act) {
 #pragma unroll
