@@ -1,0 +1,66 @@
+"""GPU test of the RCCL plumbing on ONE GPU: a 1-rank communicator is created through the same
+bootstrap bench.py uses (pcr_comm_unique_id -> pcr_solver_comm_init) and every collective of the
+training loop then really goes through ncclAllReduce on the solver's stream.  Results must equal
+the communicator-free run bit for bit.  torch is imported first, as in bench.py, so the test also
+covers libprimalcr's RCCL/HIP runtime coexisting with PyTorch's in one process."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_training_through_rccl_single_rank():
+    import torch  # noqa: F401  (library coexistence)
+    import primalcr_amd as pcr
+    from primalcr_amd import synth
+    R = synth.generate("small", seed=2)
+    ds = pcr.Dataset.from_ratings(R)
+    U0, V0 = pcr.initial(R.d1, 16), pcr.initial(R.d2, 16)
+    out = []
+    for use_comm in (False, True):
+        s = pcr.Solver(ds, pcr.Parameter(k=16, maxiter=2, do_predict=1, **{"lambda": 100.0}))
+        if use_comm:
+            s.comm_init(pcr.comm_unique_id())
+        s.set_factors(U0, V0)
+        recs, _ = s.train()
+        U, V = s.get_factors()
+        out.append((recs, U, V))
+        s.close()
+    (r0, U_a, V_a), (r1, U_b, V_b) = out
+    assert np.array_equal(U_a, U_b) and np.array_equal(V_a, V_b)
+    for a, b in zip(r0, r1):
+        assert a["obj"] == b["obj"] and a["test_ndcg"] == b["test_ndcg"] and a["cg_v"] == b["cg_v"]
+
+
+def test_headline_config_matches_reference_binary(tmp_path):
+    """BASELINE configs[1]: ml1m-shaped synthetic, PrimalCR++ -k 100 -l 5000, 3 outer iterations, default
+    (fp32) precision on the GPU vs the UNMODIFIED reference binary (oracle/_ref/omp-pmf-train, all host
+    cores) on the same files: objective within 1e-3 relative, NDCG@10 / pairwise error within 1e-3."""
+    import os
+    import re
+    import subprocess
+    import primalcr_amd as pcr
+    from oracle import oracle_py
+    from primalcr_amd import synth
+    if not os.path.exists(oracle_py.REF_TRAIN):
+        pytest.skip("oracle/_ref was not built (no /root/reference at build time)")
+    R = synth.generate("ml1m")
+    d = synth.write_dir(R, str(tmp_path / "ml1m"))
+    iters = 3
+    out = subprocess.run([oracle_py.REF_TRAIN, "-k", "100", "-l", "5000", "-t", str(iters), "-n", "16",
+                          d, str(tmp_path / "ref.model")], cwd=tmp_path, capture_output=True, text=True, check=True).stdout
+    objs = [float(x) for x in re.findall(r"^Iter \d+ time \S+ obj (\S+)$", out, re.M)]
+    te = [(float(a), float(b)) for a, b in re.findall(r"^\(Testing\) pairwise error is (\S+) and ndcg is (\S+)$", out, re.M)]
+    tr = [(float(a), float(b)) for a, b in re.findall(r"^\(Training\) pairwise error is (\S+) and ndcg is (\S+)$", out, re.M)]
+    ds = pcr.Dataset.load(d)
+    s = pcr.Solver(ds, pcr.Parameter(k=100, maxiter=iters, **{"lambda": 5000.0}))
+    s.set_factors(pcr.initial(R.d1, 100), pcr.initial(R.d2, 100))
+    recs, _ = s.train()
+    assert len(objs) == iters + 1
+    for k, rec in enumerate(recs):
+        # the reference's printed objective after a U step is racy for -n > 1 (shared obj_u_new, pcrpp.cpp:822-832):
+        # compare it at iteration 0 only, where it comes from objective_new
+        if k == 0:
+            assert abs(rec["obj"] / objs[k] - 1) < 1e-3
+        assert abs(rec["test_err"] - te[k][0]) < 1e-3 and abs(rec["test_ndcg"] - te[k][1]) < 1e-3
+        assert abs(rec["train_err"] - tr[k][0]) < 1e-3 and abs(rec["train_ndcg"] - tr[k][1]) < 1e-3
