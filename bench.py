@@ -70,7 +70,7 @@ def algorithmic_bytes(slot, nnz_b, nu_b, d2, r, esz):
 
 # HIP-event slot -> kernel symbol prefix in a rocprofv3 trace (profiles/, tools/pmc_traffic.py)
 SLOT_KERNEL = {"sddmm": "void k_sddmm<", "spmm": "void k_spmm<", "spmm_fin": "void k_spmm_fin<", "prepare": "void k_prepare<",
-               "vgrad": "void k_vsweep<", "vhv": "void k_vsweep<", "ustep": "void k_ustep<"}
+               "vgrad": "void k_vsweep", "vhv": "void k_vsweep", "ustep": "void k_ustep<"}
 
 
 def slot_kernel_match(slot, kernel_name, prec):
@@ -80,6 +80,10 @@ def slot_kernel_match(slot, kernel_name, prec):
         return False
     args = kernel_name[kernel_name.index("<") + 1:kernel_name.index(">")].replace(" ", "").split(",")
     if args[0] != ("float" if prec == "f32" else "double"):
+        return False
+    if kernel_name.startswith("void k_vsweep_wave<"):          # one wave per user: slot tag "64"
+        return cls in ("vgrad", "vhv") and tag == "64" and (args[1] == "true") == (cls == "vhv")
+    if cls in ("vgrad", "vhv") and not kernel_name.startswith("void k_vsweep<"):
         return False
     if not tag:
         return True
@@ -233,7 +237,7 @@ def main():
         idx, _, _ = ds.csr(0)
         lens = np.diff(idx)[s.first_user:s.first_user + s.n_users]
         vbins = {"64": lens <= 128, "256": (lens > 128) & (lens <= 512), "512": (lens > 512) & (lens <= 4096), "512g": lens > 4096}
-        sbins = {"256": lens <= 512, "512": (lens > 512) & (lens <= 4096), "512g": lens > 4096}
+        sbins = {"64": lens <= 256, "512": (lens > 256) & (lens <= 4096), "512g": lens > 4096}
         ubins = {"64": lens <= 128, "256": (lens > 128) & (lens <= 512), "512": (lens > 512) & (lens <= 1024),
                  "512c": (lens > 1024) & (lens <= 4096), "512gc": lens > 4096, "512g": lens > 4096}
         esz = 4 if prec == pcr.PCR_F32 else 8

@@ -649,6 +649,69 @@ __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int
     }
 }
 
+// k_vsweep for short users (<= 256 ratings), ONE WAVE PER USER, four users per 256-thread
+// workgroup: no workgroup barriers at all (LDS traffic stays inside a wave, which the LDS serves
+// in program order), so the many short users of a rating set do not pay a block's fixed cost each.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <typename T>
+static inline size_t vsweep_wave_bytes(int cap, int rs_cap) {      // per wave
+    return carve_bytes(cap, sizeof(T)) * 2 + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
+}
+template <typename T, bool HV>
+__global__ __launch_bounds__(256) void k_vsweep_wave(Shard<T> S, const int32_t* __restrict__ users, int nusers,
+                                                     const T* __restrict__ bsrc, T* __restrict__ c_out,
+                                                     int cap, int rs_cap, size_t wave_bytes, int strict, const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int ui = blockIdx.x * 4 + wid;
+    if (ui >= nusers) return;
+    Carver big(smem + (size_t)wid * wave_bytes);
+    T* ms = big.take<T>(cap);
+    T* x = big.take<T>(cap);
+    double* Sx = big.take<double>(cap + 1);
+    int* rs = big.take<int>(rs_cap);
+    const int u = users[ui];
+    const int64_t s0 = S.uptr[u];
+    const int n = (int)(S.uptr[u + 1] - s0);
+    const int nlev = (int)(S.runofs[u + 1] - S.runofs[u]) - 1;
+    if (n == 0) return;
+    if (!HV || !S.ws) for (int p = lane; p < n; p += 64) ms[p] = S.ms[s0 + p];
+    for (int l = lane; l <= nlev; l += 64) rs[l] = S.runstart[S.runofs[u] + l];
+    const T* xs = ms;
+    if (HV) {
+        for (int p = lane; p < n; p += 64) x[p] = bsrc[s0 + p];
+        xs = x;
+    }
+    wave_sync();
+    double carry = 0.0;                                     // wave-level exclusive scan of xs -> Sx[0..n]
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const double v = (i < n) ? (double)xs[i] : 0.0;
+        double inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (i < n) Sx[i] = carry + inc - v;
+        carry += __shfl(inc, 63);
+    }
+    if (lane == 0) Sx[n] = carry;
+    wave_sync();
+    for (int p = lane; p < n; p += 64) {
+        const int lev = S.slvl[s0 + p];
+        const double c = S.ws
+            ? sweep_coeff_win(S.win + (size_t)(s0 + p) * S.ws, Sx, rs, nlev, lev, (double)xs[p], HV ? 0.0 : 1.0)
+            : sweep_coeff<T>(ms, Sx, rs, nlev, lev, ms[p], (double)xs[p], HV ? 0.0 : 1.0, strict);
+        c_out[s0 + p] = (T)c;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // k_spmm + k_spmm_fin: out[j,:] = beta * base[j,:] + sum_{z in column j} c[z] * U[cuser[z],:]
 // (pcrpp.cpp:240-243, 323-327).  Item-major (CSC) gather instead of the reference's per-scalar

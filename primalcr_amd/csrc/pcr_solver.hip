@@ -333,7 +333,7 @@ struct Solver final : pcr_solver {
         }
         make_bins(uptr, nu, &lv.run_ofs, bins);
         for (auto& b : bins) RC(b.d_users.upload(b.users, st));
-        make_bins(uptr, nu, &lv.run_ofs, sbins, {512, 4096}, {256, 512, 512});
+        make_bins(uptr, nu, &lv.run_ofs, sbins, {256, 4096}, {64, 512, 512});       // bin 0: one wave per user (k_vsweep_wave)
         for (auto& b : sbins) RC(b.d_users.upload(b.users, st));
         // U step: users with more than 1024 ratings are bound by one CU's gather bandwidth -> clusters of 4 workgroups
         make_bins(uptr, nu, &lv.run_ofs, ubins, {128, 512, 1024, 4096}, {64, 256, 512, 512, 512});
@@ -519,21 +519,18 @@ struct Solver final : pcr_solver {
         auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
             const int rsc = b.max_lev + 2;
+            if (b.block == 64) {                         // short users: one wave each, four per workgroup
+                const size_t wb = (vsweep_wave_bytes<T>(b.cap, rsc) + 15) & ~(size_t)15;
+                if (hv) hipLaunchKernelGGL((k_vsweep_wave<T, true>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip);
+                else hipLaunchKernelGGL((k_vsweep_wave<T, false>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip);
+                return;
+            }
             const size_t bigb = vsweep_bytes<T>(b.cap, rsc);
             const size_t lds = small_common(b.block) + (b.big ? 0 : bigb);
             const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
 #define LV(BL, BG, HV) hipLaunchKernelGGL((k_vsweep<T, BL, BG, HV>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, d_scratch.p, scratch_stride, strict(), skip)
-            if (hv) {
-                if (b.big) LV(512, true, true);
-                else if (b.block == 64) LV(64, false, true);
-                else if (b.block == 256) LV(256, false, true);
-                else LV(512, false, true);
-            } else {
-                if (b.big) LV(512, true, false);
-                else if (b.block == 64) LV(64, false, false);
-                else if (b.block == 256) LV(256, false, false);
-                else LV(512, false, false);
-            }
+            if (hv) { if (b.big) LV(512, true, true); else LV(512, false, true); }
+            else { if (b.big) LV(512, true, false); else LV(512, false, false); }
 #undef LV
         };
         RC(for_bins_seq(sbins, hv ? "vhv" : "vgrad", fn));
