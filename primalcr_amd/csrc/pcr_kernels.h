@@ -497,20 +497,59 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(const T* __restrict__ U, const 
         const int ch = g + k * G;
         const bool act = ch < geo.nchunk;
         int cur = -1;
-        V uv;
+        V uv = V{};
+        const int chv = act ? ch : 0;                 // idle lanes re-read chunk 0 and multiply it by zero
         for (int q0 = l0; q0 < l1; q0 += PCR_UNR) {
             V rv[PCR_UNR];
-#pragma unroll
-            for (int e = 0; e < PCR_UNR; ++e)
-                if (q0 + e < l1 && act) rv[e] = *reinterpret_cast<const V*>(M + (size_t)s_row[q0 + e] * geo.ld + ch * VEC);
             T part[PCR_UNR];
+            bool fast = false;
+            if (q0 + PCR_UNR <= l1) {
+                // full batch: the 8 item ids and 8 user ids come in four 16-byte LDS reads, the 8 row loads are
+                // issued back to back with no per-row wait or branch
+                const int4 i0 = *reinterpret_cast<const int4*>(s_row + q0), i1 = *reinterpret_cast<const int4*>(s_row + q0 + 4);
+                const int4 u0 = *reinterpret_cast<const int4*>(s_usr + q0), u1 = *reinterpret_cast<const int4*>(s_usr + q0 + 4);
+                const int ri[PCR_UNR] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
 #pragma unroll
-            for (int e = 0; e < PCR_UNR; ++e) {
-                part[e] = (T)0;
-                if (q0 + e < l1) {                                  // uniform inside a lane group
-                    const int uu = s_usr[q0 + e];
-                    if (uu != cur) { cur = uu; if (act) uv = *reinterpret_cast<const V*>(U + (size_t)uu * geo.ld + ch * VEC); }
-                    if (act) part[e] = vdot(rv[e], uv);
+                for (int e = 0; e < PCR_UNR; ++e) rv[e] = *reinterpret_cast<const V*>(M + (size_t)ri[e] * geo.ld + chv * VEC);
+                if (u0.x != cur) {                      // at most one reload in front of a same-user batch
+                    cur = u0.x;
+                    uv = *reinterpret_cast<const V*>(U + (size_t)cur * geo.ld + chv * VEC);
+                    if (!act) uv = V{};
+                }
+                fast = (u0.y == cur) & (u0.z == cur) & (u0.w == cur) & (u1.x == cur) & (u1.y == cur) & (u1.z == cur) & (u1.w == cur);
+                if (fast) {
+#pragma unroll
+                    for (int e = 0; e < PCR_UNR; ++e) part[e] = vdot(rv[e], uv);
+                } else {                                // a user boundary inside the batch
+                    const int ui8[PCR_UNR] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+                    for (int e = 0; e < PCR_UNR; ++e) {
+                        if (ui8[e] != cur) {
+                            cur = ui8[e];
+                            uv = *reinterpret_cast<const V*>(U + (size_t)cur * geo.ld + chv * VEC);
+                            if (!act) uv = V{};
+                        }
+                        part[e] = vdot(rv[e], uv);
+                    }
+                    fast = true;
+                }
+            }
+            if (!fast) {                                // ragged tail of the tile
+#pragma unroll
+                for (int e = 0; e < PCR_UNR; ++e)
+                    if (q0 + e < l1) rv[e] = *reinterpret_cast<const V*>(M + (size_t)s_row[q0 + e] * geo.ld + chv * VEC);
+#pragma unroll
+                for (int e = 0; e < PCR_UNR; ++e) {
+                    part[e] = (T)0;
+                    if (q0 + e < l1) {                              // uniform inside a lane group
+                        const int uu = s_usr[q0 + e];
+                        if (uu != cur) {
+                            cur = uu;
+                            uv = *reinterpret_cast<const V*>(U + (size_t)uu * geo.ld + chv * VEC);
+                            if (!act) uv = V{};
+                        }
+                        part[e] = vdot(rv[e], uv);
+                    }
                 }
             }
             if (G >= 8) {
