@@ -143,7 +143,9 @@ template <> struct LiOps<uint64_t> {
 // ascending bitonic sort of (key, li) by (level, key); npad = pow2 >= n, padding carries the
 // maximum level so it sinks to the end.  Tie order among equal (level, key) is irrelevant to
 // every sum computed from the order (the reference's std::sort is unstable too).
-template <typename T, typename LI, int BLOCK>
+// TIE = true additionally orders equal (level, key) by DESCENDING index (k_eval2: the lowest index then
+// sits at the end of its run and is taken first).
+template <typename T, typename LI, int BLOCK, bool TIE = false>
 __device__ __forceinline__ void bitonic_sort(T* key, LI* li, int npad) {
     const int tid = threadIdx.x;
     for (int k = 2; k <= npad; k <<= 1) {
@@ -157,6 +159,10 @@ __device__ __forceinline__ void bitonic_sort(T* key, LI* li, int npad) {
                 unsigned va = LiOps<LI>::lev(la), vb = LiOps<LI>::lev(lb);
                 bool b_lt_a = (vb < va) || (vb == va && kb < ka);
                 bool a_lt_b = (va < vb) || (va == vb && ka < kb);
+                if (TIE && va == vb && ka == kb) {
+                    const unsigned ia = LiOps<LI>::idx(la), ib = LiOps<LI>::idx(lb);
+                    b_lt_a = ib > ia; a_lt_b = ia > ib;
+                }
                 bool sw = up ? b_lt_a : a_lt_b;
                 if (sw) { key[i] = kb; key[l] = ka; li[i] = lb; li[l] = la; }
             }
@@ -1375,6 +1381,100 @@ __global__ __launch_bounds__(BLOCK) void k_eval(const int64_t* __restrict__ uptr
             out4[4 * (size_t)u + 1] = (npairs > 0.0) ? 1.0 : 0.0;
             out4[4 * (size_t)u + 2] = dcg / idcg[u];
             out4[4 * (size_t)u + 3] = 1.0;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_eval2: the evaluator in O(len * T * log len) instead of O(len^2), for rating sets with at most 64
+// distinct RAW rating values per user (the reference compares raw doubles, util.cpp:471-475).
+// Scores are sorted by (raw level, score); then
+//   #{(a,b): s_a >= s_b && v_a < v_b} = sum_a sum_{l' > l_a} #{b in run l' : s_b <= s_a}   (upper_bound)
+// and the top-k by score is a k-step merge of the run tails by one wave (ties: lower index first).
+// Same out4 layout as k_eval.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+static inline size_t eval2_bytes(int cap, int cap_pad, int rs_cap) {
+    return carve_bytes(cap_pad, sizeof(T)) + carve_bytes(cap_pad, 4) + carve_bytes(cap, 4) + carve_bytes(rs_cap, 4);
+}
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_eval2(const int64_t* __restrict__ uptr, const int32_t* __restrict__ item,
+                                                 const uint16_t* __restrict__ elvl, const int64_t* __restrict__ erunofs,
+                                                 const int32_t* __restrict__ erunstart, const double* __restrict__ gain,
+                                                 const double* __restrict__ idcg, const double* __restrict__ disc, int ndcg_k,
+                                                 const int32_t* __restrict__ users, int nusers, const T* __restrict__ U,
+                                                 const T* __restrict__ Vm, Geo geo, double* __restrict__ out4, int cap, int cap_pad,
+                                                 int rs_cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Carver small(smem);
+    T* vecT = small.take<T>(geo.ld);
+    double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
+    T* key = small.take<T>(cap_pad);
+    uint32_t* li = small.take<uint32_t>(cap_pad);
+    int32_t* itm = small.take<int32_t>(cap);
+    int* rs = small.take<int>(rs_cap);
+    const int tid = threadIdx.x;
+    for (int ui = blockIdx.x; ui < nusers; ui += gridDim.x) {
+        const int u = users[ui];
+        const int64_t s0 = uptr[u];
+        const int n = (int)(uptr[u + 1] - s0);
+        const int nlev = (int)(erunofs[u + 1] - erunofs[u]) - 1;
+        if (n == 0) {
+            if (tid == 0) { out4[4 * (size_t)u] = 0.0; out4[4 * (size_t)u + 1] = 0.0; out4[4 * (size_t)u + 2] = 0.0; out4[4 * (size_t)u + 3] = 0.0; }
+            continue;
+        }
+        for (int t = tid; t < geo.ld; t += BLOCK) vecT[t] = U[(size_t)u * geo.ld + t];
+        for (int p = tid; p < n; p += BLOCK) itm[p] = item[s0 + p];
+        for (int l = tid; l <= nlev; l += BLOCK) rs[l] = erunstart[erunofs[u] + l];
+        __syncthreads();
+        block_sddmm<T, BLOCK>(Vm, vecT, itm, n, key, geo);
+        const int npad = next_pow2(n);
+        for (int p = tid; p < npad; p += BLOCK) {
+            if (p < n) li[p] = LiOps<uint32_t>::pack(elvl[s0 + p], (unsigned)p);
+            else { li[p] = LiOps<uint32_t>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
+        }
+        __syncthreads();
+        bitonic_sort<T, uint32_t, BLOCK, true>(key, li, npad);
+        // ---- mis-ordered pairs
+        double bad = 0.0;
+        for (int p = tid; p < n; p += BLOCK) {
+            const int lev = (int)LiOps<uint32_t>::lev(li[p]);
+            const T sa = key[p];
+            unsigned cnt = 0;
+            for (int l = lev + 1; l < nlev; ++l) cnt += (unsigned)(ubound(key, rs[l], rs[l + 1], sa) - rs[l]);
+            bad += (double)cnt;
+        }
+        const double badsum = block_sum<BLOCK>(bad, red);               // exact below 2^53
+        const double npairs = 0.5 * (double)n * (double)(n - 1);
+        // ---- top-k: wave 0 merges the run tails (lane l owns run l; nlev <= 64)
+        if (tid < PCR_WAVE) {
+            const int lane = tid;
+            int cur = (lane < nlev) ? rs[lane + 1] - 1 : -1;
+            const int lo = (lane < nlev) ? rs[lane] : 0;
+            const int nowk = n < ndcg_k ? n : ndcg_k;
+            double dcg = 0.0;
+            for (int k = 0; k < nowk; ++k) {
+                const bool have = (lane < nlev) && cur >= lo;
+                T best = have ? key[cur] : (T)0;
+                int bi = have ? (int)LiOps<uint32_t>::idx(li[cur]) : -1;
+                int owner = lane;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const T ob = __shfl_xor(best, off);
+                    const int oi = __shfl_xor(bi, off);
+                    const int oo = __shfl_xor(owner, off);
+                    if (oi >= 0 && (bi < 0 || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; owner = oo; }
+                }
+                if (lane == owner) cur -= 1;
+                dcg += gain[s0 + bi] * disc[k];
+            }
+            if (lane == 0) {
+                out4[4 * (size_t)u] = (npairs > 0.0) ? badsum / npairs : 0.0;
+                out4[4 * (size_t)u + 1] = (npairs > 0.0) ? 1.0 : 0.0;
+                out4[4 * (size_t)u + 2] = dcg / idcg[u];
+                out4[4 * (size_t)u + 3] = 1.0;
+            }
         }
         __syncthreads();
     }

@@ -149,6 +149,10 @@ struct Solver final : pcr_solver {
         DBuf<int64_t> uptr;
         DBuf<int32_t> item;
         DBuf<double> val, gain, idcg, disc;
+        DBuf<uint16_t> elvl;              // dense rank of the RAW rating inside the user (util.cpp:471 compares doubles)
+        DBuf<int64_t> erunofs;
+        DBuf<int32_t> erunstart;
+        int max_raw_levels = 0;
         std::vector<Bin> bins;
         std::vector<int64_t> h_uptr;
         std::vector<double> h_val;
@@ -386,7 +390,18 @@ struct Solver final : pcr_solver {
             for (int64_t z = 0; z < es.nnz; ++z) gain[z] = pow(2.0, es.h_val[z]) - 1.0;     // util.cpp:519
             RC(es.gain.upload(gain, st));
             RC(es.idcg.alloc(nu));
-            make_bins(es.h_uptr, nu, nullptr, es.bins);
+            {
+                PcrLevels rl;
+                std::string e2;
+                if (pcr_build_levels(E, first_user, first_user + nu, PCR_SOLVER_PCR, rl, e2) == PCR_OK) {
+                    es.max_raw_levels = rl.max_levels;
+                    RC(es.elvl.upload(rl.level, st)); RC(es.erunofs.upload(rl.run_ofs, st)); RC(es.erunstart.upload(rl.run_start, st));
+                    make_bins(es.h_uptr, nu, &rl.run_ofs, es.bins);
+                } else {
+                    es.max_raw_levels = 1 << 30;
+                    make_bins(es.h_uptr, nu, nullptr, es.bins);
+                }
+            }
             for (auto& bn : es.bins) RC(bn.d_users.upload(bn.users, st));
         }
         RC(d_out4.alloc(4 * (size_t)std::max<int64_t>(nu, 1)));
@@ -439,6 +454,7 @@ struct Solver final : pcr_solver {
         HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_eval<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_eval2<T, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         return PCR_OK;
     }
 
@@ -821,10 +837,19 @@ struct Solver final : pcr_solver {
         }
         // dcg uses gain/discount products in the reference's order: gain / log2(k+1); keep the division exact
         {
+            const bool fast_eval = es.max_raw_levels <= 64 && !(getenv("PCR_EVAL_BRUTE") && atoi(getenv("PCR_EVAL_BRUTE")));
             const int64_t* up = which == 0 ? d_uptr.p : es.uptr.p;
             const int32_t* it = which == 0 ? d_item.p : es.item.p;
             auto fn = [&](Bin& b, hipStream_t q) {
                 const int nus = (int)b.users.size();
+                if (fast_eval && !b.big) {               // O(len T log len): sort by (raw level, score)
+                    const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
+                    const size_t lds2 = small_common(b.block) + eval2_bytes<T>(b.cap, cap_pad, rsc);
+#define LE2(BL) hipLaunchKernelGGL((k_eval2<T, BL>), dim3(nus), dim3(BL), lds2, q, up, it, es.elvl.p, es.erunofs.p, es.erunstart.p, es.gain.p, es.idcg.p, es.disc.p, ndcg_k, b.d_users.p, nus, d_U.p, d_V.p, geo, d_out4.p, b.cap, cap_pad, rsc)
+                    if (b.block == 64) LE2(64); else if (b.block == 256) LE2(256); else LE2(512);
+#undef LE2
+                    return;
+                }
                 const size_t smallb = small_common(b.block) + carve_bytes(b.block / PCR_WAVE + 1, sizeof(T)) + carve_bytes(b.block / PCR_WAVE + 1, 4);
                 const size_t lds = smallb + (b.big ? 0 : eval_bytes<T>(b.cap));
                 const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
