@@ -87,6 +87,8 @@ typedef struct pcr_dataset pcr_dataset;   /* training CSR + test CSR, host memor
  * testset_t::load + util.cpp:219-274 convert(): reads <dir>/meta and the rating
  * files it names. */
 int pcr_dataset_load(const char *dir, pcr_dataset **out);                 /* [host] */
+/* the same with `threads` host parser threads (the CLI passes -n; 0 = up to 16) */
+int pcr_dataset_load_mt(const char *dir, int threads, pcr_dataset **out); /* [host] */
 /* same conversion from in-memory 0-based triplets (train in any order; test must
  * be user-sorted, util.cpp:259-261).  tnnz may be 0. */
 int pcr_dataset_from_triplets(int64_t d1, int64_t d2,

@@ -82,7 +82,7 @@ int main(int argc, char** argv) {
     fclose(fp);
 
     pcr_dataset* ds = nullptr;
-    if (pcr_dataset_load(input.c_str(), &ds) != PCR_OK) die("load");
+    if (pcr_dataset_load_mt(input.c_str(), param.threads, &ds) != PCR_OK) die("load");
     int64_t d1, d2, nnz, tnnz;
     pcr_dataset_dims(ds, &d1, &d2, &nnz, &tnnz);
     const int k = param.k;

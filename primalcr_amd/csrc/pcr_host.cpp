@@ -13,6 +13,7 @@
 #include <cstring>
 #include <numeric>
 #include <random>
+#include <thread>
 
 static thread_local std::string g_err;
 void pcr_set_error(const std::string& msg) { g_err = msg; }
@@ -142,32 +143,128 @@ static int read_file(const std::string& path, std::vector<char>& buf) {
     return PCR_OK;
 }
 
-// "%d %d %lf" per entry, 1-based ids (util.h:126,131; util.h:367-368)
+// One rating "user item value" (util.h:126, util.h:367).  Fast path for the common "digits digits
+// [-]digits[.digits]" shape, strtol/strtod for anything else (exponents, inf, ...).
+static inline bool parse_one(const char*& p, const char* end, int32_t& u, int32_t& it, double& v) {
+    auto skip_ws = [&]() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p; };
+    auto parse_uint = [&](long& out) -> bool {
+        skip_ws();
+        const char* s = p;
+        long x = 0;
+        while (p < end && *p >= '0' && *p <= '9') { x = x * 10 + (*p - '0'); ++p; }
+        if (p == s || (p < end && (*p == '.' || *p == '-' || *p == '+' || *p == 'e' || *p == 'E'))) { p = s; return false; }
+        out = x;
+        return true;
+    };
+    const char* save = p;
+    long a, b;
+    if (parse_uint(a) && parse_uint(b)) {
+        skip_ws();
+        const char* s = p;
+        bool neg = false;
+        if (p < end && (*p == '-' || *p == '+')) { neg = *p == '-'; ++p; }
+        long ip = 0; int nd = 0;
+        while (p < end && *p >= '0' && *p <= '9' && nd < 15) { ip = ip * 10 + (*p - '0'); ++p; ++nd; }
+        bool simple = nd > 0 || (p < end && *p == '.');
+        double val = (double)ip;
+        if (simple && p < end && *p == '.') {
+            ++p;
+            long fp = 0; int fd = 0;
+            while (p < end && *p >= '0' && *p <= '9' && fd < 15) { fp = fp * 10 + (*p - '0'); ++p; ++fd; }
+            static const double P10[16] = {1, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+            // exact only when the decimal is short; otherwise defer to strtod for correct rounding
+            if (nd + fd > 15 || (p < end && *p >= '0' && *p <= '9')) simple = false;
+            else if (fd > 0) val = (double)(ip * (long)P10[fd] + fp) / P10[fd];
+        }
+        if (simple && (p >= end || *p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == 0)) {
+            u = (int32_t)(a - 1); it = (int32_t)(b - 1); v = neg ? -val : val;
+            return true;
+        }
+        p = s;
+        char* e;
+        double dv = strtod(p, &e);
+        if (e == p) { p = save; return false; }
+        p = e;
+        u = (int32_t)(a - 1); it = (int32_t)(b - 1); v = dv;
+        return true;
+    }
+    p = save;                                           // signs / odd formats in the ids: the libc path
+    char* e;
+    long i = strtol(p, &e, 10);
+    if (e == p) return false;
+    p = e;
+    long j = strtol(p, &e, 10);
+    if (e == p) return false;
+    p = e;
+    double dv = strtod(p, &e);
+    if (e == p) return false;
+    p = e;
+    u = (int32_t)(i - 1); it = (int32_t)(j - 1); v = dv;
+    return true;
+}
+
+// "%d %d %lf" per entry, 1-based ids (util.h:126,131; util.h:367-368); exactly nnz entries are read.
+// Parsed by `threads` host threads: the buffer is cut at line boundaries, lines are counted per
+// piece, then every piece parses into its slice of the output.
 static int parse_ratings(const std::string& path, int64_t nnz, std::vector<int32_t>& user,
-                         std::vector<int32_t>& item, std::vector<double>& val) {
+                         std::vector<int32_t>& item, std::vector<double>& val, int threads) {
     std::vector<char> buf;
     int rc = read_file(path, buf);
     if (rc != PCR_OK) return rc;
     user.resize(nnz); item.resize(nnz); val.resize(nnz);
-    char* p = buf.data();
-    for (int64_t z = 0; z < nnz; ++z) {
-        char* e;
-        long i = strtol(p, &e, 10);
-        if (e == p) { pcr_set_error(path + ": expected " + std::to_string(nnz) + " ratings, found " + std::to_string(z)); return PCR_ERR_IO; }
-        p = e;
-        long j = strtol(p, &e, 10);
-        if (e == p) { pcr_set_error(path + ": malformed rating line " + std::to_string(z + 1)); return PCR_ERR_IO; }
-        p = e;
-        double v = strtod(p, &e);
-        if (e == p) { pcr_set_error(path + ": malformed rating line " + std::to_string(z + 1)); return PCR_ERR_IO; }
-        p = e;
-        user[z] = (int32_t)(i - 1); item[z] = (int32_t)(j - 1); val[z] = v;
+    const char* base = buf.data();
+    const size_t len = buf.size() - 1;
+    int T = std::max(1, std::min(threads, 64));
+    if (len < (size_t)1 << 20) T = 1;
+    std::vector<size_t> cut(T + 1, len);
+    cut[0] = 0;
+    for (int t = 1; t < T; ++t) {
+        size_t c = len * t / T;
+        while (c < len && base[c] != '\n') ++c;
+        cut[t] = c < len ? c + 1 : len;
     }
+    auto nonblank_lines = [&](size_t a, size_t b) {
+        int64_t n = 0; bool content = false;
+        for (size_t q = a; q < b; ++q) {
+            if (base[q] == '\n') { n += content; content = false; }
+            else if (base[q] != ' ' && base[q] != '\t' && base[q] != '\r') content = true;
+        }
+        return n + (content ? 1 : 0);
+    };
+    std::vector<int64_t> first(T + 1, 0);
+    {
+        std::vector<int64_t> cnt(T, 0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back([&, t]() { cnt[t] = nonblank_lines(cut[t], cut[t + 1]); });
+        for (auto& x : th) x.join();
+        for (int t = 0; t < T; ++t) first[t + 1] = first[t] + cnt[t];
+    }
+    if (first[T] < nnz) {
+        pcr_set_error(path + ": expected " + std::to_string(nnz) + " ratings, found " + std::to_string(first[T]));
+        return PCR_ERR_IO;
+    }
+    std::vector<int64_t> bad(T, -1);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t]() {
+                const char* p = base + cut[t];
+                const char* end = base + cut[t + 1];
+                for (int64_t z = first[t]; z < first[t + 1] && z < nnz; ++z)
+                    if (!parse_one(p, end, user[z], item[z], val[z])) { bad[t] = z; return; }
+            });
+        for (auto& x : th) x.join();
+    }
+    for (int t = 0; t < T; ++t)
+        if (bad[t] >= 0) { pcr_set_error(path + ": malformed rating line " + std::to_string(bad[t] + 1)); return PCR_ERR_IO; }
     return PCR_OK;
 }
 
-extern "C" int pcr_dataset_load(const char* dir, pcr_dataset** out) {
+extern "C" int pcr_dataset_load(const char* dir, pcr_dataset** out) { return pcr_dataset_load_mt(dir, 0, out); }
+
+extern "C" int pcr_dataset_load_mt(const char* dir, int threads, pcr_dataset** out) {
     if (!dir || !out) { pcr_set_error("pcr_dataset_load: bad argument"); return PCR_ERR_ARG; }
+    if (threads <= 0) threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::string d(dir);
     std::string metap = d + "/meta";
     FILE* fp = fopen(metap.c_str(), "r");
@@ -184,10 +281,10 @@ extern "C" int pcr_dataset_load(const char* dir, pcr_dataset** out) {
     fclose(fp);
     std::vector<int32_t> u, i, tu, ti;
     std::vector<double> v, tv;
-    int rc = parse_ratings(d + "/" + name, nnz, u, i, v);
+    int rc = parse_ratings(d + "/" + name, nnz, u, i, v, threads);
     if (rc != PCR_OK) return rc;
     if (have_test) {
-        rc = parse_ratings(d + "/" + tname, tnnz, tu, ti, tv);
+        rc = parse_ratings(d + "/" + tname, tnnz, tu, ti, tv, threads);
         if (rc != PCR_OK) return rc;
     } else {
         tnnz = 0;
