@@ -64,3 +64,59 @@ def test_headline_config_matches_reference_binary(tmp_path):
             assert abs(rec["obj"] / objs[k] - 1) < 1e-3
         assert abs(rec["test_err"] - te[k][0]) < 1e-3 and abs(rec["test_ndcg"] - te[k][1]) < 1e-3
         assert abs(rec["train_err"] - tr[k][0]) < 1e-3 and abs(rec["train_ndcg"] - tr[k][1]) < 1e-3
+
+
+def test_config0_toy_shaped_real_valued_k10(oracle):
+    """BASELINE configs[0]: toy-example-shaped data (6040 x 3952, ~900k REAL-VALUED ratings, PrimalCR++ -k 10):
+    the reference's own CPU-runnable case.  fp64 on the GPU vs the oracle: one outer iteration function by
+    function (real-valued ratings are bucketed by lround into ~9 levels; k = 10 takes the 4-lane row path)."""
+    import primalcr_amd as pcr
+    from primalcr_amd import synth
+    R = synth.generate("toy")
+    r, lam = 10, 5000.0
+    X = oracle.build_csr(R.d1, R.d2, R.user, R.item, R.val)
+    U0, V0 = pcr.initial(R.d1, r), pcr.initial(R.d2, r)
+    s = pcr.Solver(pcr.Dataset.from_ratings(R), pcr.Parameter(k=r, precision=pcr.PCR_F64, **{"lambda": lam}))
+    s.set_factors(U0, V0)
+    m = s.comp_m()
+    mo = oracle.comp_m(U0, V0, X)
+    assert np.abs(m - mo).max() < 1e-12
+    assert abs(s.objective() / oracle.objective_new(mo, U0, V0, X, lam) - 1) < 1e-11
+    g, go = s.obtain_g(), oracle.obtain_g_new(U0, V0, X, mo, lam)
+    assert np.abs(g - go).max() / np.abs(go).max() < 1e-10
+    V1, m1, objV, info_o = oracle.update_V_new(X, lam, 1.0, U0, V0)
+    oV, info = s.update_V()
+    assert info["cg"] == info_o["cg"] and info["ls"] == info_o["ls"]
+    assert abs(oV / objV - 1) < 1e-9
+    U1, objU, iu_o = oracle.update_U_new(X, m1, lam, 1.0, V1, U0)
+    oU, iu = s.update_U()
+    Ug, Vg = s.get_factors()
+    assert np.abs(Vg - V1).max() / np.abs(V1).max() < 1e-7 and np.abs(Ug - U1).max() / np.abs(U1).max() < 1e-7
+    assert abs(oU / objU - 1) < 1e-9 and iu["cg"] == iu_o["cg"] and iu["ls"] == iu_o["ls"]
+
+
+def test_config2_solver1_ml1m_vs_reference_binary(tmp_path):
+    """BASELINE configs[2]: ml1m-shaped, PrimalCR (solver 1) -k 100: default precision on the GPU vs the unmodified
+    reference binary (-s 1), 2 outer iterations: NDCG@10 / pairwise error within 1e-3."""
+    import os
+    import re
+    import subprocess
+    import primalcr_amd as pcr
+    from oracle import oracle_py
+    from primalcr_amd import synth
+    if not os.path.exists(oracle_py.REF_TRAIN):
+        pytest.skip("oracle/_ref was not built (no /root/reference at build time)")
+    R = synth.generate("ml1m")
+    d = synth.write_dir(R, str(tmp_path / "ml1m"))
+    iters = 2
+    out = subprocess.run([oracle_py.REF_TRAIN, "-s", "1", "-k", "100", "-l", "5000", "-t", str(iters), "-n", "16",
+                          d, str(tmp_path / "ref.model")], cwd=tmp_path, capture_output=True, text=True, check=True).stdout
+    te = [(float(a), float(b)) for a, b in re.findall(r"^\(Testing\) pairwise error is (\S+) and ndcg is (\S+)$", out, re.M)]
+    tr = [(float(a), float(b)) for a, b in re.findall(r"^\(Training\) pairwise error is (\S+) and ndcg is (\S+)$", out, re.M)]
+    s = pcr.Solver(pcr.Dataset.load(d), pcr.Parameter(k=100, solver_type=1, maxiter=iters, **{"lambda": 5000.0}))
+    s.set_factors(pcr.initial(R.d1, 100), pcr.initial(R.d2, 100))
+    recs, lines = s.train()
+    assert lines[0] == "running PrimalCR ndcg_k is 10"
+    for k, rec in enumerate(recs):
+        assert abs(rec["test_err"] - te[k][0]) < 1e-3 and abs(rec["test_ndcg"] - te[k][1]) < 1e-3
+        assert abs(rec["train_err"] - tr[k][0]) < 1e-3 and abs(rec["train_ndcg"] - tr[k][1]) < 1e-3
