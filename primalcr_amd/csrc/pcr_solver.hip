@@ -467,7 +467,10 @@ struct Solver final : pcr_solver {
         for (size_t i = 0; i < bs.size(); ++i) if (bs[i].users.size() > most) { most = bs[i].users.size(); main_bin = (int)i; }
         if (main_bin < 0) return PCR_OK;
         bool forked = false;
-        for (size_t i = 0; i < bs.size(); ++i) {
+        // longest users first: their workgroups are the critical path and must not queue behind the many
+        // short-user workgroups
+        for (size_t ii = bs.size(); ii-- > 0;) {
+            const size_t i = ii;
             if (bs[i].users.empty() || (int)i == main_bin) continue;
             if (!forked) { HIPCHK(hipEventRecord(ev_fork, st)); forked = true; }
             HIPCHK(hipStreamWaitEvent(side[i], ev_fork, 0));
