@@ -1197,9 +1197,9 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         un2 = block_sum<BLOCK>(un2, red);
         gn2 = block_sum<BLOCK>(gn2, red);
         // ---- prev_obj, objective_u_new (pcrpp.cpp:542-573)
-        const double prev_obj = lambda / 2.0 * un2 +
-            (win ? block_objective_win<T, BLOCK>(ms0, [&](int p) { return (int)lv0[p]; }, rs, nlev, n, win, S.ws, Sx, red)
-                 : block_objective<T, BLOCK>(ms0, [&](int p) { return (int)lv0[p]; }, rs, nlev, n, Sx, red, strict));
+        // the user's loss at the gradient point is what the last k_prepare left in objp[u] (same m, same windows):
+        // no need to sweep for it again
+        const double prev_obj = lambda / 2.0 * un2 + S.objp[u];
         double obj_new = prev_obj;
         int n_cg = 0, n_ls = 0;
         // pcrpp.cpp:787-790; PrimalCR additionally keeps u when no comparable pair exists

@@ -466,6 +466,9 @@ struct Solver final : pcr_solver {
         size_t most = 0;
         for (size_t i = 0; i < bs.size(); ++i) if (bs[i].users.size() > most) { most = bs[i].users.size(); main_bin = (int)i; }
         if (main_bin < 0) return PCR_OK;
+        // wall time of the whole concurrent group on the solver's stream (fork .. join): the per-bin slots
+        // overlap, so their sum overstates the group's share of the timed region
+        ProfScope wall(this, std::string("wall:") + cls, st);
         bool forked = false;
         // longest users first: their workgroups are the critical path and must not queue behind the many
         // short-user workgroups
