@@ -5,6 +5,8 @@
 // Extensions use long options the reference would reject anyway (unknown option -> usage, exit 1):
 //   --f64          fp64 storage on the device (default: fp32 storage, fp64 accumulation)
 //   --device N     HIP device ordinal
+//   --init-model F warm start: take the initial U, V from a model file instead of initial()
+//                  (the reference only has a commented-out text-file variant, pmf-train.cpp:262-263)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,7 +31,8 @@ static void exit_with_help() {
         "    -t max_iter: set the number of iterations (default 10)\n"
         "    -p do_predict: compute training/testing error & NDCG at each iteration or not (default 1)\n"
         "    --f64 : keep U, V in fp64 on the GPU (default fp32 storage, fp64 accumulation)\n"
-        "    --device id : GPU to use (default 0)\n");
+        "    --device id : GPU to use (default 0)\n"
+        "    --init-model file : warm start from a model file\n");
     exit(1);
 }
 
@@ -41,12 +44,14 @@ static void die(const char* what) {
 int main(int argc, char** argv) {
     pcr_params param;
     pcr_params_default(&param);
+    std::string init_model;
     int i;
     for (i = 1; i < argc; i++) {                       // pmf-train.cpp:36-108
         if (argv[i][0] != '-') break;
         if (!strcmp(argv[i], "--f64")) { param.precision = PCR_F64; continue; }
         if (++i >= argc) exit_with_help();
         if (!strcmp(argv[i - 1], "--device")) { param.device = atoi(argv[i]); continue; }
+        if (!strcmp(argv[i - 1], "--init-model")) { init_model = argv[i]; continue; }
         switch (argv[i - 1][1]) {
             case 's': param.solver_type = atoi(argv[i]); break;
             case 'k': param.k = atoi(argv[i]); break;
@@ -89,6 +94,16 @@ int main(int argc, char** argv) {
     std::vector<double> U((size_t)d1 * k), V((size_t)d2 * k);
     pcr_initial(U.data(), d1, k);                      // pmf-train.cpp:264-266
     pcr_initial(V.data(), d2, k);
+    if (!init_model.empty()) {                         // warm start
+        int64_t m1, m2, kk;
+        if (pcr_model_load(init_model.c_str(), &m1, &m2, &kk, nullptr, nullptr) != PCR_OK) die("init-model");
+        if (m1 != d1 || m2 != d2 || kk != k) {
+            fprintf(stderr, "init-model %s is %ld x %ld / %ld x %ld, expected %ld x %d / %ld x %d\n", init_model.c_str(),
+                    (long)m1, (long)kk, (long)m2, (long)kk, (long)d1, k, (long)d2, k);
+            return 1;
+        }
+        if (pcr_model_load(init_model.c_str(), &m1, &m2, &kk, U.data(), V.data()) != PCR_OK) die("init-model");
+    }
     std::cout << "the rank is " << k << std::endl;
     std::cout << "the number of rows is " << d1 << " and the number of cols is " << d2 << std::endl;
     if (param.solver_type == PCR_SOLVER_PCRPP) { std::cout << nnz << std::endl; std::cout << "starts!" << std::endl; }

@@ -107,3 +107,20 @@ def test_train_cli_default_precision_quality(tmp_path):
     assert len(a) == len(b) > 0
     for (t1, e1, n1), (t2, e2, n2) in zip(a, b):
         assert t1 == t2 and abs(float(e1) - float(e2)) < 1e-3 and abs(float(n1) - float(n2)) < 1e-3
+
+
+@pytest.mark.gpu
+def test_warm_start_continues_the_trajectory(tmp_path):
+    """--init-model: 2 iterations, then 1 more from the saved model == 3 iterations in one run
+    (fp64: every outer iteration recomputes m and resets the step size, so the state is just U and V)."""
+    g, meta, d = golden_dir("mid5", tmp_path)
+    base = [TRAIN, "-k", str(int(g["r"])), "-l", repr(float(g["lam"])), "-p", "0", "--f64"]
+    assert run(base + ["-t", "3", d, "m3.model"], tmp_path).returncode == 0
+    assert run(base + ["-t", "2", d, "m2.model"], tmp_path).returncode == 0
+    r = run(base + ["-t", "1", "--init-model", "m2.model", d, "m21.model"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    a = np.frombuffer(open(tmp_path / "m3.model", "rb").read(), np.float64)
+    b = np.frombuffer(open(tmp_path / "m21.model", "rb").read(), np.float64)
+    assert a.shape == b.shape and np.nanmax(np.abs(a[2:] - b[2:])) < 1e-9 * np.nanmax(np.abs(a[2:]))
+    bad = run(base + ["-k", "3", "-t", "1", "--init-model", "m2.model", d, "x.model"], tmp_path)
+    assert bad.returncode == 1 and "expected" in bad.stderr
