@@ -1,21 +1,23 @@
 // pcr_kernels.h -- hand-written HIP kernels for gfx950 (CDNA4, wave64) of the PrimalCR /
 // PrimalCR++ hot path.  Header-only templates, instantiated in pcr_solver.hip.
 //
-// Kernel map (reference site -> kernel), SURVEY 2.4:
-//   K1+K2+K6  comp_m_new + get_sorted_mm + objective_new   -> k_prepare   (per user)
-//   K4        obtain_g_new  sweep (pcrpp.cpp:214-238)      -> k_vsweep<GRAD> + k_spmm
-//   K5        compute_Ha_new sweep (pcrpp.cpp:294-318)     -> k_vsweep<HV>   + k_spmm
-//   K7        solve_delta_new vector ops (pcrpp.cpp:335)   -> k_cg_*
-//   K8        update_u_new (pcrpp.cpp:779-815)             -> k_ustep     (per user, fused)
-//   K10       compute_pairwise_error_ndcg (util.cpp:434)   -> k_eval      (per user)
+// Kernel map (reference site -> kernel); design and rooflines: DESIGN.md section 3:
+//   K1        comp_m_new, b = u.a in compute_Ha_new        -> k_sddmm     (rating-parallel)
+//   K2+K6     get_sorted_mm + objective_new                -> k_prepare   (per user: sort, windows, loss)
+//   K4        obtain_g_new  sweep (pcrpp.cpp:214-238)      -> k_vsweep<GRAD> / k_vsweep_wave + k_spmm + k_spmm_fin
+//   K5        compute_Ha_new sweep (pcrpp.cpp:294-318)     -> k_vsweep<HV>   / k_vsweep_wave + k_spmm + k_spmm_fin
+//   K7        solve_delta_new vector ops (pcrpp.cpp:335)   -> k_cg_init / k_cg_a / k_cg_b / k_cg_c
+//   K8        update_u_new (pcrpp.cpp:779-815)             -> k_ustep     (per user, fused; K workgroups per long user)
+//   K10       compute_pairwise_error_ndcg (util.cpp:434)   -> k_eval2 (sorted) / k_eval (brute force)
+//             pmf-predict.cpp:56-64                        -> k_predict
 //
 // Formulation (replaces the sequential two-pointer sweep with data-parallel primitives,
 // same result): a user's ratings are sorted by (level, m), so every rating level is one
 // sorted run.  For item p of level l and another level l':
 //     l' > l : partners are the run prefix {q : m_q <= m_p + 1}   (pcrpp.cpp:218)
 //     l' < l : partners are the run suffix {q : m_q >= m_p - 1}   (pcrpp.cpp:224)
-// found by binary search; counts come from the indices, sums from ONE fp64 exclusive prefix
-// sum over the sorted order.  Work per pass O(len * T * log len), all lane-parallel in LDS.
+// found by binary search ONCE per sorted state (window cache); counts come from the indices, sums
+// from one fp64 exclusive prefix sum over the sorted order.  Every later sweep is O(len * T).
 //
 // Layout: factor rows are padded to ld = roundup(k, 4) elements so every row is 16-byte
 // aligned; a row is read by a group of G lanes (G = pow2 >= ld/VEC, <= 64), one 16-byte
@@ -876,12 +878,6 @@ struct CGState {
 #define PCR_EW_BLOCK 256
 
 template <typename T>
-__global__ void k_scale(T* __restrict__ out, const T* __restrict__ in, double s, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (T)(s * (double)in[i]);
-}
-
-template <typename T>
 __global__ void k_axpy_out(T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b, double s, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // out = a + s*b (mat_substract_vec, util.cpp:395)
     if (i < n) out[i] = (T)((double)a[i] + s * (double)b[i]);
@@ -966,11 +962,10 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_init_fin(const double* __re
     }
 }
 
-// A: partials of p.Hp and rr.p   (Hp += lam_add * p first: the lambda*p term when it was not
-// folded into the SpMM's initial value, i.e. after a multi-GPU all-reduce)
+// A: partials of p.Hp and rr.p
 template <typename T>
-__global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_a(const T* __restrict__ p, T* __restrict__ Hp, const T* __restrict__ rr,
-                                                        double lam_add, int64_t n, int per_block, double* __restrict__ part,
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_a(const T* __restrict__ p, const T* __restrict__ Hp, const T* __restrict__ rr,
+                                                        int64_t n, int per_block, double* __restrict__ part,
                                                         CGState* st) {
     __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
     if (st->done) return;     // CG already converged: later iterations are queued but idle
@@ -979,8 +974,7 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_a(const T* __restrict__ p, 
     double x = 0.0, y = 0.0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) {
         const double pv = (double)p[i];
-        double h = (double)Hp[i];
-        if (lam_add != 0.0) { h += lam_add * pv; Hp[i] = (T)h; h = (double)Hp[i]; }
+        const double h = (double)Hp[i];
         x += pv * h;
         y += (double)rr[i] * pv;
     }

@@ -174,7 +174,6 @@ struct Solver final : pcr_solver {
     bool have_sorted = false;
     double unorm2 = 0.0;                          // all-rank |U|^2 of the current U
     bool unorm_valid = false;
-    double last_loss = 0.0;                       // all-rank loss of the last prepare
 
     ~Solver() override {
         if (st) (void)hipStreamSynchronize(st);
@@ -633,7 +632,6 @@ struct Solver final : pcr_solver {
         RC(allreduce_f64(d_scal.p, 1));
         RC(norm2(Vm, (int64_t)d2 * geo.ld, 2));
         RC(fetch_scal(4));
-        last_loss = h_scal[0];
         *obj = h_scal[0] + prm.lambda * (unorm2 + h_scal[2]) / 2.0;
         return PCR_OK;
     }
@@ -730,7 +728,7 @@ struct Solver final : pcr_solver {
             RC(device_hv(d_p.p, d_Hp.p, skip));
             {
                 ProfScope ps(this, "cg");
-                hipLaunchKernelGGL((k_cg_a<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, 0.0, n, ew_per_block, d_partA.p, d_cg.p);
+                hipLaunchKernelGGL((k_cg_a<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, n, ew_per_block, d_partA.p, d_cg.p);
                 hipLaunchKernelGGL((k_cg_b<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, d_delta.p, n, ew_per_block, ew_blocks, d_partA.p, d_partB.p, d_cg.p);
                 hipLaunchKernelGGL((k_cg_c<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_rr.p, n, ew_per_block, ew_blocks, d_partB.p, d_cg.p);
             }
