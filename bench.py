@@ -87,7 +87,7 @@ def slot_kernel_match(slot, kernel_name, prec):
         return False
     if not tag:
         return True
-    block = tag.rstrip("gc")
+    block = tag.rstrip("gct")
     big, clu = "g" in tag[len(block):], "c" in tag[len(block):]
     if args[1] != block or (args[2] == "true") != big:
         return False
@@ -238,8 +238,16 @@ def main():
         lens = np.diff(idx)[s.first_user:s.first_user + s.n_users]
         vbins = {"64": lens <= 128, "256": (lens > 128) & (lens <= 512), "512": (lens > 512) & (lens <= 4096), "512g": lens > 4096}
         sbins = {"64": lens <= 256, "512": (lens > 256) & (lens <= 4096), "512g": lens > 4096}
+        def head_tail(mask, head=32):        # cluster bins: the 32 longest users get 4 workgroups each, the rest one
+            order = np.argsort(-lens, kind="stable")
+            order = order[mask[order]]
+            h = np.zeros_like(mask); t = np.zeros_like(mask)
+            h[order[:head]] = True; t[order[head:]] = True
+            return h, t
+        h3, t3 = head_tail((lens > 1024) & (lens <= 4096))
+        h4, t4 = head_tail(lens > 4096)
         ubins = {"64": lens <= 128, "256": (lens > 128) & (lens <= 512), "512": (lens > 512) & (lens <= 1024),
-                 "512c": (lens > 1024) & (lens <= 4096), "512gc": lens > 4096, "512g": lens > 4096}
+                 "512c": h3, "512t": t3, "512gc": h4, "512gt": t4}
         esz = 4 if prec == pcr.PCR_F32 else 8
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")      # PMC passes of this command (tools/pmc_traffic.py)

@@ -63,6 +63,11 @@ struct DBuf {
         return PCR_OK;
     }
     void free() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    DBuf() = default;
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    DBuf(DBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { free(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
     ~DBuf() { free(); }
 };
 
@@ -71,6 +76,9 @@ struct Bin {
     int block = 64;
     bool big = false;
     int K = 1;           // workgroups per user (k_ustep clusters)
+    bool tail = false;   // the K = 1 remainder of a cluster bin
+    int ugrid = 0;       // k_ustep grid of this bin
+    int scratch_ofs = 0; // first global-scratch slice of this bin (big bins that run concurrently must not share slices)
     int cap = 0;         // longest user in the bin
     int max_lev = 0;
     std::vector<int32_t> users;
@@ -120,7 +128,7 @@ struct Solver final : pcr_solver {
     int64_t d1 = 0, d2 = 0, tnnz_file = 0;
     Geo geo;
     hipStream_t st = nullptr;
-    static constexpr int NSIDE = 6;
+    static constexpr int NSIDE = 8;
     hipStream_t side[NSIDE] = {};                                 // length bins run concurrently
     hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {};
     ncclComm_t comm = nullptr;
@@ -167,6 +175,7 @@ struct Solver final : pcr_solver {
     DBuf<char> d_scratch;
     size_t scratch_stride = 0;
     int scratch_blocks = 0;
+    int u_big_blocks = 0;                         // scratch slices the concurrent big U-step bins need together
     double* h_scal = nullptr;                     // pinned
     CGState* h_cg = nullptr;                      // pinned
     unsigned long long* h_counters = nullptr;     // pinned
@@ -346,6 +355,27 @@ struct Solver final : pcr_solver {
         for (int q = 0; q < 3; ++q) if (ck[q] != 1 && ck[q] != 2 && ck[q] != 4 && ck[q] != 8) ck[q] = 1;
         ubins[2].K = ck[0]; ubins[3].K = ck[1]; ubins[4].K = ck[2];
         max_clusters = std::max(1, ncu / 2);
+        // Clusters trade throughput for latency: only the head of a bin (its longest users, the critical path) gets
+        // them, ncu/(2K) users at most so that all their workgroups fit the chip at once; the rest of the bin runs
+        // one workgroup per user.
+        for (size_t q = 2; q < 5; ++q) {
+            Bin& b = ubins[q];
+            const size_t head = (size_t)std::max(1, ncu / (2 * std::max(1, b.K)));
+            if (b.K > 1 && b.users.size() > head) {
+                Bin tail;
+                tail.block = b.block; tail.big = b.big; tail.K = 1; tail.tail = true; tail.max_lev = b.max_lev;
+                tail.users.assign(b.users.begin() + head, b.users.end());
+                tail.cap = (int)(uptr[tail.users[0] + 1] - uptr[tail.users[0]]);
+                b.users.resize(head);
+                ubins.push_back(std::move(tail));
+            }
+        }
+        u_big_blocks = 0;
+        for (auto& b : ubins) {
+            const int nus = (int)b.users.size();
+            b.ugrid = b.K > 1 ? std::min(nus, std::max(1, ncu / b.K)) * b.K : (b.big ? std::min(nus, 2 * ncu) : nus);
+            if (b.big) { b.scratch_ofs = u_big_blocks; u_big_blocks += b.ugrid; }
+        }
         for (auto& b : ubins) RC(b.d_users.upload(b.users, st));
         {
             size_t need_x = 0;
@@ -434,7 +464,7 @@ struct Solver final : pcr_solver {
             scratch_stride = (need + 255) & ~(size_t)255;
             size_t nbig = bins[3].users.size();
             for (int w = 0; w < 2; ++w) nbig = std::max(nbig, ev[w].bins[3].users.size());
-            scratch_blocks = (int)std::min<size_t>(std::max<size_t>(nbig * 8, 1), (size_t)ncu * 2);
+            scratch_blocks = std::max((int)std::min<size_t>(std::max<size_t>(nbig, 1), (size_t)ncu * 2), u_big_blocks);
             RC(d_scratch.alloc(scratch_stride * (size_t)scratch_blocks));
         }
         RC(set_lds_limits());
@@ -497,7 +527,7 @@ struct Solver final : pcr_solver {
         return PCR_OK;
     }
     // profile slot of one kernel launch: "<class>/<workgroup size>[g]" (g = global-scratch variant)
-    static std::string pname(const char* cls, const Bin& b) { return std::string(cls) + "/" + std::to_string(b.block) + (b.big ? "g" : "") + (b.K > 1 ? "c" : ""); }
+    static std::string pname(const char* cls, const Bin& b) { return std::string(cls) + "/" + std::to_string(b.block) + (b.big ? "g" : "") + (b.K > 1 ? "c" : "") + (b.tail ? "t" : ""); }
     size_t small_common(int block) const { return carve_bytes(geo.ld, sizeof(T)) + carve_bytes(block / PCR_WAVE + 1, 8); }
     int strict() const { return prm.solver_type == PCR_SOLVER_PCR ? 1 : 0; }
 
@@ -784,9 +814,9 @@ struct Solver final : pcr_solver {
             const size_t bi = (size_t)(&b - &ubins[0]);
             ClusterBufs cb{d_bar.p + bi * max_clusters, d_xch.p + bi * max_clusters * xch_stride, xch_stride};
             // clusters: grid <= one workgroup per CU so that every member of every cluster is resident
-            const int nclus = std::min(nus, std::max(1, ncu / b.K));
-            const int grid = b.K > 1 ? nclus * b.K : (b.big ? std::min(nus, scratch_blocks) : nus);
-#define LU(BL, BG, KK) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, strict(), strict(), b.cap, cap_pad, rsc, d_scratch.p, scratch_stride, d_counters.p, cb)
+            const int grid = b.ugrid;
+            char* scr = d_scratch.p + (size_t)b.scratch_ofs * scratch_stride;
+#define LU(BL, BG, KK) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, strict(), strict(), b.cap, cap_pad, rsc, scr, scratch_stride, d_counters.p, cb)
             if (b.big) { if (b.K == 8) LU(512, true, 8); else if (b.K == 4) LU(512, true, 4); else if (b.K == 2) LU(512, true, 2); else LU(512, true, 1); }
             else if (b.block == 64) LU(64, false, 1);
             else if (b.block == 256) LU(256, false, 1);
