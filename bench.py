@@ -65,30 +65,35 @@ def algorithmic_bytes(slot, nnz_b, nu_b, d2, r, esz):
         return 3 * F_V
     if cls == "ustep":             # k_ustep: read ms,sitem,slvl,U,V; write U,objp
         return nnz_b * (esz + 4 + 2) + nu_b * 24 + 2 * F_U + F_V
+    if cls == "cg":                # k_cg_b + k_cg_c: read p,Hp,rr,delta, write rr,delta; read rr,p, write p
+        return 9 * F_V
     return 0
 
 
 # HIP-event slot -> kernel symbol prefix in a rocprofv3 trace (profiles/, tools/pmc_traffic.py)
 SLOT_KERNEL = {"sddmm": "void k_sddmm<", "spmm": "void k_spmm<", "spmm_fin": "void k_spmm_fin<", "prepare": "void k_prepare<",
-               "vgrad": "void k_vsweep", "vhv": "void k_vsweep", "ustep": "void k_ustep<"}
+               "vgrad": "void k_vsweep", "vhv": "void k_vsweep", "ustep": "void k_ustep<", "cg": "void k_cg_"}
 
 
 def slot_kernel_match(slot, kernel_name, prec):
-    """Does a rocprof kernel name belong to this HIP-event slot (class/workgroup size[g][c])?"""
+    """Does a rocprof kernel name belong to this HIP-event slot (class/workgroup size[.bound][g][c][t])?"""
     cls, _, tag = slot.partition("/")
     if not kernel_name.startswith(SLOT_KERNEL.get(cls, "\0")):
         return False
     args = kernel_name[kernel_name.index("<") + 1:kernel_name.index(">")].replace(" ", "").split(",")
     if args[0] != ("float" if prec == "f32" else "double"):
         return False
+    if kernel_name.startswith("void k_vsweep_all<"):           # both LDS classes in one launch: slot tag "all"
+        return cls in ("vgrad", "vhv") and tag == "all" and (args[1] == "true") == (cls == "vhv")
     if kernel_name.startswith("void k_vsweep_wave<"):          # one wave per user: slot tag "64"
         return cls in ("vgrad", "vhv") and tag == "64" and (args[1] == "true") == (cls == "vhv")
     if cls in ("vgrad", "vhv") and not kernel_name.startswith("void k_vsweep<"):
         return False
     if not tag:
         return True
-    block = tag.rstrip("gct")
-    big, clu = "g" in tag[len(block):], "c" in tag[len(block):]
+    flags = tag.lstrip("0123456789.")
+    block = tag[:len(tag) - len(flags)].partition(".")[0]
+    big, clu = "g" in flags, "c" in flags
     if args[1] != block or (args[2] == "true") != big:
         return False
     if cls in ("vgrad", "vhv"):
@@ -234,20 +239,6 @@ def main():
     # ---- roofline of the dominant kernel (rank 0's shard)
     roof, kernels = None, {}
     if prof:
-        idx, _, _ = ds.csr(0)
-        lens = np.diff(idx)[s.first_user:s.first_user + s.n_users]
-        vbins = {"64": lens <= 128, "256": (lens > 128) & (lens <= 512), "512": (lens > 512) & (lens <= 4096), "512g": lens > 4096}
-        sbins = {"64": lens <= 256, "512": (lens > 256) & (lens <= 4096), "512g": lens > 4096}
-        def head_tail(mask, head=32):        # cluster bins: the 32 longest users get 4 workgroups each, the rest one
-            order = np.argsort(-lens, kind="stable")
-            order = order[mask[order]]
-            h = np.zeros_like(mask); t = np.zeros_like(mask)
-            h[order[:head]] = True; t[order[head:]] = True
-            return h, t
-        h3, t3 = head_tail((lens > 1024) & (lens <= 4096))
-        h4, t4 = head_tail(lens > 4096)
-        ubins = {"64": lens <= 128, "256": (lens > 128) & (lens <= 512), "512": (lens > 512) & (lens <= 1024),
-                 "512c": h3, "512t": t3, "512gc": h4, "512gt": t4}
         esz = 4 if prec == pcr.PCR_F32 else 8
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")      # PMC passes of this command (tools/pmc_traffic.py)
@@ -274,13 +265,16 @@ def main():
             cls, _, tag = name.partition("/")
             if cls not in SLOT_KERNEL or n == 0:
                 continue
-            sel = (ubins if cls == "ustep" else sbins if cls in ("vgrad", "vhv") else vbins)[tag] if tag else np.ones(lens.shape[0], bool)
-            nnz_b, nu_b = int(lens[sel].sum()), int(sel.sum())
+            nnz_b, nu_b = s.profile_scope(name)          # ratings / users one launch of this slot covers
             ab = algorithmic_bytes(name, nnz_b, nu_b, R.d2, r, esz)
             avg_s = ms / n / 1e3
             tr = None
+            # several slots can share one kernel symbol (k_ustep of one workgroup size serves several length classes):
+            # a per-symbol PMC average cannot be split between them, so those slots carry no traffic figure
+            shared = sum(1 for other in prof if other != name and prof[other][1] and other.partition("/")[0] == cls and
+                         any(slot_kernel_match(other, kn, args.precision) and slot_kernel_match(name, kn, args.precision) for kn in traffic))
             for kname, t in traffic.items():
-                if slot_kernel_match(name, kname, args.precision):
+                if not shared and slot_kernel_match(name, kname, args.precision):
                     # FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md): quote the raw
                     # counter sum; the x2-corrected read side is in profiles/r01_traffic.json
                     tr = int(t["fetch_bytes_per_launch_raw"] + t["write_bytes_per_launch"])

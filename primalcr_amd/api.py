@@ -95,6 +95,7 @@ def lib():
     L.pcr_predict.argtypes = [_dp, i64, _dp, i64, i64, i64, _ip, _ip, _dp, ci]
     L.pcr_profile_enable.argtypes = [vp, ci]
     L.pcr_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(cd), C.POINTER(i64)]
+    L.pcr_profile_scope.argtypes = [vp, C.c_char_p, C.POINTER(i64), C.POINTER(i64)]
     L.pcr_profile_reset.argtypes = [vp]
     L.pcr_profile_list.argtypes = [vp, C.c_char_p, i64]
     L.pcr_solver_sync.argtypes = [vp]
@@ -301,6 +302,12 @@ class Solver:
         ms, n = C.c_double(), C.c_int64()
         _chk(lib().pcr_profile_get(self._h, name.encode(), ms, n))
         return ms.value, n.value
+
+    def profile_scope(self, name):
+        """(ratings, users) one launch of the slot covers on this rank."""
+        a, b = C.c_int64(), C.c_int64()
+        _chk(lib().pcr_profile_scope(self._h, name.encode(), a, b))
+        return a.value, b.value
 
     def profile_all(self):
         """{slot name: (total ms, launches)} of every kernel timed so far."""

@@ -359,10 +359,25 @@ __device__ __forceinline__ T group_reduce4(const T (&a)[4], int g, int G) {
 // (occupancy), and its many resident waves provide the memory-level parallelism instead.
 // rows in flight per lane group of the per-user primitives: 4 in the one-wave / 256-thread kernels (register-bound:
 // occupancy provides the memory-level parallelism), 8 in the 512-thread kernels (one workgroup per CU anyway)
+#ifndef PCR_BUNR
 #define PCR_BUNR (BLOCK >= 512 ? 8 : 4)
-template <typename T, int BLOCK>
+#endif
+// LROWS: M is the workgroup's LDS image of rows [r0, n) (stage_rows), lstride elements per row.
+#define PCR_LDS __attribute__((address_space(3)))
+// one 16-byte ds_read_b128 from the workgroup's LDS (p: generic pointer known to point into LDS)
+__device__ __forceinline__ float4 lds_load_vec(const float* p) {
+    typedef float nat __attribute__((ext_vector_type(4)));
+    const nat v = *(const PCR_LDS nat*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ double2 lds_load_vec(const double* p) {
+    typedef double nat __attribute__((ext_vector_type(2)));
+    const nat v = *(const PCR_LDS nat*)p;
+    return make_double2(v.x, v.y);
+}
+template <typename T, int BLOCK, bool LROWS = false>
 __device__ __forceinline__ void block_sddmm(const T* __restrict__ M, const T* vecT, const int32_t* rows, int n,
-                                            T* out, const Geo& geo, int r0 = 0) {      // rows [r0, n)
+                                            T* out, const Geo& geo, int r0 = 0, int lstride = 0) {      // rows [r0, n)
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     const int G = geo.G, g = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = BLOCK / G;
@@ -378,7 +393,10 @@ __device__ __forceinline__ void block_sddmm(const T* __restrict__ M, const T* ve
 #pragma unroll
             for (int q = 0; q < UNR; ++q) {
                 const int row = base + q * ngrp;
-                if (row < n && act) rv[q] = *reinterpret_cast<const V*>(M + (size_t)rows[row] * geo.ld + ch * VEC);
+                if (row < n && act) {
+                    if (LROWS) rv[q] = lds_load_vec(M + (row - r0) * lstride + ch * VEC);
+                    else rv[q] = *reinterpret_cast<const V*>(M + (size_t)rows[row] * geo.ld + ch * VEC);
+                }
             }
             T part[UNR];
 #pragma unroll
@@ -405,9 +423,10 @@ __device__ __forceinline__ void block_sddmm(const T* __restrict__ M, const T* ve
 // outvec[0..ld) += sum_{p in [r0,n)} c[p] * M[rows[p]]   (pcrpp.cpp:536, :622).  fp64 accumulation.
 // wbuf: LDS, (BLOCK/64) * ld doubles.  Ends with a barrier; outvec valid for all threads.
 // assign = true: outvec = sum (a partial, for the multi-workgroup exchange) instead of +=.
-template <typename T, typename CT, int BLOCK>
+template <typename T, typename CT, int BLOCK, bool LROWS = false>
 __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const int32_t* rows, const CT* c, int n,
-                                                  double* outvec, double* wbuf, const Geo& geo, int r0 = 0, bool assign = false) {
+                                                  double* outvec, double* wbuf, const Geo& geo, int r0 = 0, bool assign = false,
+                                                  int lstride = 0) {
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     const int G = geo.G, g = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = BLOCK / G;
@@ -428,7 +447,8 @@ __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const
                 cc[q] = 0.0;
                 if (row < n && act) {
                     cc[q] = (double)c[row];
-                    rv[q] = *reinterpret_cast<const V*>(M + (size_t)rows[row] * geo.ld + ch * VEC);
+                    if (LROWS) rv[q] = lds_load_vec(M + (row - r0) * lstride + ch * VEC);
+                    else rv[q] = *reinterpret_cast<const V*>(M + (size_t)rows[row] * geo.ld + ch * VEC);
                 }
             }
 #pragma unroll
@@ -458,6 +478,31 @@ __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const
         outvec[t] = assign ? sum : outvec[t] + sum;
     }
     __syncthreads();
+}
+
+// LDS image of rows [q0, q1) of one user: img[(row - q0) * nchp + ch] (16-byte chunks; nchp = chunks per LDS row, odd so
+// that the 16 lanes of a ds_read_b128 quarter-wave that read the same chunk of consecutive rows hit distinct banks).
+// Filled by LDS-DMA (global_load_lds_dwordx4: no VGPR destination, so a wave keeps dozens of row pieces in flight):
+// one wave-instruction writes 64 consecutive chunks = wave-uniform base + lane * 16 B, the source address is per lane;
+// lanes that fall on a pad chunk or past the end are masked off.  The caller waits (vmcnt(0) + barrier) before reading.
+template <typename T, int BLOCK>
+__device__ __forceinline__ void stage_rows(const T* __restrict__ M, const int32_t* rows, int q0, int q1, T* img,
+                                           const Geo& geo, int nchp) {
+    constexpr int VEC = VecOf<T>::N;
+    const int total = (q1 - q0) * nchp;
+    const int lane = threadIdx.x & 63;
+    int row = (int)threadIdx.x / nchp, col = (int)threadIdx.x - row * nchp;
+    const int drow = BLOCK / nchp, dcol = BLOCK - drow * nchp;
+    for (int base = (int)(threadIdx.x & ~63u); base < total; base += BLOCK) {
+        const int ubase = __builtin_amdgcn_readfirstlane(base);
+        if (ubase + lane < total && col < geo.nchunk) {
+            const T* src = M + (size_t)rows[q0 + row] * geo.ld + col * VEC;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (PCR_LDS void*)((PCR_LDS char*)img + (size_t)ubase * 16), 16, 0, 0);
+        }
+        row += drow; col += dcol;
+        if (col >= nchp) { col -= nchp; ++row; }
+    }
 }
 
 // carve typed arrays out of a byte region (16-byte aligned pieces)
@@ -655,22 +700,21 @@ static inline size_t vsweep_bytes(int cap, int rs_cap) {
     return carve_bytes(cap, sizeof(T)) * 2 + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
 }
 
+// body of k_vsweep: workgroup `blk` of `nblk` walks users blk, blk + nblk, ...
 template <typename T, int BLOCK, bool BIG, bool HV>
-__global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
-                                                  const T* __restrict__ bsrc, T* __restrict__ c_out,
-                                                  int cap, int rs_cap, char* scratch, size_t stride, int strict, const int* skip) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (skip && *skip) return;
+__device__ __forceinline__ void vsweep_block_body(char* smem, const Shard<T>& S, const int32_t* __restrict__ users, int nusers,
+                                                  const T* __restrict__ bsrc, T* __restrict__ c_out, int cap, int rs_cap,
+                                                  char* scratch, size_t stride, int strict, int blk, int nblk) {
     Carver small(smem);
     double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
-    Carver big(BIG ? scratch + (size_t)blockIdx.x * stride : small.p);
+    Carver big(BIG ? scratch + (size_t)blk * stride : small.p);
     T* ms = big.take<T>(cap);
     T* x = big.take<T>(cap);
     double* Sx = big.take<double>(cap + 1);
     int* rs = big.take<int>(rs_cap);
     const int tid = threadIdx.x;
 
-    for (int ui = blockIdx.x; ui < nusers; ui += gridDim.x) {
+    for (int ui = blk; ui < nusers; ui += nblk) {
         const int u = users[ui];
         const int64_t s0 = S.uptr[u];
         const int n = (int)(S.uptr[u + 1] - s0);
@@ -695,6 +739,15 @@ __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int
         __syncthreads();
     }
 }
+template <typename T, int BLOCK, bool BIG, bool HV>
+__global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
+                                                  const T* __restrict__ bsrc, T* __restrict__ c_out,
+                                                  int cap, int rs_cap, char* scratch, size_t stride, int strict, const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    vsweep_block_body<T, BLOCK, BIG, HV>(smem, S, users, nusers, bsrc, c_out, cap, rs_cap, scratch, stride, strict,
+                                         (int)blockIdx.x, (int)gridDim.x);
+}
 
 // k_vsweep for short users (<= 256 ratings), ONE WAVE PER USER, four users per 256-thread
 // workgroup: no workgroup barriers at all (LDS traffic stays inside a wave, which the LDS serves
@@ -708,14 +761,12 @@ template <typename T>
 static inline size_t vsweep_wave_bytes(int cap, int rs_cap) {      // per wave
     return carve_bytes(cap, sizeof(T)) * 2 + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
 }
+// body: this wave sweeps user number ui of the list
 template <typename T, bool HV>
-__global__ __launch_bounds__(256) void k_vsweep_wave(Shard<T> S, const int32_t* __restrict__ users, int nusers,
-                                                     const T* __restrict__ bsrc, T* __restrict__ c_out,
-                                                     int cap, int rs_cap, size_t wave_bytes, int strict, const int* skip) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (skip && *skip) return;
+__device__ __forceinline__ void vsweep_wave_body(char* smem, const Shard<T>& S, const int32_t* __restrict__ users, int nusers,
+                                                 const T* __restrict__ bsrc, T* __restrict__ c_out,
+                                                 int cap, int rs_cap, size_t wave_bytes, int strict, int ui) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int ui = blockIdx.x * 4 + wid;
     if (ui >= nusers) return;
     Carver big(smem + (size_t)wid * wave_bytes);
     T* ms = big.take<T>(cap);
@@ -757,6 +808,33 @@ __global__ __launch_bounds__(256) void k_vsweep_wave(Shard<T> S, const int32_t* 
             : sweep_coeff<T>(ms, Sx, rs, nlev, lev, ms[p], (double)xs[p], HV ? 0.0 : 1.0, strict);
         c_out[s0 + p] = (T)c;
     }
+}
+template <typename T, bool HV>
+__global__ __launch_bounds__(256) void k_vsweep_wave(Shard<T> S, const int32_t* __restrict__ users, int nusers,
+                                                     const T* __restrict__ bsrc, T* __restrict__ c_out,
+                                                     int cap, int rs_cap, size_t wave_bytes, int strict, const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    vsweep_wave_body<T, HV>(smem, S, users, nusers, bsrc, c_out, cap, rs_cap, wave_bytes, strict,
+                            (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+}
+
+// Both LDS-resident classes in ONE launch of 512-thread workgroups (the two sweeps are each shorter than a launch
+// round trip, so back to back they cost two kernel latencies and side by side a fork/join): workgroups [0, nblk_b)
+// take the long users of list B one per workgroup, the others take eight short users of list A, one per wave.
+template <typename T, bool HV>
+__global__ __launch_bounds__(512) void k_vsweep_all(Shard<T> S, const int32_t* __restrict__ users_a, int nusers_a, int cap_a,
+                                                    int rs_cap_a, size_t wave_bytes, const int32_t* __restrict__ users_b,
+                                                    int nusers_b, int cap_b, int rs_cap_b, int nblk_b,
+                                                    const T* __restrict__ bsrc, T* __restrict__ c_out, int strict, const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    if ((int)blockIdx.x < nblk_b)
+        vsweep_block_body<T, 512, false, HV>(smem, S, users_b, nusers_b, bsrc, c_out, cap_b, rs_cap_b, nullptr, 0, strict,
+                                             (int)blockIdx.x, nblk_b);
+    else
+        vsweep_wave_body<T, HV>(smem, S, users_a, nusers_a, bsrc, c_out, cap_a, rs_cap_a, wave_bytes, strict,
+                                ((int)blockIdx.x - nblk_b) * 8 + (int)(threadIdx.x >> 6));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -835,33 +913,51 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const i
     }
 }
 
-// out[j,:] = beta * base[j,:] + sum of the item's slab slots [item_slot[j], item_slot[j+1]); G lanes per item
-template <typename T, int BLOCK>
+// out[j,:] = beta * base[j,:] + sum of the item's slab slots [item_slot[j], item_slot[j+1]); G lanes per item, items
+// strided over the grid.  DOTS (CG on one GPU, where out = Hp is final here and base = p): the kernel also leaves the
+// partials of p.Hp and rr.p of solve_delta_new (pcrpp.cpp:346) in part[blk][2], so no separate pass re-reads p, Hp, rr.
+template <typename T, int BLOCK, bool DOTS>
 __global__ __launch_bounds__(BLOCK) void k_spmm_fin(const T* __restrict__ slab, const int32_t* __restrict__ item_slot,
                                                     const T* __restrict__ base, double beta, int d2, T* __restrict__ out,
-                                                    Geo geo, const int* skip) {
+                                                    Geo geo, const int* skip, const T* __restrict__ rr, double* __restrict__ part) {
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
+    __shared__ double red[BLOCK / PCR_WAVE + 1];
     if (skip && *skip) return;
-    const int G = geo.G, g = threadIdx.x & (G - 1);
-    const int j = (int)(((int64_t)blockIdx.x * BLOCK + threadIdx.x) / G);
-    if (j >= d2) return;
-    const int s0 = item_slot[j], s1 = item_slot[j + 1];
-    for (int ch = g; ch < geo.nchunk; ch += G) {
-        double acc[VEC];
-        const V bv = *reinterpret_cast<const V*>(base + (size_t)j * geo.ld + ch * VEC);
+    const int G = geo.G, g = threadIdx.x & (G - 1), ipb = BLOCK / G;
+    double x = 0.0, y = 0.0;
+    for (int j = (int)blockIdx.x * ipb + (int)threadIdx.x / G; j < d2; j += (int)gridDim.x * ipb) {
+        const int s0 = item_slot[j], s1 = item_slot[j + 1];
+        for (int ch = g; ch < geo.nchunk; ch += G) {
+            double acc[VEC];
+            const V bv = *reinterpret_cast<const V*>(base + (size_t)j * geo.ld + ch * VEC);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] = beta * (double)velem(bv, e);
-        for (int sl = s0; sl < s1; ++sl) {
-            const V pv = *reinterpret_cast<const V*>(slab + (size_t)sl * geo.ld + ch * VEC);
+            for (int e = 0; e < VEC; ++e) acc[e] = beta * (double)velem(bv, e);
+            for (int sl = s0; sl < s1; ++sl) {
+                const V pv = *reinterpret_cast<const V*>(slab + (size_t)sl * geo.ld + ch * VEC);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] += (double)velem(pv, e);
+                for (int e = 0; e < VEC; ++e) acc[e] += (double)velem(pv, e);
+            }
+            V o;
+            T* op = reinterpret_cast<T*>(&o);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) op[e] = (T)acc[e];
+            *reinterpret_cast<V*>(out + (size_t)j * geo.ld + ch * VEC) = o;
+            if (DOTS) {
+                const V rv = *reinterpret_cast<const V*>(rr + (size_t)j * geo.ld + ch * VEC);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const double pe = (double)velem(bv, e);
+                    x += pe * (double)op[e];
+                    y += (double)velem(rv, e) * pe;
+                }
+            }
         }
-        V o;
-        T* op = reinterpret_cast<T*>(&o);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) op[e] = (T)acc[e];
-        *reinterpret_cast<V*>(out + (size_t)j * geo.ld + ch * VEC) = o;
+    }
+    if (DOTS) {
+        x = block_sum<BLOCK>(x, red);
+        y = block_sum<BLOCK>(y, red);
+        if (threadIdx.x == 0) { part[2 * blockIdx.x] = x; part[2 * blockIdx.x + 1] = y; }
     }
 }
 
@@ -1095,16 +1191,22 @@ static inline size_t ustep_small_bytes(int ld, int block, size_t elt) {
     return carve_bytes(ld, elt) + carve_bytes(block / PCR_WAVE + 1, 8) + 8 * carve_bytes(ld, 8) +
            carve_bytes((size_t)(block / PCR_WAVE) * ld, 8);
 }
+static inline size_t ustep_rows_bytes(int rcap, int nchp) { return (size_t)rcap * nchp * 16; }
 template <typename T>
 static inline size_t ustep_xch_bytes(int cap_pad, int ld, int K) {
     return 2 * carve_bytes(cap_pad, sizeof(T)) + 2 * carve_bytes((size_t)K * ld, 8);
 }
 
+#ifdef PCR_USTEP_PROF
+#define UPROF(ph) do { if (threadIdx.x == 0) { const long long now_ = clock64(); prof_[ph] += now_ - tprev_; tprev_ = now_; } } while (0)
+#else
+#define UPROF(ph) do { } while (0)
+#endif
 template <typename T, int BLOCK, bool BIG, int K>
 __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                  T* __restrict__ U, const T* __restrict__ Vm, double lambda, double stepsize0,
-                                                 int strict, int solver1, int cap, int cap_pad, int rs_cap, char* scratch, size_t stride,
-                                                 unsigned long long* counters, ClusterBufs cb) {
+                                                 int strict, int solver1, int cap, int cap_pad, int rs_cap, int rcap, int nchp,
+                                                 char* scratch, size_t stride, unsigned long long* counters, ClusterBufs cb) {
     typedef typename LiSel<T, BIG>::type LI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Carver small(smem);
@@ -1119,6 +1221,11 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
     double* unew = small.take<double>(geo.ld);
     double* part = small.take<double>(geo.ld);
     double* wbuf = small.take<double>((size_t)(BLOCK / PCR_WAVE) * geo.ld);
+    // LDS image of the first rcap rows of V this workgroup gathers for its user (stage_rows): every pass of the Newton
+    // step over those rows (gradient, 2 per CG iteration, 1 per line-search try) reads LDS instead of L2
+    constexpr int VEC = VecOf<T>::N;
+    const int lstride = nchp * VEC;
+    T* rowsL = small.take<T>((size_t)rcap * lstride);
     Carver big(BIG ? scratch + (size_t)blockIdx.x * stride : small.p);
     T* ms0 = big.take<T>(cap);
     T* key = big.take<T>(cap_pad);
@@ -1166,16 +1273,40 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         __syncthreads();
     };
 
+#ifdef PCR_USTEP_PROF
+    long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
+    const long long tstart_ = tprev_;
+#endif
     for (int ui = cid; ui < nusers; ui += nclus) {
         const int u = users[ui];
         const int64_t s0 = S.uptr[u];
         const int n = (int)(S.uptr[u + 1] - s0);
         const int nlev = (int)(S.runofs[u + 1] - S.runofs[u]) - 1;
         const int r0 = (int)((int64_t)n * mem / K), r1 = (int)((int64_t)n * (mem + 1) / K);
+        const int q0 = r0, q1 = min(r1, r0 + rcap);                  // rows [q0, q1) are LDS-resident, [q1, r1) stay in L2
+        // out[p] = vec . V[item p] over this member's rows
+        auto sddmm = [&](T* out) {
+            if (q1 > q0) block_sddmm<T, BLOCK, true>(rowsL, vecT, nullptr, q1, out, geo, q0, lstride);
+            if (r1 > q1) block_sddmm<T, BLOCK, false>(Vm, vecT, itm, r1, out, geo, q1);
+        };
+        // vec += sum_p c[p] V[item p] over all rows of the user (cluster: partials exchanged)
+        auto gather_axpy = [&](const T* c, double* vec) {
+            if (K == 1) {
+                if (q1 > q0) block_gather_axpy<T, T, BLOCK, true>(rowsL, nullptr, c, q1, vec, wbuf, geo, q0, false, lstride);
+                if (r1 > q1) block_gather_axpy<T, T, BLOCK, false>(Vm, itm, c, r1, vec, wbuf, geo, q1, false);
+                if (r1 == q0) __syncthreads();
+            } else {
+                if (q1 > q0) block_gather_axpy<T, T, BLOCK, true>(rowsL, nullptr, c, q1, part, wbuf, geo, q0, true, lstride);
+                if (r1 > q1 || q1 == q0) block_gather_axpy<T, T, BLOCK, false>(Vm, itm, c, r1, part, wbuf, geo, q1, q1 == q0);
+                exchange_vector(vec);
+            }
+        };
         for (int t = tid; t < ld; t += BLOCK) uvec[t] = (double)U[(size_t)u * ld + t];
         for (int p = tid; p < n; p += BLOCK) { ms0[p] = S.ms[s0 + p]; lv0[p] = S.slvl[s0 + p]; itm[p] = S.sitem[s0 + p]; }
         for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
         __syncthreads();
+        if (q1 > q0) stage_rows<T, BLOCK>(Vm, itm, q0, q1, rowsL, geo, nchp);      // lands while the gradient sweep runs
+        UPROF(0);
         // ---- gradient coefficients, obtain_g_u_new (pcrpp.cpp:506-535)
         block_excl_scan<BLOCK>([&](int i) { return (double)ms0[i]; }, Sx, n, red);
         const uint32_t* win = S.ws ? S.win + (size_t)s0 * S.ws : nullptr;       // windows of the gradient point
@@ -1183,9 +1314,11 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
             key[p] = (T)(win ? sweep_coeff_win(win + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)ms0[p], 1.0)
                              : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)ms0[p], 1.0, strict));
         for (int t = tid; t < ld; t += BLOCK) gvec[t] = (n == 0) ? 0.0 : uvec[t] * lambda;   // :495-498
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // the LDS-DMA of stage_rows
         __syncthreads();
-        if (K == 1) block_gather_axpy<T, T, BLOCK>(Vm, itm, key, n, gvec, wbuf, geo);
-        else { block_gather_axpy<T, T, BLOCK>(Vm, itm, key, r1, part, wbuf, geo, r0, true); exchange_vector(gvec); }
+        UPROF(1);
+        gather_axpy(key, gvec);
+        UPROF(2);
         double un2 = 0.0, gn2 = 0.0;
         for (int t = tid; t < ld; t += BLOCK) { un2 += uvec[t] * uvec[t]; gn2 += gvec[t] * gvec[t]; }
         un2 = block_sum<BLOCK>(un2, red);
@@ -1201,6 +1334,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         const bool skip = (gn2 < 0.0001) || (solver1 && nlev <= 1);
         for (int t = tid; t < ld; t += BLOCK) unew[t] = uvec[t];
         __syncthreads();
+        UPROF(6);
         if (!skip) {
             // ---- CG, solve_delta_u_new (pcrpp.cpp:628-647)
             for (int t = tid; t < ld; t += BLOCK) { delta[t] = 0.0; rr[t] = gvec[t] * -1.0; pv[t] = gvec[t]; }
@@ -1209,16 +1343,18 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
             for (int k = 1; k <= 10; ++k) {
                 for (int t = tid; t < ld; t += BLOCK) { vecT[t] = (T)pv[t]; Hp[t] = pv[t] * lambda; }
                 __syncthreads();
-                block_sddmm<T, BLOCK>(Vm, vecT, itm, (K == 1) ? n : r1, key, geo, (K == 1) ? 0 : r0);   // b = V_I p  (:592-594)
+                sddmm(key);                                                     // b = V_I p  (:592-594)
                 __syncthreads();
                 exchange_scores(key, n, r0, r1);
+                UPROF(3);
                 block_excl_scan<BLOCK>([&](int i) { return (double)key[i]; }, Sx, n, red);
                 for (int p = tid; p < n; p += BLOCK)
                     key[p] = (T)(win ? sweep_coeff_win(win + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)key[p], 0.0)
                                      : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)key[p], 0.0, strict));
                 __syncthreads();
-                if (K == 1) block_gather_axpy<T, T, BLOCK>(Vm, itm, key, n, Hp, wbuf, geo);
-                else { block_gather_axpy<T, T, BLOCK>(Vm, itm, key, r1, part, wbuf, geo, r0, true); exchange_vector(Hp); }
+                UPROF(4);
+                gather_axpy(key, Hp);
+                UPROF(5);
                 ++n_cg;
                 double a = 0.0, b = 0.0;
                 for (int t = tid; t < ld; t += BLOCK) { a += pv[t] * Hp[t]; b += rr[t] * pv[t]; }
@@ -1235,6 +1371,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                 }
                 const double rr2 = block_sum<BLOCK>(a, red);
                 const double rHp = block_sum<BLOCK>(b, red);
+                UPROF(6);
                 if (sqrt(rr2) < err) break;
                 const double beta = rHp / pHp;
                 for (int t = tid; t < ld; t += BLOCK) pv[t] = rr[t] * -1.0 + pv[t] * beta;
@@ -1254,17 +1391,21 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                 }
                 nn = block_sum<BLOCK>(nn, red);
                 __syncthreads();
-                block_sddmm<T, BLOCK>(Vm, vecT, itm, (K == 1) ? n : r1, key, geo, (K == 1) ? 0 : r0);   // compute_mm_old (:728-744)
+                UPROF(6);
+                sddmm(key);                                                     // compute_mm_old (:728-744)
                 if (K > 1) { __syncthreads(); exchange_scores(key, n, r0, r1); }
+                UPROF(7);
                 for (int p = tid; p < npad; p += BLOCK) {
                     if (p < n) li[p] = LiOps<LI>::pack(lv0[p], (unsigned)p);
                     else { li[p] = LiOps<LI>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
                 }
                 __syncthreads();
                 bitonic_sort<T, LI, BLOCK>(key, li, npad);                      // update_infor_ui (:684-726)
+                UPROF(8);
                 obj_new = lambda / 2.0 * nn +
                     block_objective<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, Sx, red, strict);
                 ++n_ls;
+                UPROF(9);
                 if (obj_new < prev_obj) break;
                 step /= 2.0;
             }
@@ -1277,7 +1418,16 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
             if (n_ls) atomicAdd(counters + 1, (unsigned long long)n_ls);
         }
         __syncthreads();
+        UPROF(10);
     }
+#ifdef PCR_USTEP_PROF
+    if (threadIdx.x == 0) {
+        const int cls = (K > 1) ? 3 : (BLOCK == 64 ? 0 : BLOCK == 256 ? 1 : 2);
+        for (int ph = 0; ph < 11; ++ph) atomicAdd(counters + 4 + cls * 16 + ph, (unsigned long long)prof_[ph]);
+        atomicAdd(counters + 4 + cls * 16 + 11, (unsigned long long)(clock64() - tstart_));
+        atomicAdd(counters + 4 + cls * 16 + 12, 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

@@ -80,7 +80,10 @@ struct Bin {
     int ugrid = 0;       // k_ustep grid of this bin
     int scratch_ofs = 0; // first global-scratch slice of this bin (big bins that run concurrently must not share slices)
     int cap = 0;         // longest user in the bin
+    int limit = 0;       // upper length bound of the class (0: none)
+    int rcap = 0;        // k_ustep: rows of V a workgroup keeps resident in LDS
     int max_lev = 0;
+    int64_t nnz = 0;     // ratings of the users in the bin
     std::vector<int32_t> users;
     DBuf<int32_t> d_users;
 };
@@ -91,6 +94,7 @@ static const int BIN_LIMIT[3] = {128, 512, 4096};
 static const int BIN_BLOCK[4] = {64, 256, 512, 512};
 
 struct ProfSlot {
+    int64_t ratings = -1, users = -1;      // what one launch covers (-1: the whole shard)
     int64_t seen = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double ms = 0.0;
@@ -128,7 +132,7 @@ struct Solver final : pcr_solver {
     int64_t d1 = 0, d2 = 0, tnnz_file = 0;
     Geo geo;
     hipStream_t st = nullptr;
-    static constexpr int NSIDE = 8;
+    static constexpr int NSIDE = 12;
     hipStream_t side[NSIDE] = {};                                 // length bins run concurrently
     hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {};
     ncclComm_t comm = nullptr;
@@ -200,9 +204,11 @@ struct Solver final : pcr_solver {
     // ------------------------------------------------------------------------------ profiling
     struct ProfScope {
         Solver* s; ProfSlot* slot = nullptr; hipEvent_t a = nullptr, b = nullptr; hipStream_t q;
-        ProfScope(Solver* s_, const std::string& name, hipStream_t q_ = nullptr) : s(s_), q(q_ ? q_ : s_->st) {
+        ProfScope(Solver* s_, const std::string& name, hipStream_t q_ = nullptr, int64_t ratings = -1, int64_t users = -1)
+            : s(s_), q(q_ ? q_ : s_->st) {
             if (!s->prof_on) return;
             ProfSlot* sl = &s->prof[name];
+            sl->ratings = ratings; sl->users = users;
             if ((sl->seen++ % s->prof_period) != 0) return;       // sampled: an event pair costs ~3 us of queue time
             slot = sl;
             a = s->ev_get(); b = s->ev_get();
@@ -245,12 +251,13 @@ struct Solver final : pcr_solver {
         const int nb = (int)limits.size() + 1;
         out.clear();
         out.resize(nb);
-        for (int b = 0; b < nb; ++b) { out[b].block = blocks[b]; out[b].big = (b == nb - 1); }
+        for (int b = 0; b < nb; ++b) { out[b].block = blocks[b]; out[b].big = (b == nb - 1); out[b].limit = b < nb - 1 ? limits[b] : 0; }
         for (int64_t u = 0; u < nu; ++u) {
             int64_t len = uptr[u + 1] - uptr[u];
             int b = 0;
             while (b < nb - 1 && len > limits[b]) ++b;
             out[b].users.push_back((int32_t)u);
+            out[b].nnz += len;
             out[b].cap = std::max<int>(out[b].cap, (int)len);
             if (runofs) out[b].max_lev = std::max<int>(out[b].max_lev, (int)((*runofs)[u + 1] - (*runofs)[u]) - 1);
         }
@@ -348,23 +355,45 @@ struct Solver final : pcr_solver {
         make_bins(uptr, nu, &lv.run_ofs, sbins, {256, 4096}, {64, 512, 512});       // bin 0: one wave per user (k_vsweep_wave)
         for (auto& b : sbins) RC(b.d_users.upload(b.users, st));
         // U step: users with more than 1024 ratings are bound by one CU's gather bandwidth -> clusters of 4 workgroups
-        make_bins(uptr, nu, &lv.run_ofs, ubins, {128, 512, 1024, 4096}, {64, 256, 512, 512, 512});
-        // cluster sizes per U-step bin: PCR_CLUSTER_K="k2,k3,k4" overrides (each 1, 2, 4 or 8)
+        // The U step keeps each user's rows of V in LDS (k_ustep, stage_rows), so its occupancy is set by LDS bytes, not
+        // registers: finer length classes than the V side, and a workgroup size that grows with the class.
+        // PCR_UBINS="cap:block,..." overrides the classes below 1024 (developer knob).
+        // Measured (ml1m shape, k = 100): residency pays for users of <= 64 ratings (7 / 4 one-wave workgroups per CU still
+        // fit); above that the LDS image leaves 1-2 workgroups per CU and the lost occupancy costs more than the faster
+        // passes gain, so those classes gather from L2 with 16 waves per CU.
+        std::vector<int> ucap = {32, 64, 128, 512}, ublk = {64, 64, 64, 256}, ures = {1, 1, 0, 0};
+        if (const char* e = getenv("PCR_UBINS")) {                 // "cap:block:resident,..."
+            ucap.clear(); ublk.clear(); ures.clear();
+            for (const char* q = e; *q;) {
+                int c = 0, bl = 0, rs = 1, used = 0;
+                if (sscanf(q, "%d:%d:%d%n", &c, &bl, &rs, &used) != 3 || (bl != 64 && bl != 128 && bl != 256 && bl != 512) || c < 1 || c >= 1024 ||
+                    (!ucap.empty() && c <= ucap.back())) { pcr_set_error("bad PCR_UBINS"); return PCR_ERR_ARG; }
+                ucap.push_back(c); ublk.push_back(bl); ures.push_back(rs);
+                q += used; if (*q == ',') ++q;
+            }
+        }
+        const size_t nsmall = ucap.size();
+        ucap.push_back(1024); ucap.push_back(4096);
+        ublk.push_back(512); ublk.push_back(512); ublk.push_back(512);
+        make_bins(uptr, nu, &lv.run_ofs, ubins, ucap, ublk);
+        // cluster sizes of the three top classes (<= 1024, <= 4096, longer): PCR_CLUSTER_K="k2,k3,k4" overrides (each 1, 2, 4 or 8)
         int ck[3] = {1, 4, 4};
         if (const char* e = getenv("PCR_CLUSTER_K")) sscanf(e, "%d,%d,%d", &ck[0], &ck[1], &ck[2]);
         for (int q = 0; q < 3; ++q) if (ck[q] != 1 && ck[q] != 2 && ck[q] != 4 && ck[q] != 8) ck[q] = 1;
-        ubins[2].K = ck[0]; ubins[3].K = ck[1]; ubins[4].K = ck[2];
+        for (int q = 0; q < 3; ++q) ubins[nsmall + q].K = ck[q];
         max_clusters = std::max(1, ncu / 2);
         // Clusters trade throughput for latency: only the head of a bin (its longest users, the critical path) gets
         // them, ncu/(2K) users at most so that all their workgroups fit the chip at once; the rest of the bin runs
         // one workgroup per user.
-        for (size_t q = 2; q < 5; ++q) {
+        for (size_t q = nsmall; q < nsmall + 3; ++q) {
             Bin& b = ubins[q];
             const size_t head = (size_t)std::max(1, ncu / (2 * std::max(1, b.K)));
             if (b.K > 1 && b.users.size() > head) {
                 Bin tail;
-                tail.block = b.block; tail.big = b.big; tail.K = 1; tail.tail = true; tail.max_lev = b.max_lev;
+                tail.block = b.block; tail.big = b.big; tail.limit = b.limit; tail.K = 1; tail.tail = true; tail.max_lev = b.max_lev;
                 tail.users.assign(b.users.begin() + head, b.users.end());
+                for (int32_t u : tail.users) tail.nnz += uptr[u + 1] - uptr[u];
+                b.nnz -= tail.nnz;
                 tail.cap = (int)(uptr[tail.users[0] + 1] - uptr[tail.users[0]]);
                 b.users.resize(head);
                 ubins.push_back(std::move(tail));
@@ -375,6 +404,22 @@ struct Solver final : pcr_solver {
             const int nus = (int)b.users.size();
             b.ugrid = b.K > 1 ? std::min(nus, std::max(1, ncu / b.K)) * b.K : (b.big ? std::min(nus, 2 * ncu) : nus);
             if (b.big) { b.scratch_ofs = u_big_blocks; u_big_blocks += b.ugrid; }
+        }
+        {   // LDS residency: what is left of the 160 KB after the r-vectors and the per-rating arrays, in rows of V
+            const int nchp = geo.nchunk | 1;
+            const size_t lim = 160 * 1024;
+            int res_top = 1;                                               // the classes from 1024 up
+            if (const char* e = getenv("PCR_USTEP_RESIDENT")) res_top = atoi(e);
+            for (size_t bi = 0; bi < ubins.size(); ++bi) {
+                Bin& b = ubins[bi];
+                if (b.users.empty()) continue;
+                const int res_on = (bi < nsmall) ? ures[bi] : res_top;
+                const size_t fixed = ustep_small_bytes(geo.ld, b.block, sizeof(T)) +
+                                     (b.big ? 0 : ustep_big_bytes<T>(b.cap, host_pow2(b.cap), b.max_lev + 2, 4));
+                const int64_t room = fixed < lim ? (int64_t)((lim - fixed) / ((size_t)nchp * 16)) : 0;
+                const int64_t want = (b.cap + b.K - 1) / b.K;                  // longest slice a member gathers
+                b.rcap = res_on ? (int)std::max<int64_t>(0, std::min(room, want)) : 0;
+            }
         }
         for (auto& b : ubins) RC(b.d_users.upload(b.users, st));
         {
@@ -445,10 +490,10 @@ struct Solver final : pcr_solver {
         ew_blocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, cdiv((int64_t)nV, 1024)));   // 4 elements per thread: these kernels are latency-bound
         ew_per_block = cdiv((int64_t)nV, ew_blocks);
         RC(d_partA.alloc(4 * 2048)); RC(d_partB.alloc(4 * 2048)); RC(d_scal.alloc(64));
-        RC(d_counters.alloc(4));
+        RC(d_counters.alloc(4 + 64));
         HIPCHK(hipHostMalloc((void**)&h_scal, 64 * sizeof(double)));
         HIPCHK(hipHostMalloc((void**)&h_cg, sizeof(CGState)));
-        HIPCHK(hipHostMalloc((void**)&h_counters, 4 * sizeof(unsigned long long)));
+        HIPCHK(hipHostMalloc((void**)&h_counters, (4 + 64) * sizeof(unsigned long long)));
 
         // ---- scratch for users that do not fit in LDS
         size_t need = 0;
@@ -478,10 +523,13 @@ struct Solver final : pcr_solver {
         HIPCHK(hipFuncSetAttribute((const void*)k_prepare<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 512, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 512, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+#define UL(BL, BG, KK) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, BL, BG, KK>, hipFuncAttributeMaxDynamicSharedMemorySize, lim))
+        UL(64, false, 1); UL(128, false, 1); UL(256, false, 1);
+        UL(512, false, 1); UL(512, false, 2); UL(512, false, 4); UL(512, false, 8);
+        UL(512, true, 1); UL(512, true, 2); UL(512, true, 4); UL(512, true, 8);
+#undef UL
         HIPCHK(hipFuncSetAttribute((const void*)k_eval<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_eval2<T, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         return PCR_OK;
@@ -506,10 +554,10 @@ struct Solver final : pcr_solver {
             if (bs[i].users.empty() || (int)i == main_bin) continue;
             if (!forked) { HIPCHK(hipEventRecord(ev_fork, st)); forked = true; }
             HIPCHK(hipStreamWaitEvent(side[i], ev_fork, 0));
-            { ProfScope ps(this, pname(cls, bs[i]), side[i]); launch(bs[i], side[i]); }
+            { ProfScope ps(this, pname(cls, bs[i]), side[i], bs[i].nnz, (int64_t)bs[i].users.size()); launch(bs[i], side[i]); }
             HIPCHK(hipEventRecord(ev_join[i], side[i]));
         }
-        { ProfScope ps(this, pname(cls, bs[main_bin]), st); launch(bs[main_bin], st); }
+        { ProfScope ps(this, pname(cls, bs[main_bin]), st, bs[main_bin].nnz, (int64_t)bs[main_bin].users.size()); launch(bs[main_bin], st); }
         for (size_t i = 0; i < bs.size(); ++i)
             if (!bs[i].users.empty() && (int)i != main_bin) HIPCHK(hipStreamWaitEvent(st, ev_join[i], 0));
         HIPCHK(hipGetLastError());
@@ -520,14 +568,19 @@ struct Solver final : pcr_solver {
     int for_bins_seq(std::vector<Bin>& bs, const char* cls, F launch) {
         for (auto& b : bs) {
             if (b.users.empty()) continue;
-            ProfScope ps(this, pname(cls, b), st);
+            ProfScope ps(this, pname(cls, b), st, b.nnz, (int64_t)b.users.size());
             launch(b, st);
         }
         HIPCHK(hipGetLastError());
         return PCR_OK;
     }
     // profile slot of one kernel launch: "<class>/<workgroup size>[g]" (g = global-scratch variant)
-    static std::string pname(const char* cls, const Bin& b) { return std::string(cls) + "/" + std::to_string(b.block) + (b.big ? "g" : "") + (b.K > 1 ? "c" : "") + (b.tail ? "t" : ""); }
+    // ("ustep" has several classes per workgroup size: "<class>/<workgroup size>.<length bound>")
+    static std::string pname(const char* cls, const Bin& b) {
+        std::string s = std::string(cls) + "/" + std::to_string(b.block);
+        if (!strcmp(cls, "ustep") && b.limit) s += "." + std::to_string(b.limit);
+        return s + (b.big ? "g" : "") + (b.K > 1 ? "c" : "") + (b.tail ? "t" : "");
+    }
     size_t small_common(int block) const { return carve_bytes(geo.ld, sizeof(T)) + carve_bytes(block / PCR_WAVE + 1, 8); }
     int strict() const { return prm.solver_type == PCR_SOLVER_PCR ? 1 : 0; }
 
@@ -584,12 +637,33 @@ struct Solver final : pcr_solver {
             else { if (b.big) LV(512, true, false); else LV(512, false, false); }
 #undef LV
         };
+        Bin &ba = sbins[0], &bb = sbins[1];
+        if (!ba.users.empty() && !bb.users.empty()) {
+            // the two LDS-resident classes in one launch (k_vsweep_all); only users beyond 4096 ratings take a second one
+            const int na = (int)ba.users.size(), nb = (int)bb.users.size();
+            const int rsa = ba.max_lev + 2, rsb = bb.max_lev + 2;
+            const size_t wb = (vsweep_wave_bytes<T>(ba.cap, rsa) + 15) & ~(size_t)15;
+            const size_t lds = std::max(wb * 8, small_common(512) + vsweep_bytes<T>(bb.cap, rsb));
+            const int grid = nb + cdiv(na, 8);
+            {
+                ProfScope ps(this, std::string(hv ? "vhv" : "vgrad") + "/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
+                if (hv) hipLaunchKernelGGL((k_vsweep_all<T, true>), dim3(grid), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, rsa, wb,
+                                           bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip);
+                else hipLaunchKernelGGL((k_vsweep_all<T, false>), dim3(grid), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, rsa, wb,
+                                        bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip);
+            }
+            if (!sbins[2].users.empty()) { ProfScope ps(this, pname(hv ? "vhv" : "vgrad", sbins[2]), st, sbins[2].nnz, (int64_t)sbins[2].users.size()); fn(sbins[2], st); }
+            HIPCHK(hipGetLastError());
+            return PCR_OK;
+        }
         RC(for_bins_seq(sbins, hv ? "vhv" : "vgrad", fn));
         return PCR_OK;
     }
 
     // out = beta * base + sum c * U-rows (item-major, deterministic slab reduction)
-    int launch_spmm(T* out, const T* base, double beta, const int* skip = nullptr) {
+    // dots_rr != nullptr: also leave the partials of base.out and dots_rr.base in d_partA (k_spmm_fin DOTS)
+    int fin_blocks() const { return (int)std::min<int64_t>(1024, cdiv(d2, 256 / geo.G)); }
+    int launch_spmm(T* out, const T* base, double beta, const int* skip = nullptr, const T* dots_rr = nullptr) {
         if (nnz_local > 0) {
             ProfScope ps(this, "spmm");
             const int64_t ngroups = (nnz_local + spmm_chunk - 1) / spmm_chunk;
@@ -598,8 +672,8 @@ struct Solver final : pcr_solver {
                                d_slot_base.p, nnz_local, d_U.p, d_slab.p, geo, spmm_chunk, skip);
         }
         ProfScope ps2(this, "spmm_fin");
-        const int gpb = 256 / geo.G;
-        hipLaunchKernelGGL((k_spmm_fin<T, 256>), dim3(cdiv(d2, gpb)), dim3(256), 0, st, d_slab.p, d_item_slot.p, base, beta, (int)d2, out, geo, skip);
+        if (dots_rr) hipLaunchKernelGGL((k_spmm_fin<T, 256, true>), dim3(fin_blocks()), dim3(256), 0, st, d_slab.p, d_item_slot.p, base, beta, (int)d2, out, geo, skip, dots_rr, d_partA.p);
+        else hipLaunchKernelGGL((k_spmm_fin<T, 256, false>), dim3(fin_blocks()), dim3(256), 0, st, d_slab.p, d_item_slot.p, base, beta, (int)d2, out, geo, skip, (const T*)nullptr, (double*)nullptr);
         HIPCHK(hipGetLastError());
         return PCR_OK;
     }
@@ -730,9 +804,9 @@ struct Solver final : pcr_solver {
         return download_mat(d_g.p, d2, g);
     }
     // out = lambda p + sum c(b) u   (the lambda term on rank 0 only; summed by the all-reduce)
-    int device_hv(const T* pvec, T* out, const int* skip = nullptr) {
+    int device_hv(const T* pvec, T* out, const int* skip = nullptr, const T* dots_rr = nullptr) {
         RC(launch_vsweep(true, pvec, skip));
-        RC(launch_spmm(out, pvec, rank == 0 ? prm.lambda : 0.0, skip));
+        RC(launch_spmm(out, pvec, rank == 0 ? prm.lambda : 0.0, skip, dots_rr));
         RC(allreduce_T(out, (size_t)d2 * geo.ld));
         return PCR_OK;
     }
@@ -754,12 +828,15 @@ struct Solver final : pcr_solver {
         // All 10 iterations are queued without a host round trip; once the device-side stop test
         // (pcrpp.cpp:350) fires, the remaining kernels return immediately.  One sync at the end.
         const int* skip = &d_cg.p->done;
+        // one GPU: Hp is final when k_spmm_fin stores it, so that kernel also produces the p.Hp / rr.p partials;
+        // with an all-reduce in between they need their own pass (k_cg_a)
+        const bool fused_dots = (nranks == 1 && !comm) || local_only;
         for (int k = 1; k <= 10; ++k) {
-            RC(device_hv(d_p.p, d_Hp.p, skip));
+            RC(device_hv(d_p.p, d_Hp.p, skip, fused_dots ? d_rr.p : nullptr));
             {
                 ProfScope ps(this, "cg");
-                hipLaunchKernelGGL((k_cg_a<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, n, ew_per_block, d_partA.p, d_cg.p);
-                hipLaunchKernelGGL((k_cg_b<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, d_delta.p, n, ew_per_block, ew_blocks, d_partA.p, d_partB.p, d_cg.p);
+                if (!fused_dots) hipLaunchKernelGGL((k_cg_a<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, n, ew_per_block, d_partA.p, d_cg.p);
+                hipLaunchKernelGGL((k_cg_b<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, d_delta.p, n, ew_per_block, fused_dots ? fin_blocks() : ew_blocks, d_partA.p, d_partB.p, d_cg.p);
                 hipLaunchKernelGGL((k_cg_c<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_rr.p, n, ew_per_block, ew_blocks, d_partB.p, d_cg.p);
             }
             HIPCHK(hipGetLastError());
@@ -805,20 +882,23 @@ struct Solver final : pcr_solver {
     }
 
     int launch_ustep() {
-        HIPCHK(hipMemsetAsync(d_counters.p, 0, 4 * sizeof(unsigned long long), st));
+        HIPCHK(hipMemsetAsync(d_counters.p, 0, (4 + 64) * sizeof(unsigned long long), st));
         HIPCHK(hipMemsetAsync(d_bar.p, 0, (size_t)max_clusters * ubins.size() * sizeof(unsigned), st));
         auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
             const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
-            const size_t lds = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + (b.big ? 0 : ustep_big_bytes<T>(b.cap, cap_pad, rsc, 4));
+            const int nchp = geo.nchunk | 1;
+            const size_t lds = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + ustep_rows_bytes(b.rcap, nchp) +
+                               (b.big ? 0 : ustep_big_bytes<T>(b.cap, cap_pad, rsc, 4));
             const size_t bi = (size_t)(&b - &ubins[0]);
             ClusterBufs cb{d_bar.p + bi * max_clusters, d_xch.p + bi * max_clusters * xch_stride, xch_stride};
             // clusters: grid <= one workgroup per CU so that every member of every cluster is resident
             const int grid = b.ugrid;
             char* scr = d_scratch.p + (size_t)b.scratch_ofs * scratch_stride;
-#define LU(BL, BG, KK) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, strict(), strict(), b.cap, cap_pad, rsc, scr, scratch_stride, d_counters.p, cb)
+#define LU(BL, BG, KK) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb)
             if (b.big) { if (b.K == 8) LU(512, true, 8); else if (b.K == 4) LU(512, true, 4); else if (b.K == 2) LU(512, true, 2); else LU(512, true, 1); }
             else if (b.block == 64) LU(64, false, 1);
+            else if (b.block == 128) LU(128, false, 1);
             else if (b.block == 256) LU(256, false, 1);
             else if (b.K == 8) LU(512, false, 8);
             else if (b.K == 4) LU(512, false, 4);
@@ -826,7 +906,8 @@ struct Solver final : pcr_solver {
             else LU(512, false, 1);
 #undef LU
         };
-        RC(for_bins(ubins, "ustep", fn));
+        static const int seq = getenv("PCR_USTEP_SEQ") ? atoi(getenv("PCR_USTEP_SEQ")) : 0;     // developer knob
+        if (seq) RC(for_bins_seq(ubins, "ustep", fn)); else RC(for_bins(ubins, "ustep", fn));
         return PCR_OK;
     }
 
@@ -839,8 +920,21 @@ struct Solver final : pcr_solver {
         RC(reduce_sum(d_objp.p, n_users, 0));                       // sum_i obj_u(i)
         RC(allreduce_f64(d_scal.p, 1));
         RC(norm2(d_V.p, (int64_t)d2 * geo.ld, 2));
-        HIPCHK(hipMemcpyAsync(h_counters, d_counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_counters, d_counters.p, (4 + 64) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         RC(fetch_scal(4));
+#ifdef PCR_USTEP_PROF
+        {   // developer build only: per-phase shader-clock totals of thread 0 of every workgroup, by bin class
+            static const char* ph[] = {"load", "g.sweep", "g.axpy", "cg.sddmm", "cg.sweep", "cg.axpy", "vec", "ls.sddmm", "ls.sort", "ls.obj", "store", "TOTAL", "wgs"};
+            static const char* cl[] = {"64", "256", "512", "cluster"};
+            for (int c = 0; c < 4; ++c) {
+                const unsigned long long* q = h_counters + 4 + c * 16;
+                if (!q[12]) continue;
+                fprintf(stderr, "ustep-prof %-8s wgs %5llu  kclk/wg %8.1f :", cl[c], q[12], q[11] / 1000.0 / q[12]);
+                for (int i = 0; i < 11; ++i) fprintf(stderr, " %s %.1f%%", ph[i], 100.0 * q[i] / (double)q[11]);
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
         if (now_obj) *now_obj = h_scal[0] + prm.lambda / 2.0 * h_scal[2];   // :835
         if (h_counters[3] != 0) { pcr_set_error("k_ustep: a workgroup cluster timed out at a hand-off (members not co-resident?)"); return PCR_ERR_DEVICE; }
         if (info) { info[0] = (int64_t)h_counters[0]; info[1] = (int64_t)h_counters[1]; }
@@ -1046,6 +1140,15 @@ int pcr_profile_get(pcr_solver* s, const char* name, double* total_ms, int64_t* 
     auto it = s->prof.find(name ? name : "");
     if (total_ms) *total_ms = it == s->prof.end() ? 0.0 : it->second.ms;
     if (launches) *launches = it == s->prof.end() ? 0 : it->second.n;
+    return PCR_OK;
+}
+
+int pcr_profile_scope(pcr_solver* s, const char* name, int64_t* ratings, int64_t* users) {
+    S_OR_ARG;
+    auto it = s->prof.find(name ? name : "");
+    const bool whole = it == s->prof.end() || it->second.ratings < 0;
+    if (ratings) *ratings = whole ? s->nnz_local : it->second.ratings;
+    if (users) *users = whole ? s->n_users : it->second.users;
     return PCR_OK;
 }
 
