@@ -846,20 +846,26 @@ __global__ __launch_bounds__(512) void k_vsweep_all(Shard<T> S, const int32_t* _
 // stores into a slab whose slot numbering is static (slots of one item are consecutive).
 // k_spmm_fin then sums each item's slots in a fixed order -> bitwise reproducible.
 // c is read through cinv (CSC entry -> sorted position), so the sweeps write it coalesced.
+// XCD-aware tiling: the CSC is built per USER TILE (a contiguous user range whose rows of U, and whose slice of c, fit
+// one XCD's 4 MB L2), tile-major, and workgroup b works on a tile t with t % 8 == b % 8 (workgroups go to the XCDs
+// round-robin), so the random row gather of a tile is served by ONE L2 instead of every L2 holding a copy of all of U
+// and c.  Chunks never straddle tiles (chunk_ptr); an item's slab slots are consecutive whatever tile they come from
+// (slot_id maps the (chunk, item) incidences, enumerated in chunk order, to item-major slab rows).
 // ---------------------------------------------------------------------------------------
 template <typename T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const int32_t* __restrict__ cinv,
                                                 const int32_t* __restrict__ cuser, const int32_t* __restrict__ crow,
-                                                const int32_t* __restrict__ slot_base, int64_t nnz, const T* __restrict__ U,
-                                                T* __restrict__ slab, Geo geo, int chunk, const int* skip) {
+                                                const int32_t* __restrict__ chunk_ptr, const int32_t* __restrict__ inc_base,
+                                                const int32_t* __restrict__ slot_id, const int2* __restrict__ blk_chunks,
+                                                const T* __restrict__ U, T* __restrict__ slab, Geo geo, const int* skip) {
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     if (skip && *skip) return;
     const int G = geo.G, g = threadIdx.x & (G - 1);
-    const int64_t gid = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / G;
-    const int64_t z0 = gid * chunk;
-    if (z0 >= nnz) return;
-    const int64_t z1 = (z0 + chunk < nnz) ? z0 + chunk : nnz;
+    const int2 bc = blk_chunks[blockIdx.x];                    // first chunk and number of chunks of this workgroup
+    if ((int)threadIdx.x / G >= bc.y) return;
+    const int gid = bc.x + (int)threadIdx.x / G;
+    const int64_t z0 = chunk_ptr[gid], z1 = chunk_ptr[gid + 1];
     for (int k = 0; k * G < geo.nchunk; ++k) {
         const int ch = g + k * G;
         const bool act = ch < geo.nchunk;
@@ -867,16 +873,16 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const i
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
         int cur = crow[z0];
-        int slot = slot_base[gid];
+        int inc = inc_base[gid];
         auto flush = [&]() {
             if (act) {
                 V o;
                 T* op = reinterpret_cast<T*>(&o);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) { op[e] = (T)acc[e]; acc[e] = 0.0; }
-                *reinterpret_cast<V*>(slab + (size_t)slot * geo.ld + ch * VEC) = o;
+                *reinterpret_cast<V*>(slab + (size_t)slot_id[inc] * geo.ld + ch * VEC) = o;
             }
-            slot += 1;
+            inc += 1;
         };
         for (int64_t zb = z0; zb < z1; zb += G) {
             const int64_t zi = zb + g;

@@ -141,7 +141,9 @@ struct Solver final : pcr_solver {
     // ---- training shard
     Shard<T> sh;
     DBuf<int64_t> d_uptr, d_runofs;
-    DBuf<int32_t> d_item, d_cpos, d_runstart, d_sitem, d_cinv, d_cuser, d_crow, d_ruser, d_slot_base, d_item_slot;
+    DBuf<int32_t> d_item, d_cpos, d_runstart, d_sitem, d_cinv, d_cuser, d_crow, d_ruser, d_slot_base, d_item_slot, d_chunk_ptr, d_slot_id;
+    DBuf<int2> d_blk_chunks;                      // k_spmm: first chunk and chunk count of every workgroup
+    int spmm_blocks = 0, spmm_tiles = 1;
     DBuf<T> d_slab;                               // k_spmm partial rows, one per (chunk, item) incidence
     int spmm_chunk = 128;
     DBuf<uint16_t> d_lvl, d_slvl;
@@ -312,43 +314,88 @@ struct Solver final : pcr_solver {
         std::string err;
         int rc = pcr_build_levels(X, first_user, first_user + nu, prm.solver_type, lv, err);
         if (rc != PCR_OK) { pcr_set_error(err); return rc; }
-        // CSC of the shard: entries of one item ordered by local user
-        std::vector<int64_t> cptr(d2 + 1, 0);
-        for (int64_t z = 0; z < nnz_local; ++z) cptr[item[z] + 1]++;
-        for (int64_t j = 0; j < d2; ++j) cptr[j + 1] += cptr[j];
+        // Tile-major CSC of the shard (pcr_kernels.h, k_spmm): users are cut into tiles of about equal rating count whose
+        // rows of U take at most 1.25 MB (measured on a 48 k x 17.8 k, 10 M shape: 1.2 MB tiles 379 us, 2.4 MB tiles 595 us =
+        // untiled, 0.6 MB tiles 411 us: the tile shares the XCD's 4 MB L2 with the streamed ids, c and the slab stores);
+        // inside a tile the entries are ordered by item, then user.
         std::vector<int32_t> cpos(nnz_local), cuser(nnz_local), crow(nnz_local), ruser(nnz_local);
         for (int64_t u = 0; u < nu; ++u)
             for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) ruser[z] = (int32_t)u;
         {
-            std::vector<int64_t> cur(cptr.begin(), cptr.end() - 1);
-            for (int64_t u = 0; u < nu; ++u)
-                for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) {
-                    int64_t q = cur[item[z]]++;
-                    cpos[z] = (int32_t)q; cuser[q] = (int32_t)u; crow[q] = item[z];
-                }
-        }
-        {   // static slot numbering of the SpMM slab: one slot per (chunk, item) incidence, in CSC order,
-            // so the slots of one item are consecutive (pcr_kernels.h, k_spmm / k_spmm_fin)
             if (const char* e = getenv("PCR_SPMM_CHUNK")) spmm_chunk = std::max(8, atoi(e));
-            const int64_t nchunks = (nnz_local + spmm_chunk - 1) / spmm_chunk;
-            std::vector<int32_t> slot_base(nchunks + 1, 0), item_slot(d2 + 1, 0);
-            int64_t slot = 0;
-            int64_t next_item = 0;
-            for (int64_t c = 0; c < nchunks; ++c) {
-                slot_base[c] = (int32_t)slot;
-                const int64_t a = c * spmm_chunk, b2 = std::min<int64_t>(a + spmm_chunk, nnz_local);
-                for (int64_t z = a; z < b2; ++z)
-                    if (z == a || crow[z] != crow[z - 1]) {
-                        if (z == 0 || crow[z] != crow[z - 1]) {          // first slot of this item
-                            for (; next_item <= crow[z]; ++next_item) item_slot[next_item] = (int32_t)slot;
-                        }
-                        ++slot;
-                    }
+            const size_t row_bytes = (size_t)geo.ld * sizeof(T);
+            const int64_t tile_users_max = std::max<int64_t>(64, (int64_t)((5u << 18) / row_bytes));
+            int64_t ntiles = std::max<int64_t>(cdiv(nu, tile_users_max), std::min<int64_t>(8, nu / 256));
+            if (ntiles > 1) ntiles = (ntiles + 7) / 8 * 8;             // every XCD the same number of tiles
+            if (const char* e = getenv("PCR_SPMM_TILES")) if (atoi(e) > 0) ntiles = atoi(e);      // developer knob
+            ntiles = std::max<int64_t>(1, std::min<int64_t>(ntiles, std::max<int64_t>(nu, 1)));
+            std::vector<int64_t> tile_u(1, 0);                       // user boundaries: equal ratings, at most tile_users_max users
+            for (int64_t t = 1; t < ntiles; ++t) {
+                const int64_t want = nnz_local * t / ntiles;
+                int64_t u = std::lower_bound(uptr.begin(), uptr.end(), want) - uptr.begin();
+                u = std::min(u, tile_u.back() + tile_users_max);
+                u = std::max(u, tile_u.back());
+                u = std::min<int64_t>(u, nu);
+                tile_u.push_back(u);
             }
-            slot_base[nchunks] = (int32_t)slot;
-            for (; next_item <= d2; ++next_item) item_slot[next_item] = (int32_t)slot;
-            RC(d_slot_base.upload(slot_base, st)); RC(d_item_slot.upload(item_slot, st));
-            RC(d_slab.alloc((size_t)std::max<int64_t>(slot, 1) * geo.ld));
+            tile_u.push_back(nu);
+            while ((int64_t)tile_u.size() >= 2 && nu - tile_u[tile_u.size() - 2] > tile_users_max) {     // the cap pushed users to the end
+                tile_u.back() = tile_u[tile_u.size() - 2] + tile_users_max;
+                tile_u.push_back(nu);
+            }
+            ntiles = (int64_t)tile_u.size() - 1;
+            std::vector<int32_t> chunk_ptr, tile_chunk0(ntiles + 1, 0);
+            std::vector<int64_t> cur(d2);
+            int64_t q = 0;
+            for (int64_t t = 0; t < ntiles; ++t) {
+                std::fill(cur.begin(), cur.end(), 0);
+                for (int64_t z = uptr[tile_u[t]]; z < uptr[tile_u[t + 1]]; ++z) cur[item[z]]++;
+                int64_t run = q;
+                for (int64_t j = 0; j < d2; ++j) { const int64_t n = cur[j]; cur[j] = run; run += n; }
+                for (int64_t u = tile_u[t]; u < tile_u[t + 1]; ++u)
+                    for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) {
+                        const int64_t p = cur[item[z]]++;
+                        cpos[z] = (int32_t)p; cuser[p] = (int32_t)u; crow[p] = item[z];
+                    }
+                tile_chunk0[t] = (int32_t)chunk_ptr.size();
+                for (int64_t a = q; a < run; a += spmm_chunk) chunk_ptr.push_back((int32_t)a);      // chunks never straddle tiles
+                q = run;
+            }
+            tile_chunk0[ntiles] = (int32_t)chunk_ptr.size();
+            const int64_t nchunks = (int64_t)chunk_ptr.size();
+            chunk_ptr.push_back((int32_t)nnz_local);
+            // (chunk, item) incidences in chunk order -> item-major slab rows: the slots of one item are consecutive
+            std::vector<int32_t> inc_base(nchunks + 1, 0), inc_item, item_slot(d2 + 1, 0);
+            for (int64_t c = 0; c < nchunks; ++c) {
+                inc_base[c] = (int32_t)inc_item.size();
+                for (int64_t z = chunk_ptr[c]; z < chunk_ptr[c + 1]; ++z)
+                    if (z == chunk_ptr[c] || crow[z] != crow[z - 1]) inc_item.push_back(crow[z]);
+            }
+            inc_base[nchunks] = (int32_t)inc_item.size();
+            for (int32_t j : inc_item) item_slot[j + 1]++;
+            for (int64_t j = 0; j < d2; ++j) item_slot[j + 1] += item_slot[j];
+            std::vector<int32_t> slot_id(inc_item.size());
+            {
+                std::vector<int32_t> nxt(item_slot.begin(), item_slot.end() - 1);
+                for (size_t i = 0; i < inc_item.size(); ++i) slot_id[i] = nxt[inc_item[i]]++;
+            }
+            // workgroup -> chunks: gpb chunks per workgroup, never across tiles; tile t is walked by workgroups b = t mod 8 (mod 8)
+            const int gpb = 256 / geo.G;
+            std::vector<std::vector<int2>> per_xcd(8);
+            size_t rr8 = 0;
+            for (int64_t t = 0; t < ntiles; ++t)
+                for (int32_t c = tile_chunk0[t]; c < tile_chunk0[t + 1]; c += gpb)       // fewer than 8 tiles: no affinity, use every XCD
+                    per_xcd[ntiles >= 8 ? t % 8 : rr8++ % 8].push_back(make_int2(c, std::min<int32_t>(gpb, tile_chunk0[t + 1] - c)));
+            size_t deepest = 0;
+            for (auto& v : per_xcd) deepest = std::max(deepest, v.size());
+            std::vector<int2> blk(deepest * 8, make_int2(0, 0));
+            for (int x = 0; x < 8; ++x)
+                for (size_t i = 0; i < per_xcd[x].size(); ++i) blk[i * 8 + x] = per_xcd[x][i];
+            spmm_blocks = (int)blk.size();
+            RC(d_chunk_ptr.upload(chunk_ptr, st)); RC(d_slot_base.upload(inc_base, st)); RC(d_slot_id.upload(slot_id, st));
+            RC(d_blk_chunks.upload(blk, st)); RC(d_item_slot.upload(item_slot, st));
+            RC(d_slab.alloc((size_t)std::max<size_t>(inc_item.size(), 1) * geo.ld));
+            spmm_tiles = (int)ntiles;
         }
         make_bins(uptr, nu, &lv.run_ofs, bins);
         for (auto& b : bins) RC(b.d_users.upload(b.users, st));
@@ -366,7 +413,7 @@ struct Solver final : pcr_solver {
             ucap.clear(); ublk.clear(); ures.clear();
             for (const char* q = e; *q;) {
                 int c = 0, bl = 0, rs = 1, used = 0;
-                if (sscanf(q, "%d:%d:%d%n", &c, &bl, &rs, &used) != 3 || (bl != 64 && bl != 128 && bl != 256 && bl != 512) || c < 1 || c >= 1024 ||
+                if (sscanf(q, "%d:%d:%d%n", &c, &bl, &rs, &used) != 3 || (bl != 64 && bl != 128 && bl != 256 && bl != 512) || c < 1 || c > 1024 ||
                     (!ucap.empty() && c <= ucap.back())) { pcr_set_error("bad PCR_UBINS"); return PCR_ERR_ARG; }
                 ucap.push_back(c); ublk.push_back(bl); ures.push_back(rs);
                 q += used; if (*q == ',') ++q;
@@ -666,10 +713,8 @@ struct Solver final : pcr_solver {
     int launch_spmm(T* out, const T* base, double beta, const int* skip = nullptr, const T* dots_rr = nullptr) {
         if (nnz_local > 0) {
             ProfScope ps(this, "spmm");
-            const int64_t ngroups = (nnz_local + spmm_chunk - 1) / spmm_chunk;
-            const int gpb = 256 / geo.G;
-            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(cdiv(ngroups, gpb)), dim3(256), 0, st, d_c.p, d_cinv.p, d_cuser.p, d_crow.p,
-                               d_slot_base.p, nnz_local, d_U.p, d_slab.p, geo, spmm_chunk, skip);
+            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(spmm_blocks), dim3(256), 0, st, d_c.p, d_cinv.p, d_cuser.p, d_crow.p,
+                               d_chunk_ptr.p, d_slot_base.p, d_slot_id.p, d_blk_chunks.p, d_U.p, d_slab.p, geo, skip);
         }
         ProfScope ps2(this, "spmm_fin");
         if (dots_rr) hipLaunchKernelGGL((k_spmm_fin<T, 256, true>), dim3(fin_blocks()), dim3(256), 0, st, d_slab.p, d_item_slot.p, base, beta, (int)d2, out, geo, skip, dots_rr, d_partA.p);

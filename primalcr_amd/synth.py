@@ -14,6 +14,8 @@ items ascending (the test file MUST be user-sorted, ``util.cpp:259-261``).
 from __future__ import annotations
 
 import os
+import sys
+import time
 from dataclasses import dataclass
 
 import numpy as np
@@ -75,7 +77,10 @@ def _sample_items(rng, cnt, d2, chunk_users=1 << 16):
     Returns (user, item) sorted by (user, item)."""
     users_out, items_out = [], []
     d1 = cnt.shape[0]
+    t0 = time.time()
     for u0 in range(0, d1, chunk_users):
+        if d1 > 4 * chunk_users:       # large shapes take minutes: say so
+            print(f"[synth] sampling users {u0}..{min(d1, u0 + chunk_users)} of {d1} ({time.time() - t0:.0f}s)", file=sys.stderr, flush=True)
         c = cnt[u0:u0 + chunk_users]
         need = c.copy()
         got_u = np.empty(0, np.int64)
