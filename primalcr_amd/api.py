@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "lib", "libprimalcr.so")
+    # PCR_LIB: developer override for A/B runs of two builds in one process launch each
+    return os.environ.get("PCR_LIB") or os.path.join(_HERE, "lib", "libprimalcr.so")
 
 
 class PcrError(RuntimeError):

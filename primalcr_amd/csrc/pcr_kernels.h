@@ -375,13 +375,13 @@ __device__ __forceinline__ double2 lds_load_vec(const double* p) {
     const nat v = *(const PCR_LDS nat*)p;
     return make_double2(v.x, v.y);
 }
-template <typename T, int BLOCK, bool LROWS = false>
+template <typename T, int BLOCK, bool LROWS = false, int UNR = PCR_BUNR>
 __device__ __forceinline__ void block_sddmm(const T* __restrict__ M, const T* vecT, const int32_t* rows, int n,
                                             T* out, const Geo& geo, int r0 = 0, int lstride = 0) {      // rows [r0, n)
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     const int G = geo.G, g = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = BLOCK / G;
-    constexpr int UNR = PCR_BUNR;
+    static_assert(UNR == 4 || UNR == 8, "rows in flight per lane group");
     const int rho = (UNR == 8) ? 4 * (g & 1) + (g & 2) + ((g >> 2) & 1) : 2 * (g & 1) + ((g >> 1) & 1);
     for (int k = 0; k * G < geo.nchunk; ++k) {
         const int ch = g + k * G;
@@ -423,7 +423,7 @@ __device__ __forceinline__ void block_sddmm(const T* __restrict__ M, const T* ve
 // outvec[0..ld) += sum_{p in [r0,n)} c[p] * M[rows[p]]   (pcrpp.cpp:536, :622).  fp64 accumulation.
 // wbuf: LDS, (BLOCK/64) * ld doubles.  Ends with a barrier; outvec valid for all threads.
 // assign = true: outvec = sum (a partial, for the multi-workgroup exchange) instead of +=.
-template <typename T, typename CT, int BLOCK, bool LROWS = false>
+template <typename T, typename CT, int BLOCK, bool LROWS = false, int UNR = PCR_BUNR>
 __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const int32_t* rows, const CT* c, int n,
                                                   double* outvec, double* wbuf, const Geo& geo, int r0 = 0, bool assign = false,
                                                   int lstride = 0) {
@@ -431,7 +431,6 @@ __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const
     constexpr int VEC = VecOf<T>::N;
     const int G = geo.G, g = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = BLOCK / G;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int UNR = PCR_BUNR;
     for (int k = 0; k * G < geo.nchunk; ++k) {
         const int ch = g + k * G;
         const bool act = ch < geo.nchunk;
@@ -967,6 +966,13 @@ __global__ __launch_bounds__(BLOCK) void k_spmm_fin(const T* __restrict__ slab, 
     }
 }
 
+// stream calibration (pcr_solver.hip, pick_lanes): hold a hardware queue busy for `ticks` of the constant-rate clock
+__global__ void k_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    for (int i = 0; i < (1 << 22) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);
+}
+__global__ void k_nop() {}
+
 // ---------------------------------------------------------------------------------------
 // elementwise / CG kernels (solve_delta_new, pcrpp.cpp:335-358).  Scalars stay on the device;
 // every reduction is two-stage and deterministic (per-block partials, then each consumer
@@ -1208,7 +1214,10 @@ static inline size_t ustep_xch_bytes(int cap_pad, int ld, int K) {
 #else
 #define UPROF(ph) do { } while (0)
 #endif
-template <typename T, int BLOCK, bool BIG, int K>
+// RES: the workgroup keeps rows of V in LDS (rcap > 0); UNR: rows in flight per lane group of the L2 gathers (8 for the
+// latency-bound classes with few users, one workgroup per CU; 4 keeps the kernel at <= 128 VGPRs so that two 512-thread
+// workgroups share a CU in the throughput-bound classes with many users).
+template <typename T, int BLOCK, bool BIG, int K, bool RES, int UNR>
 __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                  T* __restrict__ U, const T* __restrict__ Vm, double lambda, double stepsize0,
                                                  int strict, int solver1, int cap, int cap_pad, int rs_cap, int rcap, int nchp,
@@ -1289,21 +1298,21 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         const int n = (int)(S.uptr[u + 1] - s0);
         const int nlev = (int)(S.runofs[u + 1] - S.runofs[u]) - 1;
         const int r0 = (int)((int64_t)n * mem / K), r1 = (int)((int64_t)n * (mem + 1) / K);
-        const int q0 = r0, q1 = min(r1, r0 + rcap);                  // rows [q0, q1) are LDS-resident, [q1, r1) stay in L2
+        const int q0 = r0, q1 = RES ? min(r1, r0 + rcap) : r0;       // rows [q0, q1) are LDS-resident, [q1, r1) stay in L2
         // out[p] = vec . V[item p] over this member's rows
         auto sddmm = [&](T* out) {
-            if (q1 > q0) block_sddmm<T, BLOCK, true>(rowsL, vecT, nullptr, q1, out, geo, q0, lstride);
-            if (r1 > q1) block_sddmm<T, BLOCK, false>(Vm, vecT, itm, r1, out, geo, q1);
+            if (RES && q1 > q0) block_sddmm<T, BLOCK, true, UNR>(rowsL, vecT, nullptr, q1, out, geo, q0, lstride);
+            if (r1 > q1) block_sddmm<T, BLOCK, false, UNR>(Vm, vecT, itm, r1, out, geo, q1);
         };
         // vec += sum_p c[p] V[item p] over all rows of the user (cluster: partials exchanged)
         auto gather_axpy = [&](const T* c, double* vec) {
             if (K == 1) {
-                if (q1 > q0) block_gather_axpy<T, T, BLOCK, true>(rowsL, nullptr, c, q1, vec, wbuf, geo, q0, false, lstride);
-                if (r1 > q1) block_gather_axpy<T, T, BLOCK, false>(Vm, itm, c, r1, vec, wbuf, geo, q1, false);
+                if (RES && q1 > q0) block_gather_axpy<T, T, BLOCK, true, UNR>(rowsL, nullptr, c, q1, vec, wbuf, geo, q0, false, lstride);
+                if (r1 > q1) block_gather_axpy<T, T, BLOCK, false, UNR>(Vm, itm, c, r1, vec, wbuf, geo, q1, false);
                 if (r1 == q0) __syncthreads();
             } else {
-                if (q1 > q0) block_gather_axpy<T, T, BLOCK, true>(rowsL, nullptr, c, q1, part, wbuf, geo, q0, true, lstride);
-                if (r1 > q1 || q1 == q0) block_gather_axpy<T, T, BLOCK, false>(Vm, itm, c, r1, part, wbuf, geo, q1, q1 == q0);
+                if (RES && q1 > q0) block_gather_axpy<T, T, BLOCK, true, UNR>(rowsL, nullptr, c, q1, part, wbuf, geo, q0, true, lstride);
+                if (r1 > q1 || q1 == q0) block_gather_axpy<T, T, BLOCK, false, UNR>(Vm, itm, c, r1, part, wbuf, geo, q1, q1 == q0);
                 exchange_vector(vec);
             }
         };
@@ -1311,7 +1320,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         for (int p = tid; p < n; p += BLOCK) { ms0[p] = S.ms[s0 + p]; lv0[p] = S.slvl[s0 + p]; itm[p] = S.sitem[s0 + p]; }
         for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
         __syncthreads();
-        if (q1 > q0) stage_rows<T, BLOCK>(Vm, itm, q0, q1, rowsL, geo, nchp);      // lands while the gradient sweep runs
+        if (RES && q1 > q0) stage_rows<T, BLOCK>(Vm, itm, q0, q1, rowsL, geo, nchp);      // lands while the gradient sweep runs
         UPROF(0);
         // ---- gradient coefficients, obtain_g_u_new (pcrpp.cpp:506-535)
         block_excl_scan<BLOCK>([&](int i) { return (double)ms0[i]; }, Sx, n, red);
@@ -1320,7 +1329,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
             key[p] = (T)(win ? sweep_coeff_win(win + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)ms0[p], 1.0)
                              : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)ms0[p], 1.0, strict));
         for (int t = tid; t < ld; t += BLOCK) gvec[t] = (n == 0) ? 0.0 : uvec[t] * lambda;   // :495-498
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // the LDS-DMA of stage_rows
+        if (RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the LDS-DMA of stage_rows
         __syncthreads();
         UPROF(1);
         gather_axpy(key, gvec);

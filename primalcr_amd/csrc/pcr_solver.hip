@@ -76,12 +76,12 @@ struct Bin {
     int block = 64;
     bool big = false;
     int K = 1;           // workgroups per user (k_ustep clusters)
-    bool tail = false;   // the K = 1 remainder of a cluster bin
     int ugrid = 0;       // k_ustep grid of this bin
     int scratch_ofs = 0; // first global-scratch slice of this bin (big bins that run concurrently must not share slices)
     int cap = 0;         // longest user in the bin
     int limit = 0;       // upper length bound of the class (0: none)
     int rcap = 0;        // k_ustep: rows of V a workgroup keeps resident in LDS
+    int unr = 4;         // k_ustep: rows in flight per lane group (8: latency-bound class, one workgroup per CU)
     int max_lev = 0;
     int64_t nnz = 0;     // ratings of the users in the bin
     std::vector<int32_t> users;
@@ -135,6 +135,15 @@ struct Solver final : pcr_solver {
     static constexpr int NSIDE = 12;
     hipStream_t side[NSIDE] = {};                                 // length bins run concurrently
     hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {};
+    hipStream_t hi = nullptr;                                     // high priority: the cluster class of the U step
+    hipEvent_t ev_hi = nullptr;
+    // Streams that really run side by side.  HIP multiplexes its streams onto a few hardware queues (4 by default) in
+    // creation order across the whole process, and two streams on one queue serialise: which of ours collide depends on
+    // what else the process created.  pick_lanes() measures it once and keeps up to 4 mutually independent streams
+    // (lane[0] = the solver's stream); concurrent length classes are placed on lanes only.
+    hipStream_t lane[4] = {};
+    hipEvent_t ev_lane[4] = {};
+    int nlane = 1;
     ncclComm_t comm = nullptr;
     int ncu = 256;
 
@@ -200,6 +209,9 @@ struct Solver final : pcr_solver {
         if (h_counters) (void)hipHostFree(h_counters);
         for (int i = 0; i < NSIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
+        for (int i = 0; i < 4; ++i) if (ev_lane[i]) (void)hipEventDestroy(ev_lane[i]);
+        if (hi) (void)hipStreamDestroy(hi);
+        if (ev_hi) (void)hipEventDestroy(ev_hi);
         if (st) (void)hipStreamDestroy(st);
     }
 
@@ -246,6 +258,36 @@ struct Solver final : pcr_solver {
         return PCR_OK;
     }
 
+    // does work on stream b wait for work on stream a (same hardware queue)?
+    int shares_queue(hipStream_t a, hipStream_t b, long long ticks, hipEvent_t ev, bool* out) {
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks);
+        hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, b);
+        HIPCHK(hipEventRecord(ev, b));
+        const auto t0 = std::chrono::steady_clock::now();
+        HIPCHK(hipEventSynchronize(ev));
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        HIPCHK(hipStreamSynchronize(a));
+        *out = us > 150.0;                                         // the spin lasts 300 us
+        return PCR_OK;
+    }
+    int pick_lanes() {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, prm.device) != hipSuccess || khz <= 0) khz = 100000;
+        const long long ticks = (long long)khz * 300 / 1000;       // 300 us
+        for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&ev_lane[i], hipEventDisableTiming));
+        lane[0] = st; nlane = 1;
+        if (const char* e = getenv("PCR_LANES")) if (atoi(e) == 1) return PCR_OK;               // developer knob: no concurrency
+        bool dummy = false;
+        RC(shares_queue(st, side[0], ticks / 30, ev_lane[0], &dummy));                          // warm up: first launches are slow
+        for (int c = 0; c < NSIDE && nlane < 4; ++c) {
+            bool clash = false;
+            for (int l = 0; l < nlane && !clash; ++l) RC(shares_queue(lane[l], side[c], ticks, ev_lane[0], &clash));
+            if (!clash) lane[nlane++] = side[c];
+            if (getenv("PCR_DEBUG_LANES")) fprintf(stderr, "[pcr] side stream %d %s\n", c, clash ? "shares a queue with a lane" : "is a lane");
+        }
+        return PCR_OK;
+    }
+
     // ------------------------------------------------------------------------------ setup
     static void make_bins(const std::vector<int64_t>& uptr, int64_t nu, const std::vector<int64_t>* runofs, std::vector<Bin>& out,
                           const std::vector<int>& limits = {BIN_LIMIT[0], BIN_LIMIT[1], BIN_LIMIT[2]},
@@ -283,6 +325,12 @@ struct Solver final : pcr_solver {
         ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_hi, hipEventDisableTiming));
+        {
+            int least = 0, greatest = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPCHK(hipStreamCreateWithPriority(&hi, hipStreamNonBlocking, greatest));
+        }
         for (int i = 0; i < NSIDE; ++i) {
             HIPCHK(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
@@ -413,38 +461,59 @@ struct Solver final : pcr_solver {
             ucap.clear(); ublk.clear(); ures.clear();
             for (const char* q = e; *q;) {
                 int c = 0, bl = 0, rs = 1, used = 0;
-                if (sscanf(q, "%d:%d:%d%n", &c, &bl, &rs, &used) != 3 || (bl != 64 && bl != 128 && bl != 256 && bl != 512) || c < 1 || c > 1024 ||
+                if (sscanf(q, "%d:%d:%d%n", &c, &bl, &rs, &used) != 3 || (bl != 64 && bl != 256) || c < 1 || c >= 1024 || (rs && bl != 64) ||
                     (!ucap.empty() && c <= ucap.back())) { pcr_set_error("bad PCR_UBINS"); return PCR_ERR_ARG; }
                 ucap.push_back(c); ublk.push_back(bl); ures.push_back(rs);
                 q += used; if (*q == ',') ++q;
             }
         }
         const size_t nsmall = ucap.size();
-        ucap.push_back(1024); ucap.push_back(4096);
-        ublk.push_back(512); ublk.push_back(512); ublk.push_back(512);
+        // Latency or throughput?  A class with few users (ml1m's long users) is one round of workgroups and is bound by the
+        // per-user dependency chain: 512 threads, 8 rows in flight per lane group, one workgroup per CU.  A class with many
+        // users (Netflix-shaped data) is bound by how busy each CU's memory pipe stays: smaller / leaner workgroups, so that
+        // two share a CU and one gathers while the other scans or sorts (<= 1024 ratings: 256 threads; above: 512 threads
+        // at 4 rows in flight = 128 VGPRs, and a class boundary at 2048 so that the per-rating arrays of two fit the LDS).
+        static const int force_mode = getenv("PCR_USTEP_MODE") ? atoi(getenv("PCR_USTEP_MODE")) : 0;   // 1 latency, 2 throughput
+        auto many = [&](int64_t users) { return force_mode ? force_mode == 2 : users > 2 * (int64_t)ncu; };
+        int64_t n_mid = 0;
+        for (int64_t u = 0; u < nu; ++u) { const int64_t len = uptr[u + 1] - uptr[u]; n_mid += len > 1024 && len <= 4096; }
+        ucap.push_back(1024); ublk.push_back(512);
+        if (many(n_mid)) { ucap.push_back(2048); ublk.push_back(512); }
+        ucap.push_back(4096); ublk.push_back(512); ublk.push_back(512);
         make_bins(uptr, nu, &lv.run_ofs, ubins, ucap, ublk);
-        // cluster sizes of the three top classes (<= 1024, <= 4096, longer): PCR_CLUSTER_K="k2,k3,k4" overrides (each 1, 2, 4 or 8)
-        int ck[3] = {1, 4, 4};
-        if (const char* e = getenv("PCR_CLUSTER_K")) sscanf(e, "%d,%d,%d", &ck[0], &ck[1], &ck[2]);
-        for (int q = 0; q < 3; ++q) if (ck[q] != 1 && ck[q] != 2 && ck[q] != 4 && ck[q] != 8) ck[q] = 1;
-        for (int q = 0; q < 3; ++q) ubins[nsmall + q].K = ck[q];
+        // Workgroup clusters trade throughput for latency: only the longest users of the shard (the critical path, more than
+        // 1024 ratings) get them, ncu/(2K) users so that all their workgroups fit the chip at once -- ONE extra class
+        // whatever length class they came from (in global scratch if any of them needs it).  PCR_CLUSTER_K=1 disables.
+        int cluster_k = 4;
+        if (const char* e = getenv("PCR_CLUSTER_K")) cluster_k = atoi(e) == 4 ? 4 : 1;
         max_clusters = std::max(1, ncu / 2);
-        // Clusters trade throughput for latency: only the head of a bin (its longest users, the critical path) gets
-        // them, ncu/(2K) users at most so that all their workgroups fit the chip at once; the rest of the bin runs
-        // one workgroup per user.
-        for (size_t q = nsmall; q < nsmall + 3; ++q) {
-            Bin& b = ubins[q];
-            const size_t head = (size_t)std::max(1, ncu / (2 * std::max(1, b.K)));
-            if (b.K > 1 && b.users.size() > head) {
-                Bin tail;
-                tail.block = b.block; tail.big = b.big; tail.limit = b.limit; tail.K = 1; tail.tail = true; tail.max_lev = b.max_lev;
-                tail.users.assign(b.users.begin() + head, b.users.end());
-                for (int32_t u : tail.users) tail.nnz += uptr[u + 1] - uptr[u];
-                b.nnz -= tail.nnz;
-                tail.cap = (int)(uptr[tail.users[0] + 1] - uptr[tail.users[0]]);
-                b.users.resize(head);
-                ubins.push_back(std::move(tail));
+        if (cluster_k > 1) {
+            Bin head;
+            head.block = 512; head.K = cluster_k;
+            size_t budget = (size_t)std::max(1, ncu / (2 * cluster_k));
+            for (size_t q = ubins.size(); q-- > nsmall + 1 && budget > 0;) {       // longest class first; users are sorted longest first
+                Bin& b = ubins[q];
+                const size_t take = std::min(budget, b.users.size());
+                if (take == 0) continue;
+                budget -= take;
+                head.big = head.big || b.big;
+                head.max_lev = std::max(head.max_lev, b.max_lev);
+                for (size_t i = 0; i < take; ++i) {
+                    const int32_t u = b.users[i];
+                    const int64_t len = uptr[u + 1] - uptr[u];
+                    head.users.push_back(u); head.nnz += len; head.cap = std::max<int>(head.cap, (int)len);
+                    b.nnz -= len;
+                }
+                b.users.erase(b.users.begin(), b.users.begin() + take);
+                b.cap = b.users.empty() ? 0 : (int)(uptr[b.users[0] + 1] - uptr[b.users[0]]);
             }
+            if (!head.users.empty()) ubins.push_back(std::move(head));
+        }
+        for (size_t q = nsmall; q < ubins.size(); ++q) {
+            Bin& b = ubins[q];
+            if (b.K > 1 || !many((int64_t)b.users.size())) { b.unr = 8; continue; }
+            b.unr = 4;
+            if (b.limit == 1024 && !b.big) b.block = 256;
         }
         u_big_blocks = 0;
         for (auto& b : ubins) {
@@ -455,12 +524,12 @@ struct Solver final : pcr_solver {
         {   // LDS residency: what is left of the 160 KB after the r-vectors and the per-rating arrays, in rows of V
             const int nchp = geo.nchunk | 1;
             const size_t lim = 160 * 1024;
-            int res_top = 1;                                               // the classes from 1024 up
-            if (const char* e = getenv("PCR_USTEP_RESIDENT")) res_top = atoi(e);
             for (size_t bi = 0; bi < ubins.size(); ++bi) {
                 Bin& b = ubins[bi];
                 if (b.users.empty()) continue;
-                const int res_on = (bi < nsmall) ? ures[bi] : res_top;
+                // the LDS image pays where LDS is spare: the one-wave classes of <= 64 ratings, and the latency-bound
+                // 512-thread classes (one workgroup per CU anyway), which keep as many rows as fit beside their arrays
+                const int res_on = bi < nsmall ? (b.block == 64 ? ures[bi] : 0) : (b.unr == 8);
                 const size_t fixed = ustep_small_bytes(geo.ld, b.block, sizeof(T)) +
                                      (b.big ? 0 : ustep_big_bytes<T>(b.cap, host_pow2(b.cap), b.max_lev + 2, 4));
                 const int64_t room = fixed < lim ? (int64_t)((lim - fixed) / ((size_t)nchp * 16)) : 0;
@@ -561,6 +630,7 @@ struct Solver final : pcr_solver {
         }
         RC(set_lds_limits());
         HIPCHK(hipStreamSynchronize(st));
+        RC(pick_lanes());
         return PCR_OK;
     }
 
@@ -572,10 +642,10 @@ struct Solver final : pcr_solver {
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 512, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-#define UL(BL, BG, KK) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, BL, BG, KK>, hipFuncAttributeMaxDynamicSharedMemorySize, lim))
-        UL(64, false, 1); UL(128, false, 1); UL(256, false, 1);
-        UL(512, false, 1); UL(512, false, 2); UL(512, false, 4); UL(512, false, 8);
-        UL(512, true, 1); UL(512, true, 2); UL(512, true, 4); UL(512, true, 8);
+#define UL(BL, BG, KK, RS, UN) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, BL, BG, KK, RS, UN>, hipFuncAttributeMaxDynamicSharedMemorySize, lim))
+        UL(64, false, 1, true, 4); UL(64, false, 1, false, 4); UL(256, false, 1, false, 4);
+        UL(512, false, 1, true, 8); UL(512, false, 1, false, 4); UL(512, false, 4, true, 8);
+        UL(512, true, 1, true, 8); UL(512, true, 1, false, 4); UL(512, true, 4, true, 8);
 #undef UL
         HIPCHK(hipFuncSetAttribute((const void*)k_eval<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_eval2<T, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -596,17 +666,65 @@ struct Solver final : pcr_solver {
         bool forked = false;
         // longest users first: their workgroups are the critical path and must not queue behind the many
         // short-user workgroups
+        bool used[4] = {false, false, false, false};
+        int next = 0;
         for (size_t ii = bs.size(); ii-- > 0;) {
             const size_t i = ii;
             if (bs[i].users.empty() || (int)i == main_bin) continue;
-            if (!forked) { HIPCHK(hipEventRecord(ev_fork, st)); forked = true; }
-            HIPCHK(hipStreamWaitEvent(side[i], ev_fork, 0));
-            { ProfScope ps(this, pname(cls, bs[i]), side[i], bs[i].nnz, (int64_t)bs[i].users.size()); launch(bs[i], side[i]); }
-            HIPCHK(hipEventRecord(ev_join[i], side[i]));
+            const int l = nlane > 1 ? 1 + next++ % (nlane - 1) : 0;      // side lanes in turn; classes sharing a lane run back to back
+            if (l > 0 && !forked) { HIPCHK(hipEventRecord(ev_fork, st)); forked = true; }
+            if (l > 0 && !used[l]) HIPCHK(hipStreamWaitEvent(lane[l], ev_fork, 0));
+            used[l] = true;
+            ProfScope ps(this, pname(cls, bs[i]), lane[l], bs[i].nnz, (int64_t)bs[i].users.size());
+            launch(bs[i], lane[l]);
         }
         { ProfScope ps(this, pname(cls, bs[main_bin]), st, bs[main_bin].nnz, (int64_t)bs[main_bin].users.size()); launch(bs[main_bin], st); }
-        for (size_t i = 0; i < bs.size(); ++i)
-            if (!bs[i].users.empty() && (int)i != main_bin) HIPCHK(hipStreamWaitEvent(st, ev_join[i], 0));
+        for (int l = 1; l < nlane; ++l)
+            if (used[l]) { HIPCHK(hipEventRecord(ev_lane[l], lane[l])); HIPCHK(hipStreamWaitEvent(st, ev_lane[l], 0)); }
+        HIPCHK(hipGetLastError());
+        return PCR_OK;
+    }
+    // U step: the hardware runs only a few queues side by side (streams beyond that share a queue and serialise), so the
+    // classes are placed deliberately: the cluster class (the longest users, the critical path) alone on a high-priority
+    // stream; the other classes, longest first, dealt round-robin onto three streams, so the three longest start at once
+    // and the short classes queue behind them and fill the CUs as those drain.
+    template <class F>
+    int for_ubins(F launch) {
+        std::vector<Bin*> order;                       // [cluster class, then the others longest first]
+        for (auto& b : ubins) if (!b.users.empty() && b.K > 1) order.push_back(&b);
+        const size_t nhead = order.size();
+        for (auto& b : ubins) if (!b.users.empty() && b.K <= 1) order.push_back(&b);
+        if (order.empty()) return PCR_OK;
+        std::stable_sort(order.begin() + nhead, order.end(), [](const Bin* a, const Bin* b) { return a->cap > b->cap; });
+        // plan: (class, stream) in launch order.  Streams: 0..3 = lane[], 4 = hi.
+        std::vector<std::pair<int, int>> plan;
+        static const char* sched = getenv("PCR_USTEP_SCHED");        // developer knob: "class:stream,..." (stream: 0-3 lane, h)
+        if (sched) {
+            for (const char* q = sched; *q;) {
+                int c = 0, used = 0; char ch = 0;
+                if (sscanf(q, "%d:%c%n", &c, &ch, &used) != 2) break;
+                const int sidx = ch == 'h' ? 4 : std::min(nlane - 1, std::max(0, ch - '0'));
+                if (c >= 0 && c < (int)order.size()) plan.push_back({c, sidx});
+                q += used; if (*q == ',') ++q;
+            }
+        } else {
+            for (size_t i = 0; i < nhead; ++i) plan.push_back({(int)i, 4});
+            for (size_t i = nhead; i < order.size(); ++i) plan.push_back({(int)i, (int)((i - nhead) % nlane)});   // longest on the solver's stream
+        }
+        ProfScope wall(this, "wall:ustep", st);
+        bool used[5] = {false, false, false, false, false};
+        HIPCHK(hipEventRecord(ev_fork, st));
+        for (auto& pr : plan) {
+            Bin& b = *order[pr.first];
+            hipStream_t q = pr.second == 4 ? hi : lane[pr.second];
+            if (q != st && !used[pr.second]) HIPCHK(hipStreamWaitEvent(q, ev_fork, 0));
+            used[pr.second] = true;
+            ProfScope ps(this, pname("ustep", b), q, b.nnz, (int64_t)b.users.size());
+            launch(b, q);
+        }
+        for (int l = 1; l < nlane; ++l)
+            if (used[l]) { HIPCHK(hipEventRecord(ev_lane[l], lane[l])); HIPCHK(hipStreamWaitEvent(st, ev_lane[l], 0)); }
+        if (used[4]) { HIPCHK(hipEventRecord(ev_hi, hi)); HIPCHK(hipStreamWaitEvent(st, ev_hi, 0)); }
         HIPCHK(hipGetLastError());
         return PCR_OK;
     }
@@ -626,7 +744,7 @@ struct Solver final : pcr_solver {
     static std::string pname(const char* cls, const Bin& b) {
         std::string s = std::string(cls) + "/" + std::to_string(b.block);
         if (!strcmp(cls, "ustep") && b.limit) s += "." + std::to_string(b.limit);
-        return s + (b.big ? "g" : "") + (b.K > 1 ? "c" : "") + (b.tail ? "t" : "");
+        return s + (b.big ? "g" : "") + (b.K > 1 ? "c" : "");
     }
     size_t small_common(int block) const { return carve_bytes(geo.ld, sizeof(T)) + carve_bytes(block / PCR_WAVE + 1, 8); }
     int strict() const { return prm.solver_type == PCR_SOLVER_PCR ? 1 : 0; }
@@ -940,19 +1058,17 @@ struct Solver final : pcr_solver {
             // clusters: grid <= one workgroup per CU so that every member of every cluster is resident
             const int grid = b.ugrid;
             char* scr = d_scratch.p + (size_t)b.scratch_ofs * scratch_stride;
-#define LU(BL, BG, KK) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb)
-            if (b.big) { if (b.K == 8) LU(512, true, 8); else if (b.K == 4) LU(512, true, 4); else if (b.K == 2) LU(512, true, 2); else LU(512, true, 1); }
-            else if (b.block == 64) LU(64, false, 1);
-            else if (b.block == 128) LU(128, false, 1);
-            else if (b.block == 256) LU(256, false, 1);
-            else if (b.K == 8) LU(512, false, 8);
-            else if (b.K == 4) LU(512, false, 4);
-            else if (b.K == 2) LU(512, false, 2);
-            else LU(512, false, 1);
+#define LU(BL, BG, KK, RS, UN) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb)
+            if (b.big) { if (b.K == 4) LU(512, true, 4, true, 8); else if (b.unr == 8) LU(512, true, 1, true, 8); else LU(512, true, 1, false, 4); }
+            else if (b.block == 64) { if (b.rcap > 0) LU(64, false, 1, true, 4); else LU(64, false, 1, false, 4); }
+            else if (b.block == 256) LU(256, false, 1, false, 4);
+            else if (b.K == 4) LU(512, false, 4, true, 8);
+            else if (b.unr == 8) LU(512, false, 1, true, 8);
+            else LU(512, false, 1, false, 4);
 #undef LU
         };
         static const int seq = getenv("PCR_USTEP_SEQ") ? atoi(getenv("PCR_USTEP_SEQ")) : 0;     // developer knob
-        if (seq) RC(for_bins_seq(ubins, "ustep", fn)); else RC(for_bins(ubins, "ustep", fn));
+        if (seq) RC(for_bins_seq(ubins, "ustep", fn)); else RC(for_ubins(fn));
         return PCR_OK;
     }
 
