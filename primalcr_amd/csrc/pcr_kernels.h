@@ -55,7 +55,10 @@ struct Shard {
     int32_t* sitem;            // nnz    item id at sorted position
     uint16_t* slvl;            // nnz
     int32_t* cinv;             // nnz    CSC entry -> sorted position (k_spmm reads c through it)
-    double* objp;              // nu     per-user loss partial
+    int32_t* scpos;            // nnz    CSC entry of the rating at each sorted position (inverse of cinv): lets k_ustep
+                               //        re-sort a user in place without going back to CSR order
+    double* objp;              // nu     per-user loss partial (no regulariser)
+    double* objr;              // nu     k_ustep: obj_u of the returned u (loss + lambda/2 |u|^2, pcrpp.cpp:835)
     // window cache: for sorted position p and every OTHER level l' (slot = l' < l ? l' : l'-1) the
     // boundary index of the active prefix / suffix of run l'.  Depends on m only, so k_prepare
     // finds it once and every sweep of the V step (gradient + <=10 Hessian-vector products) and of
@@ -673,7 +676,9 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const in
             S.ms[s0 + p] = key[p];
             S.slvl[s0 + p] = (uint16_t)LiOps<LI>::lev(x);
             S.sitem[s0 + p] = S.item[s0 + idx];
-            S.cinv[S.cpos[s0 + idx]] = (int32_t)(s0 + p);
+            const int32_t e = S.cpos[s0 + idx];
+            S.scpos[s0 + p] = e;
+            S.cinv[e] = (int32_t)(s0 + p);
         }
         double loss;
         if (S.ws) {
@@ -1342,7 +1347,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         // the user's loss at the gradient point is what the last k_prepare left in objp[u] (same m, same windows):
         // no need to sweep for it again
         const double prev_obj = lambda / 2.0 * un2 + S.objp[u];
-        double obj_new = prev_obj;
+        double obj_new = prev_obj, loss_new = 0.0;
         int n_cg = 0, n_ls = 0;
         // pcrpp.cpp:787-790; PrimalCR additionally keeps u when no comparable pair exists
         // (cc == 0, pcr.cpp:552)
@@ -1417,8 +1422,8 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                 __syncthreads();
                 bitonic_sort<T, LI, BLOCK>(key, li, npad);                      // update_infor_ui (:684-726)
                 UPROF(8);
-                obj_new = lambda / 2.0 * nn +
-                    block_objective<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, Sx, red, strict);
+                loss_new = block_objective<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, Sx, red, strict);
+                obj_new = lambda / 2.0 * nn + loss_new;
                 ++n_ls;
                 UPROF(9);
                 if (obj_new < prev_obj) break;
@@ -1426,9 +1431,31 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
             }
         }
         __syncthreads();
+        // ---- The scores of the last line-search try ARE m = V_I u_new, sorted: leave them as the shard's sorted state
+        // (what k_prepare would rebuild from (U_new, V) at the start of the next V step: scores, items, levels, the
+        // CSC <-> sorted maps, the window cache and the loss), so that update_V needs no SDDMM + sort of its own.
+        // A skipped user (:787-790) keeps u, so its state stays valid as it is.
+        if (!skip && mem == 0) {
+            int32_t* stage = reinterpret_cast<int32_t*>(Sx);                  // Sx is free again: (cap + 1) doubles >= n ints
+            for (int p = tid; p < n; p += BLOCK) stage[p] = S.scpos[s0 + LiOps<LI>::idx(li[p])];
+            __syncthreads();                                                  // all of the old map is read before any of it is rewritten
+            uint32_t* wout = S.ws ? S.win + (size_t)s0 * S.ws : nullptr;
+            for (int p = tid; p < n; p += BLOCK) {
+                const LI x = li[p];
+                const int lev = (int)LiOps<LI>::lev(x);
+                S.ms[s0 + p] = key[p];
+                S.slvl[s0 + p] = (uint16_t)lev;
+                S.sitem[s0 + p] = itm[LiOps<LI>::idx(x)];
+                const int32_t e = stage[p];
+                S.scpos[s0 + p] = e;
+                S.cinv[e] = (int32_t)(s0 + p);
+                if (wout) find_windows<T>(key, rs, nlev, lev, key[p], strict, wout + (size_t)p * S.ws);
+            }
+        }
         if (mem == 0) for (int t = tid; t < ld; t += BLOCK) U[(size_t)u * ld + t] = (T)unew[t];
         if (tid == 0 && mem == 0) {
-            S.objp[u] = obj_new;
+            S.objr[u] = obj_new;
+            if (!skip) S.objp[u] = loss_new;
             if (n_cg) atomicAdd(counters + 0, (unsigned long long)n_cg);
             if (n_ls) atomicAdd(counters + 1, (unsigned long long)n_ls);
         }

@@ -150,6 +150,8 @@ struct Solver final : pcr_solver {
     // ---- training shard
     Shard<T> sh;
     DBuf<int64_t> d_uptr, d_runofs;
+    DBuf<int32_t> d_scpos;
+    DBuf<double> d_objr;
     DBuf<int32_t> d_item, d_cpos, d_runstart, d_sitem, d_cinv, d_cuser, d_crow, d_ruser, d_slot_base, d_item_slot, d_chunk_ptr, d_slot_id;
     DBuf<int2> d_blk_chunks;                      // k_spmm: first chunk and chunk count of every workgroup
     int spmm_blocks = 0, spmm_tiles = 1;
@@ -196,6 +198,7 @@ struct Solver final : pcr_solver {
     unsigned long long* h_counters = nullptr;     // pinned
     int ew_blocks = 1, ew_per_block = 1;          // elementwise decomposition over d2*ld
     bool have_sorted = false;
+    bool state_of_rejected_V = false;             // the sorted state belongs to a V_new the line search did not accept (q5)
     double unorm2 = 0.0;                          // all-rank |U|^2 of the current U
     bool unorm_valid = false;
 
@@ -556,6 +559,8 @@ struct Solver final : pcr_solver {
         sh.uptr = d_uptr.p; sh.item = d_item.p; sh.lvl = d_lvl.p; sh.cpos = d_cpos.p;
         sh.runofs = d_runofs.p; sh.runstart = d_runstart.p;
         sh.ms = d_ms.p; sh.sitem = d_sitem.p; sh.slvl = d_slvl.p; sh.cinv = d_cinv.p; sh.objp = d_objp.p;
+        RC(d_scpos.alloc(nnz_local)); RC(d_objr.alloc(nu));
+        sh.scpos = d_scpos.p; sh.objr = d_objr.p;
         // window cache (pcr_kernels.h, Shard::win): one slot per other level, up to 9 levels
         sh.ws = (lv.max_levels >= 2 && lv.max_levels <= 9) ? lv.max_levels - 1 : 0;
         if (const char* e = getenv("PCR_NO_WINDOW_CACHE")) if (atoi(e)) sh.ws = 0;
@@ -699,7 +704,7 @@ struct Solver final : pcr_solver {
         // plan: (class, stream) in launch order.  Streams: 0..3 = lane[], 4 = hi.
         std::vector<std::pair<int, int>> plan;
         static const char* sched = getenv("PCR_USTEP_SCHED");        // developer knob: "class:stream,..." (stream: 0-3 lane, h)
-        if (sched) {
+        if (sched && *sched) {
             for (const char* q = sched; *q;) {
                 int c = 0, used = 0; char ch = 0;
                 if (sscanf(q, "%d:%c%n", &c, &ch, &used) != 2) break;
@@ -707,7 +712,9 @@ struct Solver final : pcr_solver {
                 if (c >= 0 && c < (int)order.size()) plan.push_back({c, sidx});
                 q += used; if (*q == ',') ++q;
             }
-        } else {
+        }
+        if (plan.size() != order.size()) {                            // default (also when the knob does not name every class)
+            plan.clear();
             for (size_t i = 0; i < nhead; ++i) plan.push_back({(int)i, 4});
             for (size_t i = nhead; i < order.size(); ++i) plan.push_back({(int)i, (int)((i - nhead) % nlane)});   // longest on the solver's stream
         }
@@ -924,7 +931,7 @@ struct Solver final : pcr_solver {
     int set_factors(const double* U, const double* V) override {
         if (U) { RC(upload_mat(U + first_user * geo.r, n_users, d_U.p)); unorm_valid = false; }
         if (V) RC(upload_mat(V, d2, d_V.p));
-        have_sorted = false;
+        have_sorted = false; state_of_rejected_V = false;
         return PCR_OK;
     }
     int get_factors(double* U, double* V) override {
@@ -1019,7 +1026,7 @@ struct Solver final : pcr_solver {
     // pcrpp.cpp:415-444
     int update_V(double* now_obj, int* info) override {
         int cg_iters = 0, tries = 0, accepted = 0;
-        RC(launch_prepare(d_V.p));                        // comp_m_new (:417)
+        if (!have_sorted) RC(launch_prepare(d_V.p));      // comp_m_new (:417); after a U step its line search left exactly this state
         double prev_obj = 0.0;
         RC(full_objective(d_V.p, &prev_obj));                      // objective_new(m, U, V) (:425); m is the same
         RC(device_gradient());                                     // obtain_g_new (:418)
@@ -1039,6 +1046,7 @@ struct Solver final : pcr_solver {
             step /= 2.0;
         }
         // the sorted state now belongs to the LAST TRIED V_new, accepted or not (:430-431, :443)
+        state_of_rejected_V = !accepted;
         if (now_obj) *now_obj = obj;
         if (info) { info[0] = cg_iters; info[1] = tries; info[2] = accepted; }
         return PCR_OK;
@@ -1077,8 +1085,10 @@ struct Solver final : pcr_solver {
         RC(need_sorted());
         RC(launch_ustep());
         unorm_valid = false;
-        have_sorted = false;                                        // U changed: m is stale
-        RC(reduce_sum(d_objp.p, n_users, 0));                       // sum_i obj_u(i)
+        // U changed, and k_ustep left the sorted state of (U_new, V) behind: still valid for the next V step -- unless
+        // it started from the state of a rejected V_new, which the users it skipped still carry
+        if (state_of_rejected_V) { have_sorted = false; state_of_rejected_V = false; }
+        RC(reduce_sum(d_objr.p, n_users, 0));                       // sum_i obj_u(i)
         RC(allreduce_f64(d_scal.p, 1));
         RC(norm2(d_V.p, (int64_t)d2 * geo.ld, 2));
         HIPCHK(hipMemcpyAsync(h_counters, d_counters.p, (4 + 64) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
