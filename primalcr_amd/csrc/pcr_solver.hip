@@ -198,6 +198,8 @@ struct Solver final : pcr_solver {
     unsigned long long* h_counters = nullptr;     // pinned
     int ew_blocks = 1, ew_per_block = 1;          // elementwise decomposition over d2*ld
     bool have_sorted = false;
+    bool carry_obj_valid = false;                 // carry_obj = objective of the current (U, V) = the last U step's now_obj
+    double carry_obj = 0.0;
     bool state_of_rejected_V = false;             // the sorted state belongs to a V_new the line search did not accept (q5)
     double unorm2 = 0.0;                          // all-rank |U|^2 of the current U
     bool unorm_valid = false;
@@ -677,7 +679,10 @@ struct Solver final : pcr_solver {
             const size_t i = ii;
             if (bs[i].users.empty() || (int)i == main_bin) continue;
             const int l = nlane > 1 ? 1 + next++ % (nlane - 1) : 0;      // side lanes in turn; classes sharing a lane run back to back
-            if (l > 0 && !forked) { HIPCHK(hipEventRecord(ev_fork, st)); forked = true; }
+            // cross-stream waits on events that are still pending are slow here (see update_V): drain the solver's
+            // stream on the host before the fork, and join on the host too (join())
+            static const int fork_sync = getenv("PCR_FORK_SYNC") ? atoi(getenv("PCR_FORK_SYNC")) : 1;     // developer knob
+            if (l > 0 && !forked) { if (fork_sync) HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipEventRecord(ev_fork, st)); forked = true; }
             if (l > 0 && !used[l]) HIPCHK(hipStreamWaitEvent(lane[l], ev_fork, 0));
             used[l] = true;
             ProfScope ps(this, pname(cls, bs[i]), lane[l], bs[i].nnz, (int64_t)bs[i].users.size());
@@ -685,8 +690,14 @@ struct Solver final : pcr_solver {
         }
         { ProfScope ps(this, pname(cls, bs[main_bin]), st, bs[main_bin].nnz, (int64_t)bs[main_bin].users.size()); launch(bs[main_bin], st); }
         for (int l = 1; l < nlane; ++l)
-            if (used[l]) { HIPCHK(hipEventRecord(ev_lane[l], lane[l])); HIPCHK(hipStreamWaitEvent(st, ev_lane[l], 0)); }
+            if (used[l]) { HIPCHK(hipEventRecord(ev_lane[l], lane[l])); RC(join(ev_lane[l])); }
         HIPCHK(hipGetLastError());
+        return PCR_OK;
+    }
+    // the solver's stream continues after `ev`
+    int join(hipEvent_t ev) {
+        static const int host_join = getenv("PCR_HOST_JOIN") ? atoi(getenv("PCR_HOST_JOIN")) : 1;      // developer knob
+        if (host_join) HIPCHK(hipEventSynchronize(ev)); else HIPCHK(hipStreamWaitEvent(st, ev, 0));
         return PCR_OK;
     }
     // U step: the hardware runs only a few queues side by side (streams beyond that share a queue and serialise), so the
@@ -730,8 +741,8 @@ struct Solver final : pcr_solver {
             launch(b, q);
         }
         for (int l = 1; l < nlane; ++l)
-            if (used[l]) { HIPCHK(hipEventRecord(ev_lane[l], lane[l])); HIPCHK(hipStreamWaitEvent(st, ev_lane[l], 0)); }
-        if (used[4]) { HIPCHK(hipEventRecord(ev_hi, hi)); HIPCHK(hipStreamWaitEvent(st, ev_hi, 0)); }
+            if (used[l]) { HIPCHK(hipEventRecord(ev_lane[l], lane[l])); RC(join(ev_lane[l])); }
+        if (used[4]) { HIPCHK(hipEventRecord(ev_hi, hi)); RC(join(ev_hi)); }
         HIPCHK(hipGetLastError());
         return PCR_OK;
     }
@@ -901,11 +912,13 @@ struct Solver final : pcr_solver {
 
     // loss (all ranks) of the last prepare + lambda/2 (|U|^2 + |Vm|^2)   (pcrpp.cpp:410)
     int full_objective(const T* Vm, double* obj) {
-        RC(ensure_unorm());
+        const bool need_u = !unorm_valid;                          // |U|^2 rides on the same read-back instead of its own sync
+        if (need_u) { RC(norm2(d_U.p, (int64_t)n_users * geo.ld, 8)); RC(allreduce_f64(d_scal.p + 8, 1)); }
         RC(reduce_sum(d_objp.p, n_users, 0));
         RC(allreduce_f64(d_scal.p, 1));
         RC(norm2(Vm, (int64_t)d2 * geo.ld, 2));
-        RC(fetch_scal(4));
+        RC(fetch_scal(need_u ? 9 : 4));
+        if (need_u) { unorm2 = h_scal[8]; unorm_valid = true; }
         *obj = h_scal[0] + prm.lambda * (unorm2 + h_scal[2]) / 2.0;
         return PCR_OK;
     }
@@ -931,7 +944,7 @@ struct Solver final : pcr_solver {
     int set_factors(const double* U, const double* V) override {
         if (U) { RC(upload_mat(U + first_user * geo.r, n_users, d_U.p)); unorm_valid = false; }
         if (V) RC(upload_mat(V, d2, d_V.p));
-        have_sorted = false; state_of_rejected_V = false;
+        have_sorted = false; state_of_rejected_V = false; carry_obj_valid = false;
         return PCR_OK;
     }
     int get_factors(double* U, double* V) override {
@@ -988,6 +1001,7 @@ struct Solver final : pcr_solver {
     }
 
     // CG on H delta = g with g in d_g (pcrpp.cpp:335-358); result in d_delta
+    // iters == nullptr: no host sync; the iteration count is in h_cg once the stream has passed this point
     int device_cg(int* iters) {
         const int64_t n = (int64_t)d2 * geo.ld;
         {
@@ -1012,8 +1026,7 @@ struct Solver final : pcr_solver {
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipMemcpyAsync(h_cg, d_cg.p, sizeof(CGState), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (iters) *iters = h_cg->iters;
+        if (iters) { HIPCHK(hipStreamSynchronize(st)); *iters = h_cg->iters; }
         return PCR_OK;
     }
     int solve_delta(const double* g, double* delta, int* iters) override {
@@ -1028,9 +1041,16 @@ struct Solver final : pcr_solver {
         int cg_iters = 0, tries = 0, accepted = 0;
         if (!have_sorted) RC(launch_prepare(d_V.p));      // comp_m_new (:417); after a U step its line search left exactly this state
         double prev_obj = 0.0;
-        RC(full_objective(d_V.p, &prev_obj));                      // objective_new(m, U, V) (:425); m is the same
+        // objective_new(m, U, V) (:425): right after a U step it is that step's now_obj (sum_i obj_u + lambda/2 |V|^2, :835) --
+        // the same quantity over the same m -- so no reduction + read-back of its own
+        if (carry_obj_valid && have_sorted) prev_obj = carry_obj;
+        else RC(full_objective(d_V.p, &prev_obj));
+        carry_obj_valid = false;
         RC(device_gradient());                                     // obtain_g_new (:418)
-        RC(device_cg(&cg_iters));                                  // solve_delta_new (:422)
+        // solve_delta_new (:422).  The host waits for the CG here on purpose: the line search forks its length classes
+        // onto the lanes, and a fork whose event is still pending when the lanes reach it costs far more on this
+        // platform than the host round trip (measured: 2.19 -> 2.40 ms per iteration without this sync)
+        RC(device_cg(&cg_iters));
         double step = prm.stepsize, obj = prev_obj;
         const int64_t n = (int64_t)d2 * geo.ld;
         for (int it = 0; it < 20; ++it) {                          // :427-441
@@ -1106,7 +1126,9 @@ struct Solver final : pcr_solver {
             }
         }
 #endif
-        if (now_obj) *now_obj = h_scal[0] + prm.lambda / 2.0 * h_scal[2];   // :835
+        carry_obj = h_scal[0] + prm.lambda / 2.0 * h_scal[2];      // :835
+        carry_obj_valid = have_sorted;
+        if (now_obj) *now_obj = carry_obj;
         if (h_counters[3] != 0) { pcr_set_error("k_ustep: a workgroup cluster timed out at a hand-off (members not co-resident?)"); return PCR_ERR_DEVICE; }
         if (info) { info[0] = (int64_t)h_counters[0]; info[1] = (int64_t)h_counters[1]; }
         return PCR_OK;
