@@ -89,6 +89,15 @@ typedef struct pcr_dataset pcr_dataset;   /* training CSR + test CSR, host memor
 int pcr_dataset_load(const char *dir, pcr_dataset **out);                 /* [host] */
 /* the same with `threads` host parser threads (the CLI passes -n; 0 = up to 16) */
 int pcr_dataset_load_mt(const char *dir, int threads, pcr_dataset **out); /* [host] */
+/* Binary side-car of a loaded data set (the reference re-parses the text with fgets/sscanf and re-sorts on
+ * every run, util.cpp:6-25, util.h:197-271).  pcr_dataset_save_cache writes the converted CSRs (train + test) to
+ * `path`; pcr_dataset_load_cache reads them back (PCR_ERR_IO if the file is missing, truncated or of another version).
+ * pcr_dataset_load_cached(dir, threads, cache, out) = load_cache(cache) when the cache exists AND records the same
+ * size and modification time of <dir>/meta and of the rating files it names, else load_mt(dir) followed by a best-effort
+ * save_cache(cache) (an unwritable cache path is not an error).  The text formats stay the only input format. */
+int pcr_dataset_save_cache(const pcr_dataset *ds, const char *path);      /* [host] */
+int pcr_dataset_load_cache(const char *path, pcr_dataset **out);          /* [host] */
+int pcr_dataset_load_cached(const char *dir, int threads, const char *cache, pcr_dataset **out);   /* [host] */
 /* same conversion from in-memory 0-based triplets (train in any order; test must
  * be user-sorted, util.cpp:259-261).  tnnz may be 0. */
 int pcr_dataset_from_triplets(int64_t d1, int64_t d2,

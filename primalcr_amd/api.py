@@ -67,6 +67,9 @@ def lib():
     L.pcr_params_default.argtypes = [C.POINTER(Parameter)]
     L.pcr_initial.argtypes = [_dp, i64, i64]
     L.pcr_dataset_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.pcr_dataset_load_cached.argtypes = [C.c_char_p, ci, C.c_char_p, C.POINTER(vp)]
+    L.pcr_dataset_load_cache.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.pcr_dataset_save_cache.argtypes = [vp, C.c_char_p]
     L.pcr_dataset_from_triplets.argtypes = [i64, i64, i64, vp, vp, vp, i64, vp, vp, vp, C.POINTER(vp)]
     L.pcr_dataset_free.argtypes = [vp]
     L.pcr_dataset_dims.argtypes = [vp] + [C.POINTER(i64)] * 4
@@ -158,10 +161,23 @@ class Dataset:
         self._h = handle
 
     @classmethod
-    def load(cls, path):
+    def load(cls, path, cache=None, threads=0):
+        """cache: path of the binary side-car (read if it matches the text files, else rebuilt)."""
         h = C.c_void_p()
-        _chk(lib().pcr_dataset_load(os.fsencode(path), C.byref(h)))
+        if cache is None:
+            _chk(lib().pcr_dataset_load(os.fsencode(path), C.byref(h)))
+        else:
+            _chk(lib().pcr_dataset_load_cached(os.fsencode(path), threads, os.fsencode(cache), C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def load_cache(cls, cache):
+        h = C.c_void_p()
+        _chk(lib().pcr_dataset_load_cache(os.fsencode(cache), C.byref(h)))
+        return cls(h)
+
+    def save_cache(self, cache):
+        _chk(lib().pcr_dataset_save_cache(self._h, os.fsencode(cache)))
 
     @classmethod
     def from_triplets(cls, d1, d2, user, item, val, tuser=None, titem=None, tval=None):

@@ -7,6 +7,9 @@
 //   --device N     HIP device ordinal
 //   --init-model F warm start: take the initial U, V from a model file instead of initial()
 //                  (the reference only has a commented-out text-file variant, pmf-train.cpp:262-263)
+//   --cache F      binary side-car of the parsed data set: read F if it matches the text files' size and
+//                  modification time, else parse the text and (best effort) write F
+//   --snapshot-every N  also write <model>.iter<k> after every N-th outer iteration
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -32,8 +35,29 @@ static void exit_with_help() {
         "    -p do_predict: compute training/testing error & NDCG at each iteration or not (default 1)\n"
         "    --f64 : keep U, V in fp64 on the GPU (default fp32 storage, fp64 accumulation)\n"
         "    --device id : GPU to use (default 0)\n"
-        "    --init-model file : warm start from a model file\n");
+        "    --init-model file : warm start from a model file\n"
+        "    --cache file : binary cache of the parsed data set (rebuilt when the text files change)\n"
+        "    --snapshot-every n : also write <model>.iter<k> after every n-th iteration\n");
     exit(1);
+}
+
+// --snapshot-every: the training loop hands every log line to this callback (same text as the default stdout logger);
+// after every n-th "Iter k ..." line the current factors are written to <model>.iter<k> in the model-file format.
+struct SnapCtx {
+    pcr_solver* s; int every; std::string model; int64_t d1, d2; int k;
+    std::vector<double>*U, *V; bool failed;
+};
+static void snap_log(void* vctx, const char* line) {
+    SnapCtx* c = static_cast<SnapCtx*>(vctx);
+    fputs(line, stdout); fputc('\n', stdout); fflush(stdout);
+    int it = 0;
+    if (c->every <= 0 || sscanf(line, "Iter %d time", &it) != 1 || it <= 0 || it % c->every != 0) return;
+    const std::string path = c->model + ".iter" + std::to_string(it);
+    if (pcr_solver_get_factors(c->s, c->U->data(), c->V->data()) != PCR_OK ||
+        pcr_model_save(path.c_str(), c->U->data(), c->d1, c->V->data(), c->d2, c->k) != PCR_OK) {
+        fprintf(stderr, "snapshot %s: %s\n", path.c_str(), pcr_last_error());
+        c->failed = true;
+    }
 }
 
 static void die(const char* what) {
@@ -44,7 +68,8 @@ static void die(const char* what) {
 int main(int argc, char** argv) {
     pcr_params param;
     pcr_params_default(&param);
-    std::string init_model;
+    std::string init_model, cache;
+    int snapshot_every = 0;
     int i;
     for (i = 1; i < argc; i++) {                       // pmf-train.cpp:36-108
         if (argv[i][0] != '-') break;
@@ -52,6 +77,8 @@ int main(int argc, char** argv) {
         if (++i >= argc) exit_with_help();
         if (!strcmp(argv[i - 1], "--device")) { param.device = atoi(argv[i]); continue; }
         if (!strcmp(argv[i - 1], "--init-model")) { init_model = argv[i]; continue; }
+        if (!strcmp(argv[i - 1], "--cache")) { cache = argv[i]; continue; }
+        if (!strcmp(argv[i - 1], "--snapshot-every")) { snapshot_every = atoi(argv[i]); continue; }
         switch (argv[i - 1][1]) {
             case 's': param.solver_type = atoi(argv[i]); break;
             case 'k': param.k = atoi(argv[i]); break;
@@ -87,7 +114,8 @@ int main(int argc, char** argv) {
     fclose(fp);
 
     pcr_dataset* ds = nullptr;
-    if (pcr_dataset_load_mt(input.c_str(), param.threads, &ds) != PCR_OK) die("load");
+    if ((cache.empty() ? pcr_dataset_load_mt(input.c_str(), param.threads, &ds)
+                       : pcr_dataset_load_cached(input.c_str(), param.threads, cache.c_str(), &ds)) != PCR_OK) die("load");
     int64_t d1, d2, nnz, tnnz;
     pcr_dataset_dims(ds, &d1, &d2, &nnz, &tnnz);
     const int k = param.k;
@@ -113,7 +141,9 @@ int main(int argc, char** argv) {
     pcr_solver* s = nullptr;
     if (pcr_solver_create(ds, &param, 0, 1, &s) != PCR_OK) die("solver");
     if (pcr_solver_set_factors(s, U.data(), V.data()) != PCR_OK) die("set_factors");
-    if (pcr_train(s, nullptr, nullptr, nullptr) != PCR_OK) die("train");
+    SnapCtx snap{s, snapshot_every, model, d1, d2, k, &U, &V, false};
+    if (pcr_train(s, snapshot_every > 0 ? snap_log : nullptr, &snap, nullptr) != PCR_OK) die("train");
+    if (snap.failed) return 1;
     if (pcr_solver_get_factors(s, U.data(), V.data()) != PCR_OK) die("get_factors");
     printf("Wall-time: %lg secs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 

@@ -11,9 +11,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <numeric>
 #include <random>
 #include <thread>
+#include <sys/stat.h>
 
 static thread_local std::string g_err;
 void pcr_set_error(const std::string& msg) { g_err = msg; }
@@ -290,6 +292,92 @@ extern "C" int pcr_dataset_load_mt(const char* dir, int threads, pcr_dataset** o
         tnnz = 0;
     }
     return pcr_dataset_from_triplets(m, n, nnz, u.data(), i.data(), v.data(), tnnz, tu.data(), ti.data(), tv.data(), out);
+}
+
+// ---- binary side-car cache of the converted data set
+namespace {
+struct CacheHeader {
+    char magic[8];                 // "PCRCACH1"
+    int64_t d1, d2, nnz, tnnz, tnnz_file;
+    int64_t stamp[6];              // size, mtime (ns) of meta, training file, test file at the time of the parse (0: not recorded)
+};
+const char kCacheMagic[8] = {'P', 'C', 'R', 'C', 'A', 'C', 'H', '1'};
+
+bool file_stamp(const std::string& p, int64_t* size, int64_t* mtime) {
+    struct stat sb;
+    if (stat(p.c_str(), &sb) != 0) return false;
+    *size = (int64_t)sb.st_size;
+    *mtime = (int64_t)sb.st_mtim.tv_sec * 1000000000LL + (int64_t)sb.st_mtim.tv_nsec;
+    return true;
+}
+// stamps of <dir>/meta and the rating files it names; false if meta is unreadable
+bool dir_stamps(const std::string& d, int64_t stamp[6]) {
+    for (int i = 0; i < 6; ++i) stamp[i] = 0;
+    FILE* fp = fopen((d + "/meta").c_str(), "r");
+    if (!fp) return false;
+    long m = 0, n = 0, nnz = 0, tnnz = 0;
+    char name[1024], tname[1024];
+    const bool ok = fscanf(fp, "%ld %ld", &m, &n) == 2 && fscanf(fp, "%ld %1023s", &nnz, name) == 2;
+    const bool have_test = ok && fscanf(fp, "%ld %1023s", &tnnz, tname) == 2;
+    fclose(fp);
+    if (!ok || !file_stamp(d + "/meta", &stamp[0], &stamp[1]) || !file_stamp(d + "/" + name, &stamp[2], &stamp[3])) return false;
+    if (have_test && !file_stamp(d + "/" + tname, &stamp[4], &stamp[5])) return false;
+    return true;
+}
+template <class X> bool put(FILE* f, const std::vector<X>& v) { return v.empty() || fwrite(v.data(), sizeof(X), v.size(), f) == v.size(); }
+template <class X> bool get(FILE* f, std::vector<X>& v, size_t n) { v.resize(n); return n == 0 || fread(v.data(), sizeof(X), n, f) == n; }
+
+int save_cache(const pcr_dataset* ds, const char* path, const int64_t stamp[6]) {
+    if (!ds || !path) { pcr_set_error("pcr_dataset_save_cache: bad argument"); return PCR_ERR_ARG; }
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) { pcr_set_error("can't open " + tmp + ": " + strerror(errno)); return PCR_ERR_IO; }
+    CacheHeader h;
+    memcpy(h.magic, kCacheMagic, 8);
+    h.d1 = ds->train.d1; h.d2 = ds->train.d2; h.nnz = ds->train.nnz(); h.tnnz = ds->test.nnz(); h.tnnz_file = ds->tnnz_file;
+    for (int i = 0; i < 6; ++i) h.stamp[i] = stamp ? stamp[i] : 0;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && put(f, ds->train.index) && put(f, ds->train.item) && put(f, ds->train.val) &&
+              put(f, ds->test.index) && put(f, ds->test.item) && put(f, ds->test.val);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); pcr_set_error(std::string("can't write ") + path); return PCR_ERR_IO; }
+    return PCR_OK;
+}
+int load_cache(const char* path, const int64_t want[6], pcr_dataset** out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { pcr_set_error(std::string("can't open ") + path + ": " + strerror(errno)); return PCR_ERR_IO; }
+    CacheHeader h;
+    auto fail = [&](const char* why) { fclose(f); pcr_set_error(std::string(path) + ": " + why); return PCR_ERR_IO; };
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, kCacheMagic, 8) != 0) return fail("not a data set cache of this version");
+    if (h.d1 < 0 || h.d2 < 0 || h.nnz < 0 || h.tnnz < 0) return fail("corrupt header");
+    if (want) for (int i = 0; i < 6; ++i) if (h.stamp[i] != want[i]) return fail("stale (the text files changed)");
+    std::unique_ptr<pcr_dataset> ds(new pcr_dataset);
+    ds->train.d1 = ds->test.d1 = h.d1; ds->train.d2 = ds->test.d2 = h.d2; ds->tnnz_file = h.tnnz_file;
+    if (!get(f, ds->train.index, (size_t)h.d1 + 1) || !get(f, ds->train.item, (size_t)h.nnz) || !get(f, ds->train.val, (size_t)h.nnz) ||
+        !get(f, ds->test.index, (size_t)h.d1 + 1) || !get(f, ds->test.item, (size_t)h.tnnz) || !get(f, ds->test.val, (size_t)h.tnnz))
+        return fail("truncated");
+    if (ds->train.index.front() != 0 || ds->train.index.back() != h.nnz || ds->test.index.front() != 0 || ds->test.index.back() != h.tnnz)
+        return fail("corrupt row pointers");
+    for (int32_t j : ds->train.item) if (j < 0 || j >= h.d2) return fail("item id out of range");
+    fclose(f);
+    *out = ds.release();
+    return PCR_OK;
+}
+}  // namespace
+
+extern "C" int pcr_dataset_save_cache(const pcr_dataset* ds, const char* path) { return save_cache(ds, path, nullptr); }
+extern "C" int pcr_dataset_load_cache(const char* path, pcr_dataset** out) {
+    if (!path || !out) { pcr_set_error("pcr_dataset_load_cache: bad argument"); return PCR_ERR_ARG; }
+    return load_cache(path, nullptr, out);
+}
+extern "C" int pcr_dataset_load_cached(const char* dir, int threads, const char* cache, pcr_dataset** out) {
+    if (!dir || !cache || !out) { pcr_set_error("pcr_dataset_load_cached: bad argument"); return PCR_ERR_ARG; }
+    int64_t stamp[6];
+    const bool have = dir_stamps(dir, stamp);
+    if (have && load_cache(cache, stamp, out) == PCR_OK) return PCR_OK;
+    int rc = pcr_dataset_load_mt(dir, threads, out);
+    if (rc != PCR_OK) return rc;
+    if (have) (void)save_cache(*out, cache, stamp);      // best effort: a read-only data directory is not an error
+    return PCR_OK;
 }
 
 extern "C" void pcr_dataset_free(pcr_dataset* ds) { delete ds; }

@@ -150,7 +150,18 @@ template <> struct LiOps<uint64_t> {
 // every sum computed from the order (the reference's std::sort is unstable too).
 // TIE = true additionally orders equal (level, key) by DESCENDING index (k_eval2: the lowest index then
 // sits at the end of its run and is taken first).
-template <typename T, typename LI, int BLOCK, bool TIE = false>
+// ordering point for LDS traffic that stays inside one wave (the LDS serves a wave's accesses in program order)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Compare-exchange network over LDS.  With stride j <= 64 the pairs a wave works on (64 consecutive t) lie in ITS OWN
+// aligned 128-element chunk, in every such stage alike, so between two short-stride stages a wave-level ordering point
+// replaces the workgroup barrier: of the 78 stages of a 4096-element sort only 21 need __syncthreads().
+// (INLDS = false: the arrays live in global scratch, every stage keeps the workgroup barrier.)
+template <typename T, typename LI, int BLOCK, bool TIE = false, bool INLDS = true>
 __device__ __forceinline__ void bitonic_sort(T* key, LI* li, int npad) {
     const int tid = threadIdx.x;
     for (int k = 2; k <= npad; k <<= 1) {
@@ -171,7 +182,9 @@ __device__ __forceinline__ void bitonic_sort(T* key, LI* li, int npad) {
                 bool sw = up ? b_lt_a : a_lt_b;
                 if (sw) { key[i] = kb; key[l] = ka; li[i] = lb; li[l] = la; }
             }
-            __syncthreads();
+            const int jnext = j > 1 ? (j >> 1) : k;                 // stride of the next stage (first stage of the next phase: k)
+            const bool last = (j == 1 && k == npad);
+            if (INLDS && !last && j <= 64 && jnext <= 64) wave_sync(); else __syncthreads();
         }
     }
 }
@@ -638,6 +651,12 @@ static inline size_t prepare_bytes(int cap, int cap_pad, int rs_cap, int li_byte
     return carve_bytes(cap_pad, sizeof(T)) + carve_bytes(cap_pad, li_bytes) + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
 }
 
+#ifdef PCR_PREP_PROF
+__device__ unsigned long long g_prep_prof[4 * 8];
+#define PPROF(ph) do { if (threadIdx.x == 0) { const long long now_ = clock64(); pp_[ph] += now_ - pt_; pt_ = now_; } } while (0)
+#else
+#define PPROF(ph) do { } while (0)
+#endif
 template <typename T, int BLOCK, bool BIG>
 __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                    const T* __restrict__ m_in,
@@ -652,6 +671,9 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const in
     double* Sx = big.take<double>(cap + 1);
     int* rs = big.take<int>(rs_cap);
     const int tid = threadIdx.x;
+#ifdef PCR_PREP_PROF
+    long long pp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_ = clock64();
+#endif
 
     for (int ui = blockIdx.x; ui < nusers; ui += gridDim.x) {
         const int u = users[ui];
@@ -669,7 +691,9 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const in
             else { li[p] = LiOps<LI>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
         }
         __syncthreads();
-        bitonic_sort<T, LI, BLOCK>(key, li, npad);
+        PPROF(0);
+        bitonic_sort<T, LI, BLOCK, false, !BIG>(key, li, npad);
+        PPROF(1);
         for (int p = tid; p < n; p += BLOCK) {
             const LI x = li[p];
             const unsigned idx = LiOps<LI>::idx(x);
@@ -680,18 +704,28 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const in
             S.scpos[s0 + p] = e;
             S.cinv[e] = (int32_t)(s0 + p);
         }
+        PPROF(2);
         double loss;
         if (S.ws) {
             uint32_t* win = S.win + (size_t)s0 * S.ws;
             for (int p = tid; p < n; p += BLOCK)
                 find_windows<T>(key, rs, nlev, (int)LiOps<LI>::lev(li[p]), key[p], strict, win + (size_t)p * S.ws);
+            PPROF(3);
             loss = block_objective_win<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, win, S.ws, Sx, red);
         } else {
             loss = block_objective<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, Sx, red, strict);
         }
         if (tid == 0) S.objp[u] = loss;
         __syncthreads();
+        PPROF(4);
     }
+#ifdef PCR_PREP_PROF
+    if (threadIdx.x == 0) {
+        const int cls = BLOCK == 64 ? 0 : BLOCK == 256 ? 1 : BIG ? 3 : 2;
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_prep_prof[cls * 8 + i], (unsigned long long)pp_[i]);
+        atomicAdd(&g_prep_prof[cls * 8 + 7], 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -756,11 +790,6 @@ __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int
 // k_vsweep for short users (<= 256 ratings), ONE WAVE PER USER, four users per 256-thread
 // workgroup: no workgroup barriers at all (LDS traffic stays inside a wave, which the LDS serves
 // in program order), so the many short users of a rating set do not pay a block's fixed cost each.
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 template <typename T>
 static inline size_t vsweep_wave_bytes(int cap, int rs_cap) {      // per wave
     return carve_bytes(cap, sizeof(T)) * 2 + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
@@ -1420,7 +1449,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                     else { li[p] = LiOps<LI>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
                 }
                 __syncthreads();
-                bitonic_sort<T, LI, BLOCK>(key, li, npad);                      // update_infor_ui (:684-726)
+                bitonic_sort<T, LI, BLOCK, false, !BIG>(key, li, npad);         // update_infor_ui (:684-726)
                 UPROF(8);
                 loss_new = block_objective<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, Sx, red, strict);
                 obj_new = lambda / 2.0 * nn + loss_new;

@@ -206,6 +206,22 @@ struct Solver final : pcr_solver {
 
     ~Solver() override {
         if (st) (void)hipStreamSynchronize(st);
+#ifdef PCR_PREP_PROF
+        {   // developer build: per-phase shader clocks of thread 0 of every k_prepare workgroup, by class
+            unsigned long long h[32];
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prep_prof), sizeof(h)) == hipSuccess) {
+                static const char* ph[] = {"load", "sort", "write", "windows", "loss"};
+                static const char* cl[] = {"64", "256", "512", "512g"};
+                for (int c = 0; c < 4; ++c) {
+                    if (!h[c * 8 + 7]) continue;
+                    double tot = 0; for (int i = 0; i < 5; ++i) tot += (double)h[c * 8 + i];
+                    fprintf(stderr, "prep-prof %-5s wgs %8llu kclk/wg %8.1f :", cl[c], h[c * 8 + 7], tot / 1000.0 / h[c * 8 + 7]);
+                    for (int i = 0; i < 5; ++i) fprintf(stderr, " %s %.1f%%", ph[i], 100.0 * h[c * 8 + i] / tot);
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
+#endif
         prof_resolve();
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         if (comm) ncclCommDestroy(comm);

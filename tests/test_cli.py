@@ -27,7 +27,7 @@ def run(cmd, cwd):
 def test_usage_and_exit_codes(tmp_path):
     r = run([TRAIN], tmp_path)                                    # pmf-train.cpp:115-116
     assert r.returncode == 1 and r.stdout.startswith("Usage: omp-pmf-train [options] data_dir [model_filename]")
-    for flag in ("-s type", "-k rank", "-n threads", "-l lambda", "-t max_iter", "-p do_predict"):
+    for flag in ("-s type", "-k rank", "-n threads", "-l lambda", "-t max_iter", "-p do_predict", "--cache file", "--snapshot-every n"):
         assert flag in r.stdout
     r = run([TRAIN, "-z", "3", "dir"], tmp_path)                  # pmf-train.cpp:104-107
     assert r.returncode == 1 and "unknown option: -z" in r.stderr
@@ -124,3 +124,23 @@ def test_warm_start_continues_the_trajectory(tmp_path):
     assert a.shape == b.shape and np.nanmax(np.abs(a[2:] - b[2:])) < 1e-9 * np.nanmax(np.abs(a[2:]))
     bad = run(base + ["-k", "3", "-t", "1", "--init-model", "m2.model", d, "x.model"], tmp_path)
     assert bad.returncode == 1 and "expected" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_cache_and_snapshots(tmp_path):
+    """SURVEY 8f-2 / 8f-4: --cache gives the same run as the text parse (first call writes it, second reads it);
+    --snapshot-every 2 writes <model>.iter2 = the model of a -t 2 run, .iter4 = the final model."""
+    g, meta, d = golden_dir("mid5", tmp_path)
+    base = [TRAIN, "-k", str(int(g["r"])), "-l", repr(float(g["lam"])), "-p", "0", "--f64"]
+    cache = str(tmp_path / "mid5.cache")
+    plain = run(base + ["-t", "2", d, "plain.model"], tmp_path)
+    first = run(base + ["-t", "2", "--cache", cache, d, "c1.model"], tmp_path)
+    assert plain.returncode == 0 and first.returncode == 0 and os.path.exists(cache)
+    second = run(base + ["-t", "4", "--cache", cache, "--snapshot-every", "2", d, "c2.model"], tmp_path)
+    assert second.returncode == 0, second.stderr
+    rd = lambda n: open(tmp_path / n, "rb").read()
+    assert rd("plain.model") == rd("c1.model") == rd("c2.model.iter2")
+    assert rd("c2.model.iter4") == rd("c2.model")
+    assert not (tmp_path / "c2.model.iter1").exists() and not (tmp_path / "c2.model.iter3").exists()
+    iters = lambda s: [re.sub(r"time \S+", "time T", l) for l in s.split("\n") if l.startswith("Iter ")]
+    assert iters(plain.stdout) == iters(first.stdout) == iters(second.stdout)[:3]

@@ -95,3 +95,47 @@ def test_training_entry_points_fail_loudly_without_gpu():
     ds = pcr.Dataset.from_ratings(synth.generate("tiny"))
     with pytest.raises(pcr.PcrError, match="(?i)no HIP device|hip"):
         pcr.Solver(ds, pcr.Parameter())
+
+
+def test_dataset_cache_roundtrip_and_staleness(tmp_path):
+    """the binary side-car holds exactly what load() + convert() produce, is rebuilt when a text file
+    changes, and a corrupt / truncated file is an error for load_cache and a silent re-parse for load(cache=...)."""
+    import time
+    R = synth.generate("small")
+    d = synth.write_dir(R, str(tmp_path / "data"))
+    cache = str(tmp_path / "data.pcrcache")
+    a = pcr.Dataset.load(d)
+    b = pcr.Dataset.load(d, cache=cache)                      # parses the text, writes the cache
+    assert os.path.exists(cache)
+    c = pcr.Dataset.load(d, cache=cache)                      # reads the cache
+    e = pcr.Dataset.load_cache(cache)
+    for w in (0, 1):
+        ref = a.csr(w)
+        for other in (b, c, e):
+            got = other.csr(w)
+            assert all(np.array_equal(x, y) for x, y in zip(ref, got))
+    assert a.dims() == c.dims() == e.dims()
+    # a changed rating file invalidates the cache: flip one rating, keep the byte count
+    p = os.path.join(d, "training.ratings")
+    lines = open(p).read().split("\n")
+    u, i, v = lines[0].split()
+    lines[0] = f"{u} {i} {1 if v != '1' else 2}"
+    time.sleep(0.01)
+    open(p, "w").write("\n".join(lines))
+    f = pcr.Dataset.load(d, cache=cache)
+    g = pcr.Dataset.load(d)
+    assert all(np.array_equal(x, y) for x, y in zip(f.csr(0), g.csr(0)))
+    assert not np.array_equal(f.csr(0)[2], a.csr(0)[2])
+    # explicit save + corrupt / truncated files
+    a.save_cache(str(tmp_path / "explicit.cache"))
+    assert all(np.array_equal(x, y) for x, y in zip(pcr.Dataset.load_cache(str(tmp_path / "explicit.cache")).csr(0), a.csr(0)))
+    raw = open(cache, "rb").read()
+    open(tmp_path / "trunc.cache", "wb").write(raw[: len(raw) // 2])
+    open(tmp_path / "magic.cache", "wb").write(b"XXXXXXXX" + raw[8:])
+    for bad in ("trunc.cache", "magic.cache", "missing.cache"):
+        with pytest.raises(pcr.PcrError):
+            pcr.Dataset.load_cache(str(tmp_path / bad))
+    open(cache, "wb").write(raw[: len(raw) // 2])             # load(cache=...) falls back to the text and repairs the cache
+    h = pcr.Dataset.load(d, cache=cache)
+    assert all(np.array_equal(x, y) for x, y in zip(h.csr(0), g.csr(0)))
+    assert len(open(cache, "rb").read()) == len(raw)
