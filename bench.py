@@ -117,9 +117,18 @@ def host_cores():
 
 
 def cpu_baseline(R, n_pairs, r, lam):
-    """Reference OpenMP path on this host (kind "reference"), else the C restatement (kind "port")."""
+    """Reference OpenMP path on this host (kind "reference"), else the C restatement (kind "port").
+    Bounded: data sets beyond 2 M ratings are timed on a prefix of their users (same shape, fewer users)."""
     from oracle import oracle_py
     cores = host_cores()
+    sample_note = "the full data set"
+    if R.nnz > 2_000_000:
+        from primalcr_amd import synth
+        nu = int(R.user[2_000_000])                 # whole users within the first 2 M ratings (triplets are user-sorted)
+        keep, tkeep = R.user < nu, R.tuser < nu
+        R = synth.Ratings(nu, R.d2, R.user[keep], R.item[keep], R.val[keep], R.tuser[tkeep], R.titem[tkeep], R.tval[tkeep])
+        n_pairs = synth.count_pairs(R)
+        sample_note = f"its first {nu} users ({R.nnz} ratings, {n_pairs} ordered pairs)"
     if os.path.exists(oracle_py.REF_TRAIN):
         from primalcr_amd import synth
         iters = 2
@@ -134,7 +143,7 @@ def cpu_baseline(R, n_pairs, r, lam):
         secs = times[-1]
         log(f"[cpu_baseline] reference omp-pmf-train -n {cores}: {secs:.2f}s for {iters} iterations (wall {wall:.1f}s)")
         return {"value": n_pairs * iters / secs, "unit": "pairs/s", "cores": cores, "kind": "reference",
-                "sample": f"omp-pmf-train -s 2 -k {r} -l {lam:g} -t {iters} -p 0 -n {cores} on the full ml1m-shaped set; "
+                "sample": f"omp-pmf-train -s 2 -k {r} -l {lam:g} -t {iters} -p 0 -n {cores} on {sample_note}; "
                           f"'Iter {iters} time' = {secs:.3f} s", "s_per_iter": secs / iters}
     orc = oracle_py.Oracle()
     nu = 400
@@ -153,6 +162,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--shape", choices=["ml1m", "netflix"], default="ml1m",
+                    help="ml1m: configs[1], 6040 users per GPU (weak scaling); netflix: configs[3], 480189 x 17770, 100 M "
+                         "ratings in total, user-sharded over the GPUs (strong scaling; generating it takes minutes per rank)")
+    ap.add_argument("--users", type=int, default=None, help="override the user count of the shape (total for netflix, per GPU for ml1m)")
+    ap.add_argument("--nnz", type=int, default=None, help="override the rating count likewise")
     ap.add_argument("--rank-k", type=int, default=100, help="factor rank (BASELINE: 100)")
     ap.add_argument("--lam", type=float, default=5000.0)
     ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
@@ -183,11 +197,16 @@ def main():
 
     r, lam = args.rank_k, args.lam
     t0 = time.time()
-    R = synth.generate("ml1m", d1=USERS_PER_GPU * N, nnz=NNZ_PER_GPU * N)
+    if args.shape == "ml1m":
+        R = synth.generate("ml1m", d1=(args.users or USERS_PER_GPU) * N, nnz=(args.nnz or NNZ_PER_GPU) * N)
+        scaling, shape_note = "weak", f"ml1m-shaped PrimalCR++ -k {r} -l {lam:g} (configs[1])"
+    else:
+        R = synth.generate("netflix", d1=args.users, nnz=args.nnz)
+        scaling, shape_note = "strong", f"Netflix-shaped PrimalCR++ -k {r} -l {lam:g} (configs[3])"
     ds = pcr.Dataset.from_ratings(R)
     n_pairs = ds.count_pairs()
     if rank == 0:
-        log(f"[data] ml1m-shaped x{N}: {R.d1} users x {R.d2} items, {R.nnz} ratings, {n_pairs} ordered pairs, "
+        log(f"[data] {args.shape}-shaped x{N}: {R.d1} users x {R.d2} items, {R.nnz} ratings, {n_pairs} ordered pairs, "
             f"{len(R.tuser)} test ratings ({time.time() - t0:.1f}s)")
     prec = pcr.PCR_F32 if args.precision == "f32" else pcr.PCR_F64
     p = pcr.Parameter(k=r, precision=prec, device=local_rank, do_predict=0, maxiter=1, **{"lambda": lam})
@@ -242,8 +261,8 @@ def main():
         esz = 4 if prec == pcr.PCR_F32 else 8
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")      # PMC passes of this command (tools/pmc_traffic.py)
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath))
+        if os.path.exists(tpath) and args.shape == "ml1m" and not args.users and not args.nnz and r == 100 and N == 1:
+            traffic = json.load(open(tpath))      # the PMC passes were taken on exactly this workload
         # Share of the timed region.  The length bins of k_prepare / k_ustep run CONCURRENTLY on side streams, so the
         # sum of their durations overstates their part of the wall clock: the fork..join wall time of each group
         # ("wall:<class>" slots, timed on the solver's stream) is attributed to its bins in proportion to their
@@ -302,9 +321,9 @@ def main():
     value = n_pairs * args.steps / secs
     out = {
         "metric": "pairwise-comparisons/sec", "value": value, "unit": "pairs/s", "n_gpus": N, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps, "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f32" if prec == pcr.PCR_F32 else "f64", "data": "synthetic",
-        "config": {"workload": f"ml1m-shaped PrimalCR++ -k {r} -l {lam:g} (configs[1]); {R.d1} users x {R.d2} items, "
+        "config": {"workload": f"{shape_note}; {R.d1} users x {R.d2} items, "
                                f"{R.nnz} ratings, {n_pairs} ordered pairs; 1 step = 1 outer iteration (V step + U step)",
                    "solver": "PrimalCR++", "rank": r, "lambda": lam, "parallelism": f"user-sharded x{N}",
                    "accumulation": "f64"},

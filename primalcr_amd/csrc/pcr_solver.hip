@@ -494,7 +494,7 @@ struct Solver final : pcr_solver {
         // users (Netflix-shaped data) is bound by how busy each CU's memory pipe stays: smaller / leaner workgroups, so that
         // two share a CU and one gathers while the other scans or sorts (<= 1024 ratings: 256 threads; above: 512 threads
         // at 4 rows in flight = 128 VGPRs, and a class boundary at 2048 so that the per-rating arrays of two fit the LDS).
-        static const int force_mode = getenv("PCR_USTEP_MODE") ? atoi(getenv("PCR_USTEP_MODE")) : 0;   // 1 latency, 2 throughput
+        const int force_mode = getenv("PCR_USTEP_MODE") ? atoi(getenv("PCR_USTEP_MODE")) : 0;   // developer / test knob: 1 latency, 2 throughput
         auto many = [&](int64_t users) { return force_mode ? force_mode == 2 : users > 2 * (int64_t)ncu; };
         int64_t n_mid = 0;
         for (int64_t u = 0; u < nu; ++u) { const int64_t len = uptr[u + 1] - uptr[u]; n_mid += len > 1024 && len <= 4096; }

@@ -243,3 +243,91 @@ def test_fp32_training_matches_reference_quality(oracle):
         for key in ("train_err", "train_ndcg", "test_err", "test_ndcg"):
             assert abs(a[key] - b[key]) < 1e-3, (key, a[key], b[key])
     assert [a["cg_v"] for a in recs] == [b["cg_v"] for b in ref]
+
+
+def _mixed_set(seed=11, d1=700, d2=6000):
+    rng = np.random.default_rng(seed)
+    lens = np.concatenate([[0, 1, 2, 5000, 4500, 4097, 4096, 3000, 2049, 2048, 1500, 1025, 1024, 700, 513, 512, 300, 257, 256, 129, 128, 65, 64, 33, 32],
+                           np.clip(rng.lognormal(4.0, 1.0, d1 - 25).astype(np.int64), 3, 900)])
+    user = np.repeat(np.arange(d1), lens)
+    item = np.concatenate([rng.choice(d2, n, replace=False) for n in lens])
+    val = rng.integers(1, 6, user.shape[0]).astype(np.float64)
+    return d1, d2, user, item, val
+
+
+VARIANTS = [
+    {},                                                          # default launch configuration
+    {"PCR_USTEP_MODE": "2"},                                     # throughput variants: 256 threads / 512 threads at 4 rows in flight
+    {"PCR_USTEP_MODE": "1"},                                     # latency variants everywhere
+    {"PCR_CLUSTER_K": "1"},                                      # no workgroup clusters
+    {"PCR_UBINS": "64:64:0,512:256:0"},                          # no LDS-resident rows, coarser classes
+    {"PCR_UBINS": "16:64:1,48:64:1,200:256:0,700:256:0"},        # other class bounds
+    {"PCR_SPMM_TILES": "5"}, {"PCR_SPMM_TILES": "16"}, {"PCR_SPMM_TILES": "64"},   # user tiles of the SpMM (incl. more tiles than XCDs)
+    {"PCR_LANES": "1"},                                          # every class on the solver's stream
+]
+
+
+def test_launch_variants_agree(oracle, monkeypatch):
+    """The length classes, workgroup variants, cluster size, SpMM tiling and stream placement are scheduling choices:
+    two outer iterations in fp64 must give the same factors and objectives under every one of them (to summation-order
+    rounding), and the first U step must match the oracle."""
+    d1, d2, user, item, val = _mixed_set()
+    r, lam = 12, 30.0
+    X = oracle.build_csr(d1, d2, user, item, val)
+    U0 = oracle.initial(d1, r) * 0.3; V0 = oracle.initial(d2, r) * 0.3
+    ds = pcr.Dataset.from_triplets(d1, d2, user, item, val)
+    results = []
+    for env in VARIANTS:
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            s = pcr.Solver(ds, pcr.Parameter(k=r, precision=pcr.PCR_F64, **{"lambda": lam}))
+        s.set_factors(U0, V0)
+        objs = []
+        for _ in range(2):
+            oV, iv = s.update_V(); oU, iu = s.update_U()
+            objs += [oV, oU, iv["cg"], iv["ls"], iu["cg"], iu["ls"]]
+        U, V = s.get_factors()
+        results.append((env, np.array(objs), U, V))
+    _, o0, U_ref, V_ref = results[0]
+    for env, o, U, V in results[1:]:
+        assert np.allclose(o, o0, rtol=1e-10, atol=0), (env, o, o0)
+        assert rel(U, U_ref) < 1e-8 and rel(V, V_ref) < 1e-8, env
+    # oracle: V step then U step from the same start
+    m0 = oracle.comp_m(U0, V0, X)
+    V1, m1, objV, info_v = oracle.update_V_new(X, lam, 1.0, U0, V0)
+    U1, objU, info_u = oracle.update_U_new(X, m1, lam, 1.0, V1, U0)
+    s = pcr.Solver(ds, pcr.Parameter(k=r, precision=pcr.PCR_F64, **{"lambda": lam}))
+    s.set_factors(U0, V0)
+    oV, _ = s.update_V(); oU, iu = s.update_U()
+    Ug, Vg = s.get_factors()
+    assert abs(oV / objV - 1) < 1e-9 and abs(oU / objU - 1) < 1e-9
+    assert rel(Vg, V1) < 1e-7 and rel(Ug, U1) < 1e-7
+    assert iu["cg"] == info_u["cg"] and iu["ls"] == info_u["ls"]
+
+
+def test_state_left_by_u_step_equals_a_fresh_prepare(oracle):
+    """k_ustep leaves the sorted state of (U_new, V) behind and update_V starts from it (no SDDMM + sort of its own).
+    A second solver that is handed the same factors through set_factors must rebuild that state and take the same V step."""
+    d1, d2, user, item, val = _mixed_set(seed=12, d1=300)
+    r, lam = 10, 20.0
+    ds = pcr.Dataset.from_triplets(d1, d2, user, item, val)
+    U0 = oracle.initial(d1, r) * 0.3; V0 = oracle.initial(d2, r) * 0.3
+    for precision, tol in ((pcr.PCR_F64, 1e-9), (pcr.PCR_F32, 5e-4)):
+        a = pcr.Solver(ds, pcr.Parameter(k=r, precision=precision, **{"lambda": lam}))
+        a.set_factors(U0, V0)
+        a.update_V(); a.update_U()
+        U1, V1 = a.get_factors()
+        obj_state = a.objective()                    # from the state k_ustep left
+        gA = a.obtain_g()
+        oA, iA = a.update_V()
+        b = pcr.Solver(ds, pcr.Parameter(k=r, precision=precision, **{"lambda": lam}))
+        b.set_factors(U1, V1)
+        b.comp_m()                                   # fresh SDDMM + sort
+        assert abs(obj_state / b.objective() - 1) < tol * 1e-2
+        assert rel(gA, b.obtain_g()) < tol
+        oB, iB = b.update_V()
+        assert abs(oA / oB - 1) < tol * 1e-1
+        assert rel(a.get_factors()[1], b.get_factors()[1]) < tol * 10
+        if precision == pcr.PCR_F64:
+            assert iA == iB
