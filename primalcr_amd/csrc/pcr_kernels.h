@@ -78,6 +78,19 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// ordering point for LDS traffic that stays inside one wave (the LDS serves a wave's accesses in program order)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The per-user primitives below are written for a "team" of BLOCK threads.  BLOCK = 64 is one wave: its ordering points are
+// wave-level and its thread index is the lane, so a one-wave team runs unchanged as one of the eight independent waves of
+// a 512-thread workgroup (k_prepare_all, k_vsweep_all) as well as in a 64-thread workgroup of its own.
+template <int BLOCK> __device__ __forceinline__ void bsync() { if (BLOCK == PCR_WAVE) wave_sync(); else __syncthreads(); }
+template <int BLOCK> __device__ __forceinline__ int btid() { return BLOCK == PCR_WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x; }
+
 // total to every thread; red: LDS, >= BLOCK/64 doubles
 template <int BLOCK>
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -96,7 +109,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 // out[i] = sum_{q<i} f(q) for i in [0, n]; fp64; strided rounds keep LDS access conflict-free
 template <int BLOCK, class F>
 __device__ __forceinline__ void block_excl_scan(F f, double* out, int n, double* red) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = btid<BLOCK>(), lane = tid & 63, wid = tid >> 6;
     double carry = 0.0;
     for (int base = 0; base < n; base += BLOCK) {
         const int i = base + tid;
@@ -126,7 +139,7 @@ __device__ __forceinline__ void block_excl_scan(F f, double* out, int n, double*
         carry += total;
     }
     if (tid == 0) out[n] = carry;
-    __syncthreads();
+    bsync<BLOCK>();
 }
 
 // packed (level, index): LDS-resident users use 32 bits (level<<16 | idx), users that live in
@@ -150,20 +163,13 @@ template <> struct LiOps<uint64_t> {
 // every sum computed from the order (the reference's std::sort is unstable too).
 // TIE = true additionally orders equal (level, key) by DESCENDING index (k_eval2: the lowest index then
 // sits at the end of its run and is taken first).
-// ordering point for LDS traffic that stays inside one wave (the LDS serves a wave's accesses in program order)
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // Compare-exchange network over LDS.  With stride j <= 64 the pairs a wave works on (64 consecutive t) lie in ITS OWN
 // aligned 128-element chunk, in every such stage alike, so between two short-stride stages a wave-level ordering point
 // replaces the workgroup barrier: of the 78 stages of a 4096-element sort only 21 need __syncthreads().
 // (INLDS = false: the arrays live in global scratch, every stage keeps the workgroup barrier.)
 template <typename T, typename LI, int BLOCK, bool TIE = false, bool INLDS = true>
 __device__ __forceinline__ void bitonic_sort(T* key, LI* li, int npad) {
-    const int tid = threadIdx.x;
+    const int tid = btid<BLOCK>();
     for (int k = 2; k <= npad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = tid; t < (npad >> 1); t += BLOCK) {
@@ -184,7 +190,7 @@ __device__ __forceinline__ void bitonic_sort(T* key, LI* li, int npad) {
             }
             const int jnext = j > 1 ? (j >> 1) : k;                 // stride of the next stage (first stage of the next phase: k)
             const bool last = (j == 1 && k == npad);
-            if (INLDS && !last && j <= 64 && jnext <= 64) wave_sync(); else __syncthreads();
+            if (INLDS && !last && j <= 64 && jnext <= 64) wave_sync(); else bsync<BLOCK>();
         }
     }
 }
@@ -256,7 +262,7 @@ __device__ __forceinline__ double sweep_coeff_win(const uint32_t* __restrict__ w
 template <typename T, int BLOCK, class LevF>
 __device__ __forceinline__ double block_objective_win(const T* ms, LevF levf, const int* rs, int nlev, int n,
                                                       const uint32_t* __restrict__ win, int ws, double* S, double* red) {
-    const int tid = threadIdx.x;
+    const int tid = btid<BLOCK>();
     double part = 0.0;
     block_excl_scan<BLOCK>([&](int i) { return (double)ms[i] - 1.0; }, S, n, red);
     for (int p = tid; p < n; p += BLOCK) {
@@ -268,14 +274,14 @@ __device__ __forceinline__ double block_objective_win(const T* ms, LevF levf, co
             part += (double)(wi - s0) * m * m - 2.0 * m * (S[wi] - S[s0]);
         }
     }
-    __syncthreads();
+    bsync<BLOCK>();
     block_excl_scan<BLOCK>([&](int i) { double d = (double)ms[i] - 1.0; return d * d; }, S, n, red);
     for (int p = tid; p < n; p += BLOCK) {
         const int lev = levf(p);
         const uint32_t* w = win + (size_t)p * ws;
         for (int l = lev + 1; l < nlev; ++l) part += S[w[l - 1]] - S[rs[l]];
     }
-    __syncthreads();
+    bsync<BLOCK>();
     return block_sum<BLOCK>(part, red);
 }
 
@@ -285,7 +291,7 @@ __device__ __forceinline__ double block_objective_win(const T* ms, LevF levf, co
 template <typename T, int BLOCK, class LevF>
 __device__ __forceinline__ double block_objective(const T* ms, LevF levf, const int* rs, int nlev, int n,
                                                   double* S, double* red, int strict) {
-    const int tid = threadIdx.x;
+    const int tid = btid<BLOCK>();
     double part = 0.0;
     block_excl_scan<BLOCK>([&](int i) { return (double)ms[i] - 1.0; }, S, n, red);
     for (int p = tid; p < n; p += BLOCK) {
@@ -299,7 +305,7 @@ __device__ __forceinline__ double block_objective(const T* ms, LevF levf, const 
             part += (double)(w - s) * m * m - 2.0 * m * (S[w] - S[s]);
         }
     }
-    __syncthreads();
+    bsync<BLOCK>();
     block_excl_scan<BLOCK>([&](int i) { double d = (double)ms[i] - 1.0; return d * d; }, S, n, red);
     for (int p = tid; p < n; p += BLOCK) {
         const int lev = levf(p);
@@ -310,7 +316,7 @@ __device__ __forceinline__ double block_objective(const T* ms, LevF levf, const 
             part += S[w] - S[s];
         }
     }
-    __syncthreads();
+    bsync<BLOCK>();
     return block_sum<BLOCK>(part, red);
 }
 
@@ -657,25 +663,25 @@ __device__ unsigned long long g_prep_prof[4 * 8];
 #else
 #define PPROF(ph) do { } while (0)
 #endif
+// body of k_prepare for a team of BLOCK threads (smem: the team's LDS): team `first` of `step` walks users first, first + step, ...
 template <typename T, int BLOCK, bool BIG>
-__global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
-                                                   const T* __restrict__ m_in,
-                                                   int cap, int cap_pad, int rs_cap, char* scratch, size_t stride, int strict) {
+__device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, const int32_t* __restrict__ users, int nusers,
+                                             const T* __restrict__ m_in, int cap, int cap_pad, int rs_cap, char* scratch,
+                                             size_t stride, int strict, int first, int step) {
     typedef typename LiSel<T, BIG>::type LI;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     Carver small(smem);
     double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
-    Carver big(BIG ? scratch + (size_t)blockIdx.x * stride : small.p);
+    Carver big(BIG ? scratch + (size_t)first * stride : small.p);
     T* key = big.take<T>(cap_pad);
     LI* li = big.take<LI>(cap_pad);
     double* Sx = big.take<double>(cap + 1);
     int* rs = big.take<int>(rs_cap);
-    const int tid = threadIdx.x;
+    const int tid = btid<BLOCK>();
 #ifdef PCR_PREP_PROF
     long long pp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_ = clock64();
 #endif
 
-    for (int ui = blockIdx.x; ui < nusers; ui += gridDim.x) {
+    for (int ui = first; ui < nusers; ui += step) {
         const int u = users[ui];
         const int64_t s0 = S.uptr[u];
         const int n = (int)(S.uptr[u + 1] - s0);
@@ -690,7 +696,7 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const in
             if (p < n) { li[p] = LiOps<LI>::pack(S.lvl[s0 + p], (unsigned)p); key[p] = m_in[s0 + p]; }
             else { li[p] = LiOps<LI>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
         }
-        __syncthreads();
+        bsync<BLOCK>();
         PPROF(0);
         bitonic_sort<T, LI, BLOCK, false, !BIG>(key, li, npad);
         PPROF(1);
@@ -716,16 +722,42 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const in
             loss = block_objective<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, Sx, red, strict);
         }
         if (tid == 0) S.objp[u] = loss;
-        __syncthreads();
+        bsync<BLOCK>();
         PPROF(4);
     }
 #ifdef PCR_PREP_PROF
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         const int cls = BLOCK == 64 ? 0 : BLOCK == 256 ? 1 : BIG ? 3 : 2;
         for (int i = 0; i < 5; ++i) atomicAdd(&g_prep_prof[cls * 8 + i], (unsigned long long)pp_[i]);
         atomicAdd(&g_prep_prof[cls * 8 + 7], 1ull);
     }
 #endif
+}
+template <typename T, int BLOCK, bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
+                                                   const T* __restrict__ m_in,
+                                                   int cap, int cap_pad, int rs_cap, char* scratch, size_t stride, int strict) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    prepare_body<T, BLOCK, BIG>(smem, S, users, nusers, m_in, cap, cap_pad, rs_cap, scratch, stride, strict, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Both LDS-resident classes in ONE launch of 512-thread workgroups: workgroups [0, nblk_b) take the long users of list B
+// one per workgroup, the others eight short users of list A each, one per wave (a one-wave team needs no workgroup
+// barrier).  One launch instead of one per class on concurrent streams: no fork / join around the line search.
+template <typename T>
+__global__ __launch_bounds__(512) void k_prepare_all(Shard<T> S, const int32_t* __restrict__ users_a, int nusers_a, int cap_a,
+                                                     int cap_pad_a, int rs_cap_a, size_t wave_bytes,
+                                                     const int32_t* __restrict__ users_b, int nusers_b, int cap_b, int cap_pad_b,
+                                                     int rs_cap_b, int nblk_b, const T* __restrict__ m_in, int strict) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < nblk_b)
+        prepare_body<T, 512, false>(smem, S, users_b, nusers_b, m_in, cap_b, cap_pad_b, rs_cap_b, nullptr, 0, strict,
+                                    (int)blockIdx.x, nblk_b);
+    else
+        prepare_body<T, 64, false>(smem + (size_t)(threadIdx.x >> 6) * wave_bytes, S, users_a, nusers_a, m_in, cap_a, cap_pad_a,
+                                   rs_cap_a, nullptr, 0, strict, ((int)blockIdx.x - nblk_b) * 8 + (int)(threadIdx.x >> 6),
+                                   ((int)gridDim.x - nblk_b) * 8);
+
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1708,6 +1740,26 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_sum4_stage1(const double* __re
         const double s = block_sum<PCR_EW_BLOCK>(a[c], red);
         if (threadIdx.x == 0) part[4 * blockIdx.x + c] = s;
     }
+}
+// the three sums of an objective in one pass: sum(objx[0..nx)), |a|^2 over na elements, |b|^2 over nb (b may be null);
+// block-sliced partials part[blk][4] for k_fin4 (deterministic two-stage sums, as k_sum_stage1 / k_dots)
+template <typename T>
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_obj3(const double* __restrict__ objx, int64_t nx, const T* __restrict__ a, int64_t na,
+                                                        const T* __restrict__ b, int64_t nb, double* __restrict__ part) {
+    __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
+    const int64_t G = gridDim.x, blk = blockIdx.x;
+    double s[3] = {0.0, 0.0, 0.0};
+    { const int64_t per = (nx + G - 1) / G, lo = blk * per, hi = lo + per < nx ? lo + per : nx;
+      for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) s[0] += objx[i]; }
+    { const int64_t per = (na + G - 1) / G, lo = blk * per, hi = lo + per < na ? lo + per : na;
+      for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) { const double v = (double)a[i]; s[1] += v * v; } }
+    if (b) { const int64_t per = (nb + G - 1) / G, lo = blk * per, hi = lo + per < nb ? lo + per : nb;
+      for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) { const double v = (double)b[i]; s[2] += v * v; } }
+    for (int c = 0; c < 3; ++c) {
+        const double t = block_sum<PCR_EW_BLOCK>(s[c], red);
+        if (threadIdx.x == 0) part[4 * blk + c] = t;
+    }
+    if (threadIdx.x == 0) part[4 * blk + 3] = 0.0;
 }
 __global__ __launch_bounds__(PCR_EW_BLOCK) void k_fin4(const double* __restrict__ part, int nblk, double* __restrict__ out) {
     __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];

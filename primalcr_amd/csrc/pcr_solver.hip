@@ -661,6 +661,7 @@ struct Solver final : pcr_solver {
     int set_lds_limits() {
         const int lim = 160 * 1024;
         HIPCHK(hipFuncSetAttribute((const void*)k_prepare<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_prepare_all<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 512, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 512, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -797,6 +798,10 @@ struct Solver final : pcr_solver {
         return PCR_OK;
     }
 
+    bool prepare_is_single_launch() const {
+        static const int merged = getenv("PCR_PREPARE_MERGED") ? atoi(getenv("PCR_PREPARE_MERGED")) : 1;     // developer knob
+        return merged && !sbins[0].users.empty() && !sbins[1].users.empty();
+    }
     int launch_prepare(const T* Vm) {
         RC(launch_sddmm(Vm, d_item.p, d_mcsr.p));
         auto fn = [&](Bin& b, hipStream_t q) {
@@ -812,6 +817,24 @@ struct Solver final : pcr_solver {
             else LP(512, false);
 #undef LP
         };
+        Bin &ba = sbins[0], &bb = sbins[1];
+        if (prepare_is_single_launch()) {
+            // both LDS-resident classes (<= 256 ratings: one wave per user; <= 4096: one workgroup) in one launch on the
+            // solver's stream (k_prepare_all): no fork / join; only users beyond 4096 ratings take a second launch
+            const int na = (int)ba.users.size(), nb = (int)bb.users.size();
+            const int cpa = host_pow2(ba.cap), cpb = host_pow2(bb.cap), rsa = ba.max_lev + 2, rsb = bb.max_lev + 2;
+            const size_t wb = (small_common(64) + prepare_bytes<T>(ba.cap, cpa, rsa, 4) + 15) & ~(size_t)15;
+            const size_t lds = std::max(wb * 8, small_common(512) + prepare_bytes<T>(bb.cap, cpb, rsb, 4));
+            {
+                ProfScope ps(this, "prepare/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
+                hipLaunchKernelGGL((k_prepare_all<T>), dim3(nb + cdiv(na, 8)), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, cpa, rsa, wb,
+                                   bb.d_users.p, nb, bb.cap, cpb, rsb, nb, d_mcsr.p, strict());
+            }
+            if (!sbins[2].users.empty()) { ProfScope ps(this, pname("prepare", sbins[2]), st, sbins[2].nnz, (int64_t)sbins[2].users.size()); fn(sbins[2], st); }
+            HIPCHK(hipGetLastError());
+            have_sorted = true;
+            return PCR_OK;
+        }
         RC(for_bins(bins, "prepare", fn));
         have_sorted = true;
         return PCR_OK;
@@ -927,15 +950,23 @@ struct Solver final : pcr_solver {
     }
 
     // loss (all ranks) of the last prepare + lambda/2 (|U|^2 + |Vm|^2)   (pcrpp.cpp:410)
-    int full_objective(const T* Vm, double* obj) {
-        const bool need_u = !unorm_valid;                          // |U|^2 rides on the same read-back instead of its own sync
-        if (need_u) { RC(norm2(d_U.p, (int64_t)n_users * geo.ld, 8)); RC(allreduce_f64(d_scal.p + 8, 1)); }
-        RC(reduce_sum(d_objp.p, n_users, 0));
+    // d_scal[0] = sum objx (all ranks), [1] = |Vm|^2, [2] = |U|^2 (all ranks; only if with_u): one pass + one finish
+    int objective_sums(const double* objx, const T* Vm, bool with_u) {
+        const int64_t nV = (int64_t)d2 * geo.ld, nU = (int64_t)n_users * geo.ld;
+        const int nb = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv(std::max(nV, nU), 4096)));
+        hipLaunchKernelGGL((k_obj3<T>), dim3(nb), dim3(PCR_EW_BLOCK), 0, st, objx, n_users, Vm, nV, with_u ? d_U.p : (const T*)nullptr, nU, d_partA.p);
+        hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p);
+        HIPCHK(hipGetLastError());
         RC(allreduce_f64(d_scal.p, 1));
-        RC(norm2(Vm, (int64_t)d2 * geo.ld, 2));
-        RC(fetch_scal(need_u ? 9 : 4));
-        if (need_u) { unorm2 = h_scal[8]; unorm_valid = true; }
-        *obj = h_scal[0] + prm.lambda * (unorm2 + h_scal[2]) / 2.0;
+        if (with_u) RC(allreduce_f64(d_scal.p + 2, 1));
+        return PCR_OK;
+    }
+    int full_objective(const T* Vm, double* obj) {
+        const bool need_u = !unorm_valid;                          // |U|^2 rides on the same pass and read-back
+        RC(objective_sums(d_objp.p, Vm, need_u));
+        RC(fetch_scal(4));
+        if (need_u) { unorm2 = h_scal[2]; unorm_valid = true; }
+        *obj = h_scal[0] + prm.lambda * (unorm2 + h_scal[1]) / 2.0;
         return PCR_OK;
     }
 
@@ -1063,16 +1094,20 @@ struct Solver final : pcr_solver {
         else RC(full_objective(d_V.p, &prev_obj));
         carry_obj_valid = false;
         RC(device_gradient());                                     // obtain_g_new (:418)
-        // solve_delta_new (:422).  The host waits for the CG here on purpose: the line search forks its length classes
-        // onto the lanes, and a fork whose event is still pending when the lanes reach it costs far more on this
-        // platform than the host round trip (measured: 2.19 -> 2.40 ms per iteration without this sync)
-        RC(device_cg(&cg_iters));
+        // solve_delta_new (:422).  No host round trip when the line search's prepare is the single-launch form: everything
+        // up to the objective read-back is stream-ordered.  (With the per-class launches the host waits for the CG first: a
+        // fork whose event is still pending when the lanes reach it costs far more here than the round trip -- measured
+        // 2.19 -> 2.40 ms per iteration.)
+        static const int cg_sync_knob = getenv("PCR_CG_SYNC") ? atoi(getenv("PCR_CG_SYNC")) : -1;           // developer knob
+        const bool cg_sync = cg_sync_knob >= 0 ? cg_sync_knob != 0 : !prepare_is_single_launch();
+        RC(device_cg(cg_sync ? &cg_iters : nullptr));
         double step = prm.stepsize, obj = prev_obj;
         const int64_t n = (int64_t)d2 * geo.ld;
         for (int it = 0; it < 20; ++it) {                          // :427-441
             hipLaunchKernelGGL((k_axpy_out<T>), dim3(cdiv(n, 256)), dim3(256), 0, st, d_Vnew.p, d_V.p, d_delta.p, -step, n);
             RC(launch_prepare(d_Vnew.p));
             RC(full_objective(d_Vnew.p, &obj));
+            if (!cg_sync) cg_iters = h_cg->iters;                 // that read-back synchronised the stream
             ++tries;
             if (obj < prev_obj) {
                 std::swap(d_V.p, d_Vnew.p);
@@ -1124,9 +1159,7 @@ struct Solver final : pcr_solver {
         // U changed, and k_ustep left the sorted state of (U_new, V) behind: still valid for the next V step -- unless
         // it started from the state of a rejected V_new, which the users it skipped still carry
         if (state_of_rejected_V) { have_sorted = false; state_of_rejected_V = false; }
-        RC(reduce_sum(d_objr.p, n_users, 0));                       // sum_i obj_u(i)
-        RC(allreduce_f64(d_scal.p, 1));
-        RC(norm2(d_V.p, (int64_t)d2 * geo.ld, 2));
+        RC(objective_sums(d_objr.p, d_V.p, false));                 // sum_i obj_u(i), |V|^2
         HIPCHK(hipMemcpyAsync(h_counters, d_counters.p, (4 + 64) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         RC(fetch_scal(4));
 #ifdef PCR_USTEP_PROF
@@ -1142,7 +1175,7 @@ struct Solver final : pcr_solver {
             }
         }
 #endif
-        carry_obj = h_scal[0] + prm.lambda / 2.0 * h_scal[2];      // :835
+        carry_obj = h_scal[0] + prm.lambda / 2.0 * h_scal[1];      // :835
         carry_obj_valid = have_sorted;
         if (now_obj) *now_obj = carry_obj;
         if (h_counters[3] != 0) { pcr_set_error("k_ustep: a workgroup cluster timed out at a hand-off (members not co-resident?)"); return PCR_ERR_DEVICE; }
