@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Dev tool: profiles/<tag>_* from gpurun_out/<tag>/ (tools/collect_profiles.sh): copies the small artefacts and writes
+profiles/<tag>_summary.md.   make_summary.py <tag> "<title line>" """
+import csv, json, os, shutil, sys
+tag, title = sys.argv[1], sys.argv[2]
+src, dst = f"gpurun_out/{tag}", "profiles"
+for a, b in [("kernel_stats.csv", f"{tag}_kernel_stats.csv"), ("pmc_traffic_table.txt", f"{tag}_pmc_traffic_table.txt"),
+             ("bench.json", f"{tag}_bench.json"), ("bench_noprofile.json", f"{tag}_bench_noprofile.json"), ("traffic.json", "r01_traffic.json")]:
+    shutil.copy(os.path.join(src, a), os.path.join(dst, b))
+b = json.loads(open(f"{src}/bench.json").read().strip().split("\n")[-1])
+bn = json.loads(open(f"{src}/bench_noprofile.json").read().strip().split("\n")[-1])
+cpu = b.get("cpu_baseline") or {}
+out = [f"# {title}", "",
+       "Commands (GPU box, 1x MI355X, ml1m-shaped synthetic, PrimalCR++ k=100 lambda=5000, fp32 storage / fp64 accumulation; `tools/collect_profiles.sh`):", "",
+       f"* `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu` -> `{tag}_kernel_stats.csv`",
+       f"* `rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --no-cpu --no-profile --steps 10` and the same with `--pmc WRITE_SIZE` (separate passes) -> `r01_traffic.json`, `{tag}_pmc_traffic_table.txt` (tools/pmc_traffic.py; counters in KiB, FETCH_SIZE also given x2 per MI355X_MICROARCH.md)",
+       f"* `python3 bench.py --verbose` -> `{tag}_bench.json`; `python3 bench.py --no-profile --no-cpu` -> `{tag}_bench_noprofile.json`", "",
+       f"bench: {b['ms_per_step']:.2f} ms per outer iteration with sampled event timing ({bn['ms_per_step']:.2f} ms without = {bn['value']:.3e} pairs/s), "
+       f"test NDCG@10 {b['ndcg10_test']:.4f}, pairwise error {b['pairwise_error_test']:.4f}; "
+       + (f"reference OpenMP -n {cpu.get('cores')}: {cpu.get('s_per_iter', 0):.2f} s per iteration ({b.get('speedup_vs_cpu_baseline', 0):.0f}x)." if cpu else ""), "",
+       "roofline (dominant kernel by wall-clock share): " + json.dumps(b["roofline"]), "",
+       "| kernel (rocprofv3 --kernel-trace --stats) | calls | total us | avg us | % |", "|---|---|---|---|---|"]
+rows = list(csv.DictReader(open(f"{src}/kernel_stats.csv")))
+for r in rows[:28]:
+    out.append(f"| `{r['Name'][:64]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
+out += ["", "HIP-event averages from the same build inside bench.py (every 4th launch timed; share = wall-clock share of the timed region, concurrent length classes share their group's fork..join wall time):", "",
+        "| slot | avg us | share | algorithmic MB | algorithmic GB/s | frac of 8 TB/s | PMC bytes/launch (FETCH raw + WRITE) |", "|---|---|---|---|---|---|---|"]
+for k, v in sorted(b["kernels"].items(), key=lambda kv: -kv[1]["share"]):
+    out.append(f"| {k} | {v['avg_us']} | {v['share']} | {v['algorithmic_bytes']/1e6:.2f} | {v['achieved_GBs']} | {v['frac_hbm_peak']} | {v['traffic_bytes']} |")
+open(f"{dst}/{tag}_summary.md", "w").write("\n".join(out) + "\n")
+print("\n".join(out[:12]))
