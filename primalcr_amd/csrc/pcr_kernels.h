@@ -766,8 +766,8 @@ __global__ __launch_bounds__(512) void k_prepare_all(Shard<T> S, const int32_t* 
 //   HV = true : Hessian-vector (x = b = u_i . a_item, computed by k_sddmm)   pcrpp.cpp:294-318
 // ---------------------------------------------------------------------------------------
 template <typename T>
-static inline size_t vsweep_bytes(int cap, int rs_cap) {
-    return carve_bytes(cap, sizeof(T)) * 2 + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
+static inline size_t vsweep_bytes(int cap, int rs_cap, bool two) {      // two: scores AND sweep values (HV without window cache)
+    return carve_bytes(cap, sizeof(T)) * (two ? 2 : 1) + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
 }
 
 // body of k_vsweep: workgroup `blk` of `nblk` walks users blk, blk + nblk, ...
@@ -778,8 +778,8 @@ __device__ __forceinline__ void vsweep_block_body(char* smem, const Shard<T>& S,
     Carver small(smem);
     double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
     Carver big(BIG ? scratch + (size_t)blk * stride : small.p);
-    T* ms = big.take<T>(cap);
-    T* x = big.take<T>(cap);
+    T* ms = big.take<T>(cap);                           // scores (thresholds) -- not loaded when the window cache replaces them
+    T* x = (HV && !S.ws) ? big.take<T>(cap) : ms;       // sweep values b; they share the array unless both are needed
     double* Sx = big.take<double>(cap + 1);
     int* rs = big.take<int>(rs_cap);
     const int tid = threadIdx.x;
@@ -823,8 +823,8 @@ __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int
 // workgroup: no workgroup barriers at all (LDS traffic stays inside a wave, which the LDS serves
 // in program order), so the many short users of a rating set do not pay a block's fixed cost each.
 template <typename T>
-static inline size_t vsweep_wave_bytes(int cap, int rs_cap) {      // per wave
-    return carve_bytes(cap, sizeof(T)) * 2 + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
+static inline size_t vsweep_wave_bytes(int cap, int rs_cap, bool two) {      // per wave
+    return carve_bytes(cap, sizeof(T)) * (two ? 2 : 1) + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
 }
 // body: this wave sweeps user number ui of the list
 template <typename T, bool HV>
@@ -834,8 +834,8 @@ __device__ __forceinline__ void vsweep_wave_body(char* smem, const Shard<T>& S, 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (ui >= nusers) return;
     Carver big(smem + (size_t)wid * wave_bytes);
-    T* ms = big.take<T>(cap);
-    T* x = big.take<T>(cap);
+    T* ms = big.take<T>(cap);                           // scores (thresholds) -- not loaded when the window cache replaces them
+    T* x = (HV && !S.ws) ? big.take<T>(cap) : ms;       // sweep values b; they share the array unless both are needed
     double* Sx = big.take<double>(cap + 1);
     int* rs = big.take<int>(rs_cap);
     const int u = users[ui];

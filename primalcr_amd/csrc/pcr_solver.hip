@@ -162,7 +162,8 @@ struct Solver final : pcr_solver {
     DBuf<T> d_ms, d_c, d_mcsr, d_b;
     DBuf<double> d_objp;
     std::vector<Bin> bins;
-    std::vector<Bin> sbins;                      // sweep bins: the light V-side sweeps run back to back on one stream
+    std::vector<Bin> sbins;                      // sweep classes (k_vsweep_all)
+    std::vector<Bin> pbins;                      // prepare classes (k_prepare_all)
     std::vector<Bin> ubins;                      // U-step bins: an extra class, long users get workgroup clusters
     DBuf<unsigned> d_bar;
     DBuf<char> d_xch;
@@ -468,8 +469,18 @@ struct Solver final : pcr_solver {
         }
         make_bins(uptr, nu, &lv.run_ofs, bins);
         for (auto& b : bins) RC(b.d_users.upload(b.users, st));
-        make_bins(uptr, nu, &lv.run_ofs, sbins, {256, 4096}, {64, 512, 512});       // bin 0: one wave per user (k_vsweep_wave)
+        // sweep / prepare classes: class 0 = one wave per user, class 1 = one 512-thread workgroup, class 2 = global scratch.
+        // The sweeps keep 12 B per rating in LDS, so a wave can take users of up to 512 ratings (48 KB per 8-wave
+        // workgroup = what a 4096-rating user needs).  That pays when many users lie between 256 and 512 ratings
+        // (long-tailed data: 10 M-rating Netflix-shaped slice 181 -> 163 us per sweep) and costs when few do (ml1m 22.5 -> 25.9 us).
+        int64_t n_256_512 = 0;
+        for (int64_t u = 0; u < nu; ++u) { const int64_t len = uptr[u + 1] - uptr[u]; n_256_512 += len > 256 && len <= 512; }
+        const int sweep_wave_cap = getenv("PCR_SWEEP_WAVE_CAP") ? std::max(64, atoi(getenv("PCR_SWEEP_WAVE_CAP")))     // developer knob
+                                                                 : (n_256_512 > 8 * (int64_t)ncu ? 512 : 256);
+        make_bins(uptr, nu, &lv.run_ofs, sbins, {std::min(sweep_wave_cap, 4095), 4096}, {64, 512, 512});
         for (auto& b : sbins) RC(b.d_users.upload(b.users, st));
+        make_bins(uptr, nu, &lv.run_ofs, pbins, {256, 4096}, {64, 512, 512});
+        for (auto& b : pbins) RC(b.d_users.upload(b.users, st));
         // U step: users with more than 1024 ratings are bound by one CU's gather bandwidth -> clusters of 4 workgroups
         // The U step keeps each user's rows of V in LDS (k_ustep, stage_rows), so its occupancy is set by LDS bytes, not
         // registers: finer length classes than the V side, and a workgroup size that grows with the class.
@@ -639,7 +650,7 @@ struct Solver final : pcr_solver {
         if (!bins[3].users.empty()) {
             int cp = host_pow2(bins[3].cap), rsc = bins[3].max_lev + 2;
             need = std::max(need, prepare_bytes<T>(cp, cp, rsc, 8));   // LI is 8 bytes in scratch
-            need = std::max(need, vsweep_bytes<T>(bins[3].cap, rsc));
+            need = std::max(need, vsweep_bytes<T>(bins[3].cap, rsc, true));
             need = std::max(need, ustep_big_bytes<T>(cp, cp, rsc, 8));
         }
         for (int w = 0; w < 2; ++w)
@@ -800,7 +811,7 @@ struct Solver final : pcr_solver {
 
     bool prepare_is_single_launch() const {
         static const int merged = getenv("PCR_PREPARE_MERGED") ? atoi(getenv("PCR_PREPARE_MERGED")) : 1;     // developer knob
-        return merged && !sbins[0].users.empty() && !sbins[1].users.empty();
+        return merged && !pbins[0].users.empty() && !pbins[1].users.empty();
     }
     int launch_prepare(const T* Vm) {
         RC(launch_sddmm(Vm, d_item.p, d_mcsr.p));
@@ -817,7 +828,7 @@ struct Solver final : pcr_solver {
             else LP(512, false);
 #undef LP
         };
-        Bin &ba = sbins[0], &bb = sbins[1];
+        Bin &ba = pbins[0], &bb = pbins[1];
         if (prepare_is_single_launch()) {
             // both LDS-resident classes (<= 256 ratings: one wave per user; <= 4096: one workgroup) in one launch on the
             // solver's stream (k_prepare_all): no fork / join; only users beyond 4096 ratings take a second launch
@@ -830,7 +841,7 @@ struct Solver final : pcr_solver {
                 hipLaunchKernelGGL((k_prepare_all<T>), dim3(nb + cdiv(na, 8)), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, cpa, rsa, wb,
                                    bb.d_users.p, nb, bb.cap, cpb, rsb, nb, d_mcsr.p, strict());
             }
-            if (!sbins[2].users.empty()) { ProfScope ps(this, pname("prepare", sbins[2]), st, sbins[2].nnz, (int64_t)sbins[2].users.size()); fn(sbins[2], st); }
+            if (!pbins[2].users.empty()) { ProfScope ps(this, pname("prepare", pbins[2]), st, pbins[2].nnz, (int64_t)pbins[2].users.size()); fn(pbins[2], st); }
             HIPCHK(hipGetLastError());
             have_sorted = true;
             return PCR_OK;
@@ -842,16 +853,17 @@ struct Solver final : pcr_solver {
 
     int launch_vsweep(bool hv, const T* A, const int* skip = nullptr) {
         if (hv) RC(launch_sddmm(A, d_sitem.p, d_b.p, skip));
+        const bool two = hv && !sh.ws;                      // scores and sweep values both live in LDS (no window cache)
         auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
             const int rsc = b.max_lev + 2;
             if (b.block == 64) {                         // short users: one wave each, four per workgroup
-                const size_t wb = (vsweep_wave_bytes<T>(b.cap, rsc) + 15) & ~(size_t)15;
+                const size_t wb = (vsweep_wave_bytes<T>(b.cap, rsc, two) + 15) & ~(size_t)15;
                 if (hv) hipLaunchKernelGGL((k_vsweep_wave<T, true>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip);
                 else hipLaunchKernelGGL((k_vsweep_wave<T, false>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip);
                 return;
             }
-            const size_t bigb = vsweep_bytes<T>(b.cap, rsc);
+            const size_t bigb = vsweep_bytes<T>(b.cap, rsc, two);
             const size_t lds = small_common(b.block) + (b.big ? 0 : bigb);
             const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
 #define LV(BL, BG, HV) hipLaunchKernelGGL((k_vsweep<T, BL, BG, HV>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, d_scratch.p, scratch_stride, strict(), skip)
@@ -864,8 +876,8 @@ struct Solver final : pcr_solver {
             // the two LDS-resident classes in one launch (k_vsweep_all); only users beyond 4096 ratings take a second one
             const int na = (int)ba.users.size(), nb = (int)bb.users.size();
             const int rsa = ba.max_lev + 2, rsb = bb.max_lev + 2;
-            const size_t wb = (vsweep_wave_bytes<T>(ba.cap, rsa) + 15) & ~(size_t)15;
-            const size_t lds = std::max(wb * 8, small_common(512) + vsweep_bytes<T>(bb.cap, rsb));
+            const size_t wb = (vsweep_wave_bytes<T>(ba.cap, rsa, two) + 15) & ~(size_t)15;
+            const size_t lds = std::max(wb * 8, small_common(512) + vsweep_bytes<T>(bb.cap, rsb, two));
             const int grid = nb + cdiv(na, 8);
             {
                 ProfScope ps(this, std::string(hv ? "vhv" : "vgrad") + "/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
