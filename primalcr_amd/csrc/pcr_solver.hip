@@ -500,13 +500,16 @@ struct Solver final : pcr_solver {
             }
         }
         const size_t nsmall = ucap.size();
-        // Latency or throughput?  A class with few users (ml1m's long users) is one round of workgroups and is bound by the
-        // per-user dependency chain: 512 threads, 8 rows in flight per lane group, one workgroup per CU.  A class with many
-        // users (Netflix-shaped data) is bound by how busy each CU's memory pipe stays: smaller / leaner workgroups, so that
-        // two share a CU and one gathers while the other scans or sorts (<= 1024 ratings: 256 threads; above: 512 threads
-        // at 4 rows in flight = 128 VGPRs, and a class boundary at 2048 so that the per-rating arrays of two fit the LDS).
+        // Latency or throughput?  A class with few users is one round of workgroups and is bound by the per-user dependency
+        // chain: 512 threads, 8 rows in flight per lane group, 174-205 VGPRs = one workgroup per CU.  A class with many users
+        // is bound by how busy each CU's memory pipe stays: smaller / leaner workgroups, so that two share a CU and one
+        // gathers while the other scans or sorts (<= 1024 ratings: 256 threads; above: 512 threads at 4 rows in flight =
+        // 124 VGPRs, and a class boundary at 2048 so that the per-rating arrays of two fit the LDS).  "Many" is more than
+        // CUs/4 users: the greedy one-per-CU workgroups of all long classes together must leave CUs for the short classes
+        // (ml1m: 88 + 221 users in throughput form 2.09 -> 2.03 ms per iteration; Netflix shape: U step 87 -> 69 ms).
         const int force_mode = getenv("PCR_USTEP_MODE") ? atoi(getenv("PCR_USTEP_MODE")) : 0;   // developer / test knob: 1 latency, 2 throughput
-        auto many = [&](int64_t users) { return force_mode ? force_mode == 2 : users > 2 * (int64_t)ncu; };
+        const int64_t many_users = getenv("PCR_USTEP_MANY") ? atoll(getenv("PCR_USTEP_MANY")) : std::max<int64_t>(1, ncu / 4);   // developer knob
+        auto many = [&](int64_t users) { return force_mode ? force_mode == 2 : users > many_users; };
         int64_t n_mid = 0;
         for (int64_t u = 0; u < nu; ++u) { const int64_t len = uptr[u + 1] - uptr[u]; n_mid += len > 1024 && len <= 4096; }
         ucap.push_back(1024); ublk.push_back(512);
