@@ -546,7 +546,10 @@ struct Solver final : pcr_solver {
         }
         for (size_t q = nsmall; q < ubins.size(); ++q) {
             Bin& b = ubins[q];
-            if (b.K > 1 || !many((int64_t)b.users.size())) { b.unr = 8; continue; }
+            // (a class whose per-rating arrays fill more than half the LDS runs one workgroup per CU whatever its register
+            // count: it keeps the 8-rows-in-flight form)
+            const bool lds_bound = !b.big && ustep_big_bytes<T>(b.cap, host_pow2(b.cap), b.max_lev + 2, 4) > 72 * 1024;
+            if (b.K > 1 || lds_bound || !many((int64_t)b.users.size())) { b.unr = 8; continue; }
             b.unr = 4;
             if (b.limit == 1024 && !b.big) b.block = 256;
         }
