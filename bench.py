@@ -224,20 +224,18 @@ def main():
         if N > 1:
             dist.barrier()
 
-    objs = []
-    for _ in range(args.warmup):
-        s.update_V(); o, _ = s.update_U(); objs.append(o)
+    objs = [r["obj"] for r in s.iterate(args.warmup)]
     if not args.no_profile:
         s.profile(True, period=4)       # sampled: every 4th launch of each kernel carries an event pair
         s.profile_reset()
     barrier()
     t0 = time.perf_counter()
     inner = {"cg_v": 0, "ls_v": 0, "cg_u": 0, "ls_u": 0}
-    for _ in range(args.steps):
-        _, vi = s.update_V()
-        o, ui = s.update_U()
-        objs.append(o)
-        inner["cg_v"] += vi["cg"]; inner["ls_v"] += vi["ls"]; inner["cg_u"] += ui["cg"]; inner["ls_u"] += ui["ls"]
+    # exactly K steps = K outer iterations (V step + U step) of the training loop, as pcr_train runs them (pcr_iterate)
+    for rec in s.iterate(args.steps):
+        objs.append(rec["obj"])
+        for key in inner:
+            inner[key] += rec[key]
     barrier()
     secs = time.perf_counter() - t0
     if N > 1:

@@ -190,6 +190,11 @@ typedef void (*pcr_log_fn)(void *ctx, const char *line);
  * from the current device factors.  Emits the reference's log lines through
  * `log` (NULL = stdout).  hist may be NULL, else holds maxiter+1 records. */
 int pcr_train(pcr_solver *s, pcr_log_fn log, void *log_ctx, pcr_iter_stats *hist);
+/* The body of that loop (pcrpp.cpp:869-895: update_V_new, update_U_new, no evaluation) n times from the current state,
+ * with one host round trip per iteration: the U step is queued without waiting for it and its objective is read back
+ * together with the next iteration's line search.  out (may be NULL) receives n records: obj, seconds (cumulative
+ * device time of the loop), inner-iteration counts.  pcr_train uses it when do_predict == 0 and log == NULL. */
+int pcr_iterate(pcr_solver *s, int n, pcr_iter_stats *out);
 
 /* pmf-predict.cpp:56-64: pred[z] = U[user[z]] . V[item[z]] for n (0-based) pairs */
 int pcr_predict(const double *U, int64_t d1, const double *V, int64_t d2, int64_t k,

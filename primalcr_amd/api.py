@@ -96,6 +96,7 @@ def lib():
     L.pcr_update_U.argtypes = [vp, C.POINTER(cd), C.POINTER(i64)]
     L.pcr_evaluate.argtypes = [vp, ci, ci, C.POINTER(cd), C.POINTER(cd)]
     L.pcr_train.argtypes = [vp, vp, vp, C.POINTER(IterStats)]
+    L.pcr_iterate.argtypes = [vp, ci, C.POINTER(IterStats)]
     L.pcr_predict.argtypes = [_dp, i64, _dp, i64, i64, i64, _ip, _ip, _dp, ci]
     L.pcr_profile_enable.argtypes = [vp, ci]
     L.pcr_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(cd), C.POINTER(i64)]
@@ -307,6 +308,12 @@ class Solver:
         _chk(lib().pcr_train(self._h, C.cast(cb, C.c_void_p), None, hist))
         recs = [{k: getattr(h, k) for k, _ in IterStats._fields_} for h in hist]
         return recs, lines
+
+    def iterate(self, n):
+        """n outer iterations (V step + U step, no evaluation) with one host round trip each; returns their records."""
+        hist = (IterStats * max(n, 1))()
+        _chk(lib().pcr_iterate(self._h, n, hist))
+        return [{k: getattr(h, k) for k, _ in IterStats._fields_} for h in hist[:n]]
 
     def profile(self, on=True, period=1):
         """Per-kernel HIP-event timing; period > 1 times every period-th launch of each kernel."""

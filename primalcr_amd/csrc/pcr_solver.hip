@@ -114,6 +114,7 @@ struct pcr_solver {
     virtual int update_U(double* now_obj, int64_t* info) = 0;
     virtual int evaluate(int which, int ndcg_k, double* err, double* ndcg) = 0;
     virtual int train(pcr_log_fn log, void* ctx, pcr_iter_stats* hist) = 0;
+    virtual int iterate_abi(int n, pcr_iter_stats* out) = 0;
     virtual int comm_init(const void* id) = 0;
     virtual int sync() = 0;
     int64_t first_user = 0, n_users = 0, nnz_local = 0;
@@ -196,6 +197,12 @@ struct Solver final : pcr_solver {
     int scratch_blocks = 0;
     int u_big_blocks = 0;                         // scratch slices the concurrent big U-step bins need together
     double* h_scal = nullptr;                     // pinned
+    double* h_uobj = nullptr;                     // pinned: the U step's objective sums (its own buffer: read late by a pipelined loop)
+    bool ustep_pending = false;                   // a U step is queued whose results have not been read yet
+    double fin_obj = 0.0;                         // results of the U step that update_V finished on the loop's behalf
+    int64_t fin_info[2] = {0, 0};
+    bool fin_ready = false;
+    bool device_join = false;                     // pipelined loop: the solver's stream waits for the lanes on the device
     CGState* h_cg = nullptr;                      // pinned
     unsigned long long* h_counters = nullptr;     // pinned
     int ew_blocks = 1, ew_per_block = 1;          // elementwise decomposition over d2*ld
@@ -228,6 +235,7 @@ struct Solver final : pcr_solver {
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         if (comm) ncclCommDestroy(comm);
         if (h_scal) (void)hipHostFree(h_scal);
+        if (h_uobj) (void)hipHostFree(h_uobj);
         if (h_cg) (void)hipHostFree(h_cg);
         if (h_counters) (void)hipHostFree(h_counters);
         for (int i = 0; i < NSIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
@@ -650,6 +658,7 @@ struct Solver final : pcr_solver {
         RC(d_counters.alloc(4 + 64 + (bar_n + 1) / 2));
         bar_p = reinterpret_cast<unsigned*>(d_counters.p + 4 + 64);
         HIPCHK(hipHostMalloc((void**)&h_scal, 64 * sizeof(double)));
+        HIPCHK(hipHostMalloc((void**)&h_uobj, 4 * sizeof(double)));
         HIPCHK(hipHostMalloc((void**)&h_cg, sizeof(CGState)));
         HIPCHK(hipHostMalloc((void**)&h_counters, (4 + 64) * sizeof(unsigned long long)));
 
@@ -733,7 +742,7 @@ struct Solver final : pcr_solver {
     // the solver's stream continues after `ev`
     int join(hipEvent_t ev) {
         static const int host_join = getenv("PCR_HOST_JOIN") ? atoi(getenv("PCR_HOST_JOIN")) : 1;      // developer knob
-        if (host_join) HIPCHK(hipEventSynchronize(ev)); else HIPCHK(hipStreamWaitEvent(st, ev, 0));
+        if (host_join && !device_join) HIPCHK(hipEventSynchronize(ev)); else HIPCHK(hipStreamWaitEvent(st, ev, 0));
         return PCR_OK;
     }
     // U step: the hardware runs only a few queues side by side (streams beyond that share a queue and serialise), so the
@@ -1112,7 +1121,10 @@ struct Solver final : pcr_solver {
         double prev_obj = 0.0;
         // objective_new(m, U, V) (:425): right after a U step it is that step's now_obj (sum_i obj_u + lambda/2 |V|^2, :835) --
         // the same quantity over the same m -- so no reduction + read-back of its own
-        if (carry_obj_valid && have_sorted) prev_obj = carry_obj;
+        // (pipelined loop: that U step may still be running; its objective is read at the line search's first read-back)
+        const bool prev_later = ustep_pending;
+        if (prev_later) {}
+        else if (carry_obj_valid && have_sorted) prev_obj = carry_obj;
         else RC(full_objective(d_V.p, &prev_obj));
         carry_obj_valid = false;
         RC(device_gradient());                                     // obtain_g_new (:418)
@@ -1130,6 +1142,12 @@ struct Solver final : pcr_solver {
             RC(launch_prepare(d_Vnew.p));
             RC(full_objective(d_Vnew.p, &obj));
             if (!cg_sync) cg_iters = h_cg->iters;                 // that read-back synchronised the stream
+            if (ustep_pending) {                                   // ... and with it the U step queued before this V step
+                RC(ustep_finish(&fin_obj, fin_info));
+                fin_ready = true;
+                prev_obj = carry_obj;
+                carry_obj_valid = false;
+            }
             ++tries;
             if (obj < prev_obj) {
                 std::swap(d_V.p, d_Vnew.p);
@@ -1173,7 +1191,15 @@ struct Solver final : pcr_solver {
     }
 
     // pcrpp.cpp:818-838
+    // The U step in two halves, so that a training loop can queue the next V step behind it without a host round trip:
+    // ustep_launch_async() queues the kernels, the objective sums and the copies of the results into pinned buffers of
+    // their own; ustep_finish() reads those buffers once the stream is known to have passed them.
     int update_U(double* now_obj, int64_t* info) override {
+        RC(ustep_launch_async());
+        HIPCHK(hipStreamSynchronize(st));
+        return ustep_finish(now_obj, info);
+    }
+    int ustep_launch_async() {
         RC(need_sorted());
         RC(launch_ustep());
         unorm_valid = false;
@@ -1182,7 +1208,12 @@ struct Solver final : pcr_solver {
         if (state_of_rejected_V) { have_sorted = false; state_of_rejected_V = false; }
         RC(objective_sums(d_objr.p, d_V.p, false));                 // sum_i obj_u(i), |V|^2
         HIPCHK(hipMemcpyAsync(h_counters, d_counters.p, (4 + 64) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        RC(fetch_scal(4));
+        HIPCHK(hipMemcpyAsync(h_uobj, d_scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+        ustep_pending = true;
+        return PCR_OK;
+    }
+    int ustep_finish(double* now_obj, int64_t* info) {
+        ustep_pending = false;
 #ifdef PCR_USTEP_PROF
         {   // developer build only: per-phase shader-clock totals of thread 0 of every workgroup, by bin class
             static const char* ph[] = {"load", "g.sweep", "g.axpy", "cg.sddmm", "cg.sweep", "cg.axpy", "vec", "ls.sddmm", "ls.sort", "ls.obj", "store", "TOTAL", "wgs"};
@@ -1196,7 +1227,7 @@ struct Solver final : pcr_solver {
             }
         }
 #endif
-        carry_obj = h_scal[0] + prm.lambda / 2.0 * h_scal[1];      // :835
+        carry_obj = h_uobj[0] + prm.lambda / 2.0 * h_uobj[1];      // :835
         carry_obj_valid = have_sorted;
         if (now_obj) *now_obj = carry_obj;
         if (h_counters[3] != 0) { pcr_set_error("k_ustep: a workgroup cluster timed out at a hand-off (members not co-resident?)"); return PCR_ERR_DEVICE; }
@@ -1292,6 +1323,15 @@ struct Solver final : pcr_solver {
         snprintf(line, sizeof line, "Iter 0 time 0 obj %g", now_obj); emit(line);
         RC(do_eval(cur));
         if (hist) hist[0] = cur;
+        if (!prm.do_predict && !log) {
+            // no evaluation between iterations and nobody but stdout listening: the pipelined loop (iterate()); an
+            // iteration's line is printed once its results are in, i.e. during the next iteration's line search (a caller's
+            // log callback may look at the factors when it sees a line -- omp-pmf-train --snapshot-every does -- so with a
+            // callback the loop below keeps the factors and the lines in step)
+            return iterate(prm.maxiter, hist ? hist + 1 : nullptr, [&](int iter, const pcr_iter_stats& rec) {
+                snprintf(line, sizeof line, "Iter %d time %g obj %g", iter, rec.seconds, rec.obj); emit(line);
+            });
+        }
         double total_time = 0.0;
         for (int iter = 1; iter <= prm.maxiter; ++iter) {
             auto t0 = std::chrono::steady_clock::now();
@@ -1310,6 +1350,54 @@ struct Solver final : pcr_solver {
         }
         return PCR_OK;
     }
+
+    // n outer iterations (pcrpp.cpp:869-895 without the evaluation) with ONE host round trip each -- the line search's
+    // objective read-back.  The U step of iteration k is queued without waiting for it, the V step of iteration k + 1
+    // (gradient, CG, first line-search try) is queued right behind it, and the U step's objective and counters are read
+    // when that line search synchronises.  `seconds` is device time (events on the solver's stream), cumulative.
+    template <class F>
+    int iterate(int n, pcr_iter_stats* out, F on_done) {
+        if (n <= 0) return PCR_OK;
+        hipEvent_t ev0 = nullptr, evk[2] = {nullptr, nullptr};
+        HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&evk[0])); HIPCHK(hipEventCreate(&evk[1]));
+        struct Guard { hipEvent_t* e[3]; ~Guard() { for (auto p : e) if (*p) (void)hipEventDestroy(*p); } } guard{{&ev0, &evk[0], &evk[1]}};
+        std::vector<pcr_iter_stats> rec(n + 1);
+        for (auto& r : rec) memset(&r, 0, sizeof r);
+        int rc = PCR_OK;
+        device_join = getenv("PCR_PIPELINE") ? atoi(getenv("PCR_PIPELINE")) != 0 : true;
+        HIPCHK(hipEventRecord(ev0, st));
+        auto close = [&](int k) -> int {                         // iteration k's U step has been finished (fin_*)
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, ev0, evk[k & 1]));
+            rec[k].obj = fin_obj; rec[k].seconds = ms / 1e3; rec[k].cg_u = fin_info[0]; rec[k].ls_u = fin_info[1];
+            fin_ready = false;
+            if (out) out[k - 1] = rec[k];
+            on_done(k, rec[k]);
+            return PCR_OK;
+        };
+        for (int k = 1; k <= n && rc == PCR_OK; ++k) {
+            int vinfo[3] = {0, 0, 0};
+            double vobj = 0.0;
+            rc = update_V(&vobj, vinfo);                             // finishes the U step of iteration k - 1 on the way
+            if (rc != PCR_OK) break;
+            if (fin_ready) { rc = close(k - 1); if (rc != PCR_OK) break; }
+            rec[k].cg_v = vinfo[0]; rec[k].ls_v = vinfo[1];
+            rc = ustep_launch_async();
+            if (rc != PCR_OK) break;
+            HIPCHK(hipEventRecord(evk[k & 1], st));
+            static const int pipe = getenv("PCR_PIPELINE") ? atoi(getenv("PCR_PIPELINE")) : 1;       // developer knob
+            if (!pipe) { HIPCHK(hipStreamSynchronize(st)); rc = ustep_finish(&fin_obj, fin_info); if (rc == PCR_OK) rc = close(k); }
+        }
+        device_join = false;
+        if (rc == PCR_OK && ustep_pending) {
+            HIPCHK(hipStreamSynchronize(st));
+            rc = ustep_finish(&fin_obj, fin_info);
+            if (rc == PCR_OK) rc = close(n);
+        }
+        if (rc != PCR_OK && ustep_pending) { (void)hipStreamSynchronize(st); ustep_pending = false; }
+        return rc;
+    }
+    int iterate_abi(int n, pcr_iter_stats* out) override { return iterate(n, out, [](int, const pcr_iter_stats&) {}); }
 
     int comm_init(const void* id) override {
         ncclUniqueId uid;
@@ -1381,6 +1469,7 @@ int pcr_update_U(pcr_solver* s, double* now_obj, int64_t* info) { S_OR_ARG; retu
 int pcr_evaluate(pcr_solver* s, int which, int ndcg_k, double* e, double* n) { S_OR_ARG; return s->evaluate(which, ndcg_k, e, n); }
 int pcr_train(pcr_solver* s, pcr_log_fn log, void* ctx, pcr_iter_stats* hist) { S_OR_ARG; return s->train(log, ctx, hist); }
 int pcr_solver_sync(pcr_solver* s) { S_OR_ARG; return s->sync(); }
+int pcr_iterate(pcr_solver* s, int n, pcr_iter_stats* out) { S_OR_ARG; return s->iterate_abi(n, out); }
 
 int pcr_profile_enable(pcr_solver* s, int on) { S_OR_ARG; s->prof_on = on != 0; s->prof_period = on > 1 ? on : 1; if (on) s->prof_prewarm(4096); return PCR_OK; }
 int pcr_profile_reset(pcr_solver* s) {

@@ -331,3 +331,26 @@ def test_state_left_by_u_step_equals_a_fresh_prepare(oracle):
         assert rel(a.get_factors()[1], b.get_factors()[1]) < tol * 10
         if precision == pcr.PCR_F64:
             assert iA == iB
+
+
+def test_pipelined_iterations_equal_the_step_by_step_loop(oracle):
+    """pcr_iterate (U step queued without a host round trip, its objective read at the next line search) must walk the
+    same trajectory as update_V / update_U called one by one, bit for bit, and report the same counts."""
+    d1, d2, user, item, val = _mixed_set(seed=13, d1=400)
+    r, lam = 10, 20.0
+    ds = pcr.Dataset.from_triplets(d1, d2, user, item, val)
+    U0 = oracle.initial(d1, r) * 0.3; V0 = oracle.initial(d2, r) * 0.3
+    for precision in (pcr.PCR_F64, pcr.PCR_F32):
+        a = pcr.Solver(ds, pcr.Parameter(k=r, precision=precision, **{"lambda": lam}))
+        a.set_factors(U0, V0)
+        step = []
+        for _ in range(4):
+            _, iv = a.update_V(); o, iu = a.update_U()
+            step.append((o, iv["cg"], iv["ls"], iu["cg"], iu["ls"]))
+        b = pcr.Solver(ds, pcr.Parameter(k=r, precision=precision, **{"lambda": lam}))
+        b.set_factors(U0, V0)
+        recs = b.iterate(3) + b.iterate(1)           # also across two calls
+        assert [(x["obj"], x["cg_v"], x["ls_v"], x["cg_u"], x["ls_u"]) for x in recs] == step
+        assert all(x["seconds"] > 0 for x in recs) and recs[2]["seconds"] > recs[0]["seconds"]
+        Ua, Va = a.get_factors(); Ub, Vb = b.get_factors()
+        assert np.array_equal(Ua, Ub) and np.array_equal(Va, Vb)
