@@ -83,6 +83,10 @@ def slot_kernel_match(slot, kernel_name, prec):
     args = kernel_name[kernel_name.index("<") + 1:kernel_name.index(">")].replace(" ", "").split(",")
     if args[0] != ("float" if prec == "f32" else "double"):
         return False
+    if kernel_name.startswith("void k_prepare_all<"):          # both LDS classes in one launch: slot "prepare/all"
+        return cls == "prepare" and tag == "all"
+    if cls == "prepare" and tag == "all":
+        return False
     if kernel_name.startswith("void k_vsweep_all<"):           # both LDS classes in one launch: slot tag "all"
         return cls in ("vgrad", "vhv") and tag == "all" and (args[1] == "true") == (cls == "vhv")
     if kernel_name.startswith("void k_vsweep_wave<"):          # one wave per user: slot tag "64"

@@ -27,5 +27,8 @@ out += ["", "HIP-event averages from the same build inside bench.py (every 4th l
         "| slot | avg us | share | algorithmic MB | algorithmic GB/s | frac of 8 TB/s | PMC bytes/launch (FETCH raw + WRITE) |", "|---|---|---|---|---|---|---|"]
 for k, v in sorted(b["kernels"].items(), key=lambda kv: -kv[1]["share"]):
     out.append(f"| {k} | {v['avg_us']} | {v['share']} | {v['algorithmic_bytes']/1e6:.2f} | {v['achieved_GBs']} | {v['frac_hbm_peak']} | {v['traffic_bytes']} |")
+extra = f"{dst}/{tag}_extra.md"          # hand-written notes on runs outside bench.py (kept across regenerations)
+if os.path.exists(extra):
+    out += ["", open(extra).read().rstrip()]
 open(f"{dst}/{tag}_summary.md", "w").write("\n".join(out) + "\n")
 print("\n".join(out[:12]))
