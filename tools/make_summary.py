@@ -27,6 +27,11 @@ out += ["", "HIP-event averages from the same build inside bench.py (every 4th l
         "| slot | avg us | share | algorithmic MB | algorithmic GB/s | frac of 8 TB/s | PMC bytes/launch (FETCH raw + WRITE) |", "|---|---|---|---|---|---|---|"]
 for k, v in sorted(b["kernels"].items(), key=lambda kv: -kv[1]["share"]):
     out.append(f"| {k} | {v['avg_us']} | {v['share']} | {v['algorithmic_bytes']/1e6:.2f} | {v['achieved_GBs']} | {v['frac_hbm_peak']} | {v['traffic_bytes']} |")
+occ = os.path.join(src, "pmc_occupancy_table.txt")
+if os.path.exists(occ):
+    shutil.copy(occ, os.path.join(dst, f"{tag}_pmc_occupancy_table.txt"))
+    out += ["", "Achieved occupancy (`rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`, its own pass; PMC runs "
+            "serialise the kernels, so the concurrent U-step classes are shown alone):", "", open(occ).read().rstrip()]
 extra = f"{dst}/{tag}_extra.md"          # hand-written notes on runs outside bench.py (kept across regenerations)
 if os.path.exists(extra):
     out += ["", open(extra).read().rstrip()]
