@@ -321,6 +321,7 @@ def main():
         cpu = cpu_baseline(R, n_pairs, r, lam)
 
     value = n_pairs * args.steps / secs
+    passes = (1 + (inner["cg_v"] + inner["ls_v"]) / args.steps) + (1 + (inner["cg_u"] + inner["ls_u"]) / args.steps / max(R.d1, 1))
     out = {
         "metric": "pairwise-comparisons/sec", "value": value, "unit": "pairs/s", "n_gpus": N, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps, "higher_is_better": True, "scaling": scaling,
@@ -332,6 +333,9 @@ def main():
         "ndcg10_test": te_ndcg, "pairwise_error_test": te_err, "ndcg10_train": tr_ndcg, "pairwise_error_train": tr_err,
         "outer_iterations_run": args.warmup + args.steps, "objective": objs[-1],
         "inner_per_step": {k: v / args.steps for k, v in inner.items()},
+        # SURVEY 8d, kernel-level figure: ordered pairs swept per second over the EXECUTED sweep passes of a step
+        # (V side: gradient + Hessian-vector products + line-search objectives; U side the same per user, averaged)
+        "passes_per_step": passes, "sweep_pairs_per_s": value * passes, "s_per_iter": secs / args.steps,
         "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
     }
     if cpu:
