@@ -986,7 +986,8 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const i
 
 // out[j,:] = beta * base[j,:] + sum of the item's slab slots [item_slot[j], item_slot[j+1]); G lanes per item, items
 // strided over the grid.  DOTS (CG on one GPU, where out = Hp is final here and base = p): the kernel also leaves the
-// partials of p.Hp and rr.p of solve_delta_new (pcrpp.cpp:346) in part[blk][2], so no separate pass re-reads p, Hp, rr.
+// partials of p.Hp, rr.p, rr.Hp and Hp.Hp in part[blk][4] -- everything the CG scalars of this iteration need
+// (k_cg_bc) -- so no separate pass re-reads p, Hp, rr.
 template <typename T, int BLOCK, bool DOTS>
 __global__ __launch_bounds__(BLOCK) void k_spmm_fin(const T* __restrict__ slab, const int32_t* __restrict__ item_slot,
                                                     const T* __restrict__ base, double beta, int d2, T* __restrict__ out,
@@ -996,7 +997,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmm_fin(const T* __restrict__ slab, 
     __shared__ double red[BLOCK / PCR_WAVE + 1];
     if (skip && *skip) return;
     const int G = geo.G, g = threadIdx.x & (G - 1), ipb = BLOCK / G;
-    double x = 0.0, y = 0.0;
+    double x = 0.0, y = 0.0, z = 0.0, w = 0.0;
     for (int j = (int)blockIdx.x * ipb + (int)threadIdx.x / G; j < d2; j += (int)gridDim.x * ipb) {
         const int s0 = item_slot[j], s1 = item_slot[j + 1];
         for (int ch = g; ch < geo.nchunk; ch += G) {
@@ -1018,9 +1019,11 @@ __global__ __launch_bounds__(BLOCK) void k_spmm_fin(const T* __restrict__ slab, 
                 const V rv = *reinterpret_cast<const V*>(rr + (size_t)j * geo.ld + ch * VEC);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    const double pe = (double)velem(bv, e);
-                    x += pe * (double)op[e];
-                    y += (double)velem(rv, e) * pe;
+                    const double pe = (double)velem(bv, e), he = (double)op[e], re = (double)velem(rv, e);
+                    x += pe * he;
+                    y += re * pe;
+                    z += re * he;
+                    w += he * he;
                 }
             }
         }
@@ -1028,7 +1031,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmm_fin(const T* __restrict__ slab, 
     if (DOTS) {
         x = block_sum<BLOCK>(x, red);
         y = block_sum<BLOCK>(y, red);
-        if (threadIdx.x == 0) { part[2 * blockIdx.x] = x; part[2 * blockIdx.x + 1] = y; }
+        z = block_sum<BLOCK>(z, red);
+        w = block_sum<BLOCK>(w, red);
+        if (threadIdx.x == 0) { part[4 * blockIdx.x] = x; part[4 * blockIdx.x + 1] = y; part[4 * blockIdx.x + 2] = z; part[4 * blockIdx.x + 3] = w; }
     }
 }
 
@@ -1046,6 +1051,7 @@ __global__ void k_nop() {}
 // ---------------------------------------------------------------------------------------
 struct CGState {
     double g2, err, pHp, rp, alpha, rr2, rHp, beta;
+    double rr2buf[2];      // |rr|^2 after iteration k lives in rr2buf[k & 1] (double-buffered: readers and the writer of one launch never share a slot)
     int done, iters;
 };
 
@@ -1133,10 +1139,11 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_init_fin(const double* __re
         st->err = sqrt(a) * 0.01;            // pcrpp.cpp:340
         st->done = 0;
         st->iters = 0;
+        st->rr2buf[0] = a;                   // rr = -g
     }
 }
 
-// A: partials of p.Hp and rr.p
+// A (only when an all-reduce sits between k_spmm_fin and the dot products): partials of p.Hp, rr.p, rr.Hp, Hp.Hp
 template <typename T>
 __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_a(const T* __restrict__ p, const T* __restrict__ Hp, const T* __restrict__ rr,
                                                         int64_t n, int per_block, double* __restrict__ part,
@@ -1145,69 +1152,60 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_a(const T* __restrict__ p, 
     if (st->done) return;     // CG already converged: later iterations are queued but idle
     const int64_t lo = (int64_t)blockIdx.x * per_block;
     const int64_t hi = (lo + per_block < n) ? lo + per_block : n;
-    double x = 0.0, y = 0.0;
+    double x = 0.0, y = 0.0, z = 0.0, w = 0.0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) {
-        const double pv = (double)p[i];
-        const double h = (double)Hp[i];
-        x += pv * h;
-        y += (double)rr[i] * pv;
+        const double pv = (double)p[i], h = (double)Hp[i], r = (double)rr[i];
+        x += pv * h; y += r * pv; z += r * h; w += h * h;
     }
     x = block_sum<PCR_EW_BLOCK>(x, red);
     y = block_sum<PCR_EW_BLOCK>(y, red);
-    if (threadIdx.x == 0) { part[2 * blockIdx.x] = x; part[2 * blockIdx.x + 1] = y; }
+    z = block_sum<PCR_EW_BLOCK>(z, red);
+    w = block_sum<PCR_EW_BLOCK>(w, red);
+    if (threadIdx.x == 0) { part[4 * blockIdx.x] = x; part[4 * blockIdx.x + 1] = y; part[4 * blockIdx.x + 2] = z; part[4 * blockIdx.x + 3] = w; }
 }
 
-// B: alpha = -(rr.p)/(p.Hp); delta += alpha p; rr += alpha Hp; partials of rr.rr and rr.Hp
+// B + C of iteration k in ONE pass (pcrpp.cpp:346-356): alpha = -(rr.p)/(p.Hp); delta += alpha p; rr += alpha Hp; stop if
+// |rr| < err, else beta = (rr.Hp)/(p.Hp), p = -rr + beta p.  The two dot products of the NEW residual follow from the four
+// of the old one without touching the vectors again,
+//     |rr + a Hp|^2 = |rr|^2 + 2 a rr.Hp + a^2 Hp.Hp,      (rr + a Hp).Hp = rr.Hp + a Hp.Hp,
+// so beta and the stop test are known before the update and one kernel does what took two (and a grid-wide reduction
+// between them).  Every block reduces the short partial array identically: deterministic.
 template <typename T>
-__global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_b(const T* __restrict__ p, const T* __restrict__ Hp, T* __restrict__ rr,
-                                                        T* __restrict__ delta, int64_t n, int per_block, int nblk,
-                                                        const double* __restrict__ partA, double* __restrict__ partB, CGState* st) {
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_bc(T* __restrict__ p, const T* __restrict__ Hp, T* __restrict__ rr,
+                                                         T* __restrict__ delta, int64_t n, int per_block, int nblk,
+                                                         const double* __restrict__ part, CGState* st, int k) {
     __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
     if (st->done) return;     // CG already converged: later iterations are queued but idle
-    double pHp, rp;
-    reduce_partials2(partA, nblk, &pHp, &rp, red);
+    double s4[4];
+    for (int c = 0; c < 4; ++c) {
+        double x = 0.0;
+        for (int i = threadIdx.x; i < nblk; i += PCR_EW_BLOCK) x += part[4 * i + c];
+        s4[c] = block_sum<PCR_EW_BLOCK>(x, red);
+    }
+    const double pHp = s4[0], rp = s4[1], rHp0 = s4[2], HpHp = s4[3];
+    const double rr2_old = st->rr2buf[(k - 1) & 1];
     const double alpha = -1.0 * rp / pHp;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { st->pHp = pHp; st->rp = rp; st->alpha = alpha; st->iters += 1; }
+    double rr2 = rr2_old + 2.0 * alpha * rHp0 + alpha * alpha * HpHp;
+    rr2 = rr2 > 0.0 ? rr2 : 0.0;
+    const double rHp = rHp0 + alpha * HpHp;
+    const bool conv = sqrt(rr2) < st->err;                  // pcrpp.cpp:350
+    const double beta = rHp / pHp;
     const int64_t lo = (int64_t)blockIdx.x * per_block;
     const int64_t hi = (lo + per_block < n) ? lo + per_block : n;
-    double x = 0.0, y = 0.0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) {
         const double pv = (double)p[i], hv = (double)Hp[i];
         delta[i] = (T)((double)delta[i] + pv * alpha);
         const T rn = (T)((double)rr[i] + hv * alpha);
         rr[i] = rn;
-        x += (double)rn * (double)rn;
-        y += (double)rn * hv;
+        if (!conv) p[i] = (T)((double)rn * -1.0 + pv * beta);
     }
-    __syncthreads();
-    x = block_sum<PCR_EW_BLOCK>(x, red);
-    y = block_sum<PCR_EW_BLOCK>(y, red);
-    if (threadIdx.x == 0) { partB[2 * blockIdx.x] = x; partB[2 * blockIdx.x + 1] = y; }
-}
-
-// C: stop if |rr| < err, else beta = (rr.Hp)/(p.Hp); p = -rr + beta p
-template <typename T>
-__global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_c(T* __restrict__ p, const T* __restrict__ rr,
-                                                        int64_t n, int per_block, int nblk,
-                                                        const double* __restrict__ partB, CGState* st) {
-    __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
-    if (st->done) return;     // CG already converged: later iterations are queued but idle
-    double rr2, rHp;
-    reduce_partials2(partB, nblk, &rr2, &rHp, red);
-    const bool conv = sqrt(rr2) < st->err;                 // pcrpp.cpp:350
-    const double beta = rHp / st->pHp;
-    const int64_t lo = (int64_t)blockIdx.x * per_block;
-    const int64_t hi = (lo + per_block < n) ? lo + per_block : n;
-    if (!conv) {
-        for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) {
-            const T pn = (T)((double)rr[i] * -1.0 + (double)p[i] * beta);
-            p[i] = pn;
-        }
+    // The host queues all 10 iterations without waiting; once `done` is set every later kernel of the solve returns at
+    // once.  Blocks of THIS launch read `done` and rr2buf[(k-1)&1] only, which nobody writes during this launch.
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        st->pHp = pHp; st->rp = rp; st->alpha = alpha; st->rr2 = rr2; st->rHp = rHp; st->beta = beta;
+        st->rr2buf[k & 1] = rr2; st->iters += 1;
+        if (conv) st->done = 1;
     }
-    // The host queues all 10 iterations without waiting; once `done` is set every later kernel of
-    // the solve returns at once.  Blocks of THIS launch may see the flag early: harmless, because a
-    // converged k_cg_c changes nothing anyway (conv is the same in every block).
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { st->rr2 = rr2; st->rHp = rHp; st->beta = beta; if (conv) st->done = 1; }
 }
 
 // ---------------------------------------------------------------------------------------

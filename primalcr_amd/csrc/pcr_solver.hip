@@ -1098,8 +1098,7 @@ struct Solver final : pcr_solver {
             {
                 ProfScope ps(this, "cg");
                 if (!fused_dots) hipLaunchKernelGGL((k_cg_a<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, n, ew_per_block, d_partA.p, d_cg.p);
-                hipLaunchKernelGGL((k_cg_b<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, d_delta.p, n, ew_per_block, fused_dots ? fin_blocks() : ew_blocks, d_partA.p, d_partB.p, d_cg.p);
-                hipLaunchKernelGGL((k_cg_c<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_rr.p, n, ew_per_block, ew_blocks, d_partB.p, d_cg.p);
+                hipLaunchKernelGGL((k_cg_bc<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, d_delta.p, n, ew_per_block, fused_dots ? fin_blocks() : ew_blocks, d_partA.p, d_cg.p, k);
             }
             HIPCHK(hipGetLastError());
         }
