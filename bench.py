@@ -65,8 +65,8 @@ def algorithmic_bytes(slot, nnz_b, nu_b, d2, r, esz):
         return 3 * F_V
     if cls == "ustep":             # k_ustep: read ms,sitem,slvl,U,V; write U,objp
         return nnz_b * (esz + 4 + 2) + nu_b * 24 + 2 * F_U + F_V
-    if cls == "cg":                # k_cg_b + k_cg_c: read p,Hp,rr,delta, write rr,delta; read rr,p, write p
-        return 9 * F_V
+    if cls == "cg":                # k_cg_bc: read p,Hp,rr,delta, write delta,rr,p
+        return 7 * F_V
     return 0
 
 
