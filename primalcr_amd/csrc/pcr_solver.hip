@@ -142,8 +142,9 @@ struct Solver final : pcr_solver {
     // creation order across the whole process, and two streams on one queue serialise: which of ours collide depends on
     // what else the process created.  pick_lanes() measures it once and keeps up to 4 mutually independent streams
     // (lane[0] = the solver's stream); concurrent length classes are placed on lanes only.
-    hipStream_t lane[4] = {};
-    hipEvent_t ev_lane[4] = {};
+    static constexpr int MAXLANE = 8;
+    hipStream_t lane[MAXLANE] = {};
+    hipEvent_t ev_lane[MAXLANE] = {};
     int nlane = 1;
     ncclComm_t comm = nullptr;
     int ncu = 256;
@@ -240,7 +241,7 @@ struct Solver final : pcr_solver {
         if (h_counters) (void)hipHostFree(h_counters);
         for (int i = 0; i < NSIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
-        for (int i = 0; i < 4; ++i) if (ev_lane[i]) (void)hipEventDestroy(ev_lane[i]);
+        for (int i = 0; i < MAXLANE; ++i) if (ev_lane[i]) (void)hipEventDestroy(ev_lane[i]);
         if (hi) (void)hipStreamDestroy(hi);
         if (ev_hi) (void)hipEventDestroy(ev_hi);
         if (st) (void)hipStreamDestroy(st);
@@ -305,12 +306,13 @@ struct Solver final : pcr_solver {
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, prm.device) != hipSuccess || khz <= 0) khz = 100000;
         const long long ticks = (long long)khz * 300 / 1000;       // 300 us
-        for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&ev_lane[i], hipEventDisableTiming));
+        for (int i = 0; i < MAXLANE; ++i) HIPCHK(hipEventCreateWithFlags(&ev_lane[i], hipEventDisableTiming));
         lane[0] = st; nlane = 1;
         if (const char* e = getenv("PCR_LANES")) if (atoi(e) == 1) return PCR_OK;               // developer knob: no concurrency
         bool dummy = false;
         RC(shares_queue(st, side[0], ticks / 30, ev_lane[0], &dummy));                          // warm up: first launches are slow
-        for (int c = 0; c < NSIDE && nlane < 4; ++c) {
+        const int want = getenv("PCR_LANES") ? std::min(MAXLANE, std::max(1, atoi(getenv("PCR_LANES")))) : 4;
+        for (int c = 0; c < NSIDE && nlane < want; ++c) {
             bool clash = false;
             for (int l = 0; l < nlane && !clash; ++l) RC(shares_queue(lane[l], side[c], ticks, ev_lane[0], &clash));
             if (!clash) lane[nlane++] = side[c];
@@ -718,7 +720,7 @@ struct Solver final : pcr_solver {
         bool forked = false;
         // longest users first: their workgroups are the critical path and must not queue behind the many
         // short-user workgroups
-        bool used[4] = {false, false, false, false};
+        bool used[MAXLANE] = {};
         int next = 0;
         for (size_t ii = bs.size(); ii-- > 0;) {
             const size_t i = ii;
@@ -757,14 +759,14 @@ struct Solver final : pcr_solver {
         for (auto& b : ubins) if (!b.users.empty() && b.K <= 1) order.push_back(&b);
         if (order.empty()) return PCR_OK;
         std::stable_sort(order.begin() + nhead, order.end(), [](const Bin* a, const Bin* b) { return a->cap > b->cap; });
-        // plan: (class, stream) in launch order.  Streams: 0..3 = lane[], 4 = hi.
+        // plan: (class, stream) in launch order.  Streams: 0..MAXLANE-1 = lane[], MAXLANE = hi.
         std::vector<std::pair<int, int>> plan;
         static const char* sched = getenv("PCR_USTEP_SCHED");        // developer knob: "class:stream,..." (stream: 0-3 lane, h)
         if (sched && *sched) {
             for (const char* q = sched; *q;) {
                 int c = 0, used = 0; char ch = 0;
                 if (sscanf(q, "%d:%c%n", &c, &ch, &used) != 2) break;
-                const int sidx = ch == 'h' ? 4 : std::min(nlane - 1, std::max(0, ch - '0'));
+                const int sidx = ch == 'h' ? MAXLANE : std::min(nlane - 1, std::max(0, ch - '0'));
                 if (c >= 0 && c < (int)order.size()) plan.push_back({c, sidx});
                 q += used; if (*q == ',') ++q;
             }
@@ -773,15 +775,15 @@ struct Solver final : pcr_solver {
         // against 2.01 ms per iteration for this one -- durations measured side by side mislead it.)
         if (plan.size() != order.size()) {                            // default (also when the knob does not name every class)
             plan.clear();
-            for (size_t i = 0; i < nhead; ++i) plan.push_back({(int)i, 4});
+            for (size_t i = 0; i < nhead; ++i) plan.push_back({(int)i, MAXLANE});
             for (size_t i = nhead; i < order.size(); ++i) plan.push_back({(int)i, (int)((i - nhead) % nlane)});   // longest on the solver's stream
         }
         ProfScope wall(this, "wall:ustep", st);
-        bool used[5] = {false, false, false, false, false};
+        bool used[MAXLANE + 1] = {};
         HIPCHK(hipEventRecord(ev_fork, st));
         for (auto& pr : plan) {
             Bin& b = *order[pr.first];
-            hipStream_t q = pr.second == 4 ? hi : lane[pr.second];
+            hipStream_t q = pr.second == MAXLANE ? hi : lane[pr.second];
             if (q != st && !used[pr.second]) HIPCHK(hipStreamWaitEvent(q, ev_fork, 0));
             used[pr.second] = true;
             ProfScope ps(this, pname("ustep", b), q, b.nnz, (int64_t)b.users.size());
@@ -789,7 +791,7 @@ struct Solver final : pcr_solver {
         }
         for (int l = 1; l < nlane; ++l)
             if (used[l]) { HIPCHK(hipEventRecord(ev_lane[l], lane[l])); RC(join(ev_lane[l])); }
-        if (used[4]) { HIPCHK(hipEventRecord(ev_hi, hi)); RC(join(ev_hi)); }
+        if (used[MAXLANE]) { HIPCHK(hipEventRecord(ev_hi, hi)); RC(join(ev_hi)); }
         HIPCHK(hipGetLastError());
         return PCR_OK;
     }
