@@ -354,3 +354,28 @@ def test_pipelined_iterations_equal_the_step_by_step_loop(oracle):
         assert all(x["seconds"] > 0 for x in recs) and recs[2]["seconds"] > recs[0]["seconds"]
         Ua, Va = a.get_factors(); Ub, Vb = b.get_factors()
         assert np.array_equal(Ua, Ub) and np.array_equal(Va, Vb)
+
+
+def test_line_search_failure_quirks(oracle):
+    """q5: a V step whose 20 line-search tries all fail keeps V but hands the m of the LAST TRIED V_new to the U step
+    (pcrpp.cpp:430-431, :443); a U step whose tries all fail returns the last tried u (:794-814).  Forced with an absurd
+    initial step size; the next V step must rebuild its state (the U step's skipped users still carry the rejected one)."""
+    d1, d2, user, item, val = _mixed_set(seed=14, d1=120)
+    r, lam, step = 8, 20.0, float(2 ** 40)
+    X = oracle.build_csr(d1, d2, user, item, val)
+    U0 = oracle.initial(d1, r) * 0.3; V0 = oracle.initial(d2, r) * 0.3
+    ds = pcr.Dataset.from_triplets(d1, d2, user, item, val)
+    s = pcr.Solver(ds, pcr.Parameter(k=r, precision=pcr.PCR_F64, stepsize=step, **{"lambda": lam}))
+    s.set_factors(U0, V0)
+    U, V = U0, V0
+    for it in range(2):
+        Vn, m, objV, iv = oracle.update_V_new(X, lam, step, U, V)
+        gV, giv = s.update_V()
+        assert (giv["ls"], giv["accepted"], giv["cg"]) == (iv["ls"], iv["accepted"], iv["cg"]) and iv["accepted"] == 0 and iv["ls"] == 20
+        assert abs(gV / objV - 1) < 1e-9
+        assert rel(s.get_factors()[1], Vn) < 1e-12 and np.array_equal(Vn, V)          # V unchanged
+        Un, objU, iu = oracle.update_U_new(X, m, lam, step, Vn, U)
+        gU, giu = s.update_U()
+        assert (giu["cg"], giu["ls"]) == (iu["cg"], iu["ls"])
+        assert abs(gU / objU - 1) < 1e-9 and rel(s.get_factors()[0], Un) < 1e-9
+        U, V = Un, Vn
