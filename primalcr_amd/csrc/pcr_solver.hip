@@ -405,11 +405,16 @@ struct Solver final : pcr_solver {
         {
             if (const char* e = getenv("PCR_SPMM_CHUNK")) spmm_chunk = std::max(8, atoi(e));
             const size_t row_bytes = (size_t)geo.ld * sizeof(T);
-            const int64_t tile_users_max = std::max<int64_t>(64, (int64_t)((5u << 18) / row_bytes));
+            int64_t tile_users_max = std::max<int64_t>(64, (int64_t)((5u << 18) / row_bytes));
             int64_t ntiles = std::max<int64_t>(cdiv(nu, tile_users_max), std::min<int64_t>(8, nu / 256));
+            // ... but every (tile, item) pair with a rating costs a partial row in the slab: on a very wide, sparse item side
+            // (Yahoo-shaped: 136 k items) 1.25 MB tiles would hold ~5 ratings per pair and the slab would outweigh the
+            // gather.  Keep at least 16 ratings per pair on average (ml1m 32, Netflix shape 37: unaffected).
+            ntiles = std::min<int64_t>(ntiles, std::max<int64_t>(8, nnz_local / (16 * std::max<int64_t>(d2, 1))));
             if (ntiles > 1) ntiles = (ntiles + 7) / 8 * 8;             // every XCD the same number of tiles
             if (const char* e = getenv("PCR_SPMM_TILES")) if (atoi(e) > 0) ntiles = atoi(e);      // developer knob
             ntiles = std::max<int64_t>(1, std::min<int64_t>(ntiles, std::max<int64_t>(nu, 1)));
+            tile_users_max = std::max<int64_t>(tile_users_max, 2 * (int64_t)cdiv(nu, ntiles));       // (the density bound may ask for larger tiles)
             std::vector<int64_t> tile_u(1, 0);                       // user boundaries: equal ratings, at most tile_users_max users
             for (int64_t t = 1; t < ntiles; ++t) {
                 const int64_t want = nnz_local * t / ntiles;
