@@ -551,7 +551,9 @@ __device__ __forceinline__ int next_pow2(int n) { int p = 1; while (p < n) p <<=
 template <typename T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_sddmm(const T* __restrict__ U, const T* __restrict__ M,
                                                  const int32_t* __restrict__ ruser, const int32_t* __restrict__ rows,
-                                                 int64_t nnz, T* __restrict__ out, Geo geo, int tile, const int* skip) {
+                                                 int64_t nnz, T* __restrict__ out, Geo geo, int tile, const int* skip,
+                                                 const int32_t* __restrict__ perm, const int2* __restrict__ blk_map,
+                                                 const int32_t* __restrict__ chunk_ptr) {
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -560,8 +562,18 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(const T* __restrict__ U, const 
     const int span = ngrp * tile;
     int32_t* s_row = reinterpret_cast<int32_t*>(smem);
     int32_t* s_usr = s_row + span;
-    const int64_t b0 = (int64_t)blockIdx.x * span;
-    const int nb = (int)((nnz - b0 < span) ? (nnz - b0) : span);
+    // Default: workgroup b takes ratings [b * span, ...).  With blk_map (the XCD-aware workgroup -> chunk map of k_spmm) it
+    // takes the chunks of that map instead: the same kernel then walks the tile-major CSC, where the "sequential" side
+    // (U here) is the item table, the gathered side (M) the users of one L2-sized tile, and the result goes to
+    // out[perm[z]] -- for item tables far beyond the L2s (Yahoo-shaped data) the gather is then served by one XCD's L2.
+    int64_t b0 = (int64_t)blockIdx.x * span;
+    int nb = (int)((nnz - b0 < span) ? (nnz - b0) : span);
+    if (blk_map) {
+        const int2 bc = blk_map[blockIdx.x];
+        if (bc.y == 0) return;
+        b0 = chunk_ptr[bc.x];
+        nb = chunk_ptr[bc.x + bc.y] - (int)b0;
+    }
     for (int t = threadIdx.x; t < nb; t += BLOCK) { s_row[t] = rows[b0 + t]; s_usr[t] = ruser[b0 + t]; }
     __syncthreads();
     const int l0 = grp * tile;
@@ -629,14 +641,14 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(const T* __restrict__ U, const 
             if (G >= 8) {
                 const T tot = group_reduce8<T>(part, g, G);
                 const int q = q0 + rho;
-                if (g < 8 && q < l1) out[b0 + q] = (k == 0) ? tot : out[b0 + q] + tot;
+                if (g < 8 && q < l1) { const int64_t o = perm ? (int64_t)perm[b0 + q] : b0 + q; out[o] = (k == 0) ? tot : out[o] + tot; }
             } else {
 #pragma unroll
                 for (int e = 0; e < PCR_UNR; ++e) {
                     T v = part[e];
                     if (G > 2) v += __shfl_xor(v, 2);
                     if (G > 1) v += __shfl_xor(v, 1);
-                    if (g == 0 && q0 + e < l1) out[b0 + q0 + e] = (k == 0) ? v : out[b0 + q0 + e] + v;
+                    if (g == 0 && q0 + e < l1) { const int64_t o = perm ? (int64_t)perm[b0 + q0 + e] : b0 + q0 + e; out[o] = (k == 0) ? v : out[o] + v; }
                 }
             }
         }

@@ -157,6 +157,7 @@ struct Solver final : pcr_solver {
     DBuf<int32_t> d_item, d_cpos, d_runstart, d_sitem, d_cinv, d_cuser, d_crow, d_ruser, d_slot_base, d_item_slot, d_chunk_ptr, d_slot_id;
     DBuf<int2> d_blk_chunks;                      // k_spmm: first chunk and chunk count of every workgroup
     int spmm_blocks = 0, spmm_tiles = 1;
+    bool sddmm_csc = false;                       // the CG's SDDMM walks the SpMM's tile-major CSC (item table beyond the L2s)
     DBuf<T> d_slab;                               // k_spmm partial rows, one per (chunk, item) incidence
     int spmm_chunk = 128;
     DBuf<uint16_t> d_lvl, d_slvl;
@@ -482,6 +483,8 @@ struct Solver final : pcr_solver {
             RC(d_blk_chunks.upload(blk, st)); RC(d_item_slot.upload(item_slot, st));
             RC(d_slab.alloc((size_t)std::max<size_t>(inc_item.size(), 1) * geo.ld));
             spmm_tiles = (int)ntiles;
+            sddmm_csc = (size_t)d2 * geo.ld * sizeof(T) > ((size_t)32 << 20) && spmm_tiles >= 8;     // item table larger than all L2s together
+            if (const char* e = getenv("PCR_SDDMM_CSC")) sddmm_csc = atoi(e) != 0;                    // developer / test knob
         }
         make_bins(uptr, nu, &lv.run_ofs, bins);
         for (auto& b : bins) RC(b.d_users.upload(b.users, st));
@@ -830,7 +833,20 @@ struct Solver final : pcr_solver {
         static const int tile = getenv("PCR_SDDMM_TILE") ? atoi(getenv("PCR_SDDMM_TILE")) : 64;
         const int ngrp = 256 / geo.G, span = ngrp * tile;
         const int grid = cdiv(nnz_local, span);
-        hipLaunchKernelGGL((k_sddmm<T, 256>), dim3(grid), dim3(256), (size_t)span * 8, st, d_U.p, M, d_ruser.p, rows, nnz_local, out, geo, tile, skip);
+        hipLaunchKernelGGL((k_sddmm<T, 256>), dim3(grid), dim3(256), (size_t)span * 8, st, d_U.p, M, d_ruser.p, rows, nnz_local, out, geo, tile, skip,
+                           (const int32_t*)nullptr, (const int2*)nullptr, (const int32_t*)nullptr);
+        HIPCHK(hipGetLastError());
+        return PCR_OK;
+    }
+    // b[sorted position] = u_user . A[item] for all ratings, walked in the tile-major CSC order of k_spmm (k_sddmm with
+    // the roles swapped): for item tables far larger than the L2s.  Chosen by sddmm_by_tiles().
+    bool sddmm_by_tiles() const { return sddmm_csc; }
+    int launch_sddmm_csc(const T* A, T* out, const int* skip) {
+        if (nnz_local == 0) return PCR_OK;
+        ProfScope ps(this, "sddmm");
+        const int span = (256 / geo.G) * spmm_chunk;
+        hipLaunchKernelGGL((k_sddmm<T, 256>), dim3(spmm_blocks), dim3(256), (size_t)span * 8, st, A, d_U.p, d_crow.p, d_cuser.p, nnz_local, out, geo,
+                           spmm_chunk, skip, d_cinv.p, d_blk_chunks.p, d_chunk_ptr.p);
         HIPCHK(hipGetLastError());
         return PCR_OK;
     }
@@ -878,7 +894,7 @@ struct Solver final : pcr_solver {
     }
 
     int launch_vsweep(bool hv, const T* A, const int* skip = nullptr) {
-        if (hv) RC(launch_sddmm(A, d_sitem.p, d_b.p, skip));
+        if (hv) { if (sddmm_by_tiles()) RC(launch_sddmm_csc(A, d_b.p, skip)); else RC(launch_sddmm(A, d_sitem.p, d_b.p, skip)); }
         const bool two = hv && !sh.ws;                      // scores and sweep values both live in LDS (no window cache)
         auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();

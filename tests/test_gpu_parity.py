@@ -264,6 +264,7 @@ VARIANTS = [
     {"PCR_UBINS": "16:64:1,48:64:1,200:256:0,700:256:0"},        # other class bounds
     {"PCR_SPMM_TILES": "5"}, {"PCR_SPMM_TILES": "16"}, {"PCR_SPMM_TILES": "64"},   # user tiles of the SpMM (incl. more tiles than XCDs)
     {"PCR_LANES": "1"},                                          # every class on the solver's stream
+    {"PCR_SDDMM_CSC": "1"}, {"PCR_SDDMM_CSC": "1", "PCR_SPMM_TILES": "16"},   # the CG's SDDMM over the tile-major CSC (wide item tables)
 ]
 
 
