@@ -209,8 +209,6 @@ struct Solver final : pcr_solver {
     unsigned long long* h_counters = nullptr;     // pinned
     int ew_blocks = 1, ew_per_block = 1;          // elementwise decomposition over d2*ld
     bool have_sorted = false;
-    bool carry_obj_valid = false;                 // carry_obj = objective of the current (U, V) = the last U step's now_obj
-    double carry_obj = 0.0;
     bool state_of_rejected_V = false;             // the sorted state belongs to a V_new the line search did not accept (q5)
     double unorm2 = 0.0;                          // all-rank |U|^2 of the current U
     bool unorm_valid = false;
@@ -1005,20 +1003,20 @@ struct Solver final : pcr_solver {
 
     // loss (all ranks) of the last prepare + lambda/2 (|U|^2 + |Vm|^2)   (pcrpp.cpp:410)
     // d_scal[0] = sum objx (all ranks), [1] = |Vm|^2, [2] = |U|^2 (all ranks; only if with_u): one pass + one finish
-    int objective_sums(const double* objx, const T* Vm, bool with_u) {
+    int objective_sums(const double* objx, const T* Vm, bool with_u, int slot = 0) {
         const int64_t nV = (int64_t)d2 * geo.ld, nU = (int64_t)n_users * geo.ld;
         const int nb = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv(std::max(nV, nU), 4096)));
         hipLaunchKernelGGL((k_obj3<T>), dim3(nb), dim3(PCR_EW_BLOCK), 0, st, objx, n_users, Vm, nV, with_u ? d_U.p : (const T*)nullptr, nU, d_partA.p);
-        hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p);
+        hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + slot);
         HIPCHK(hipGetLastError());
-        RC(allreduce_f64(d_scal.p, 1));
-        if (with_u) RC(allreduce_f64(d_scal.p + 2, 1));
+        RC(allreduce_f64(d_scal.p + slot, 1));
+        if (with_u) RC(allreduce_f64(d_scal.p + slot + 2, 1));
         return PCR_OK;
     }
     int full_objective(const T* Vm, double* obj) {
         const bool need_u = !unorm_valid;                          // |U|^2 rides on the same pass and read-back
         RC(objective_sums(d_objp.p, Vm, need_u));
-        RC(fetch_scal(4));
+        RC(fetch_scal(8));                                         // slots 4..6: update_V's starting objective, queued earlier
         if (need_u) { unorm2 = h_scal[2]; unorm_valid = true; }
         *obj = h_scal[0] + prm.lambda * (unorm2 + h_scal[1]) / 2.0;
         return PCR_OK;
@@ -1045,7 +1043,7 @@ struct Solver final : pcr_solver {
     int set_factors(const double* U, const double* V) override {
         if (U) { RC(upload_mat(U + first_user * geo.r, n_users, d_U.p)); unorm_valid = false; }
         if (V) RC(upload_mat(V, d2, d_V.p));
-        have_sorted = false; state_of_rejected_V = false; carry_obj_valid = false;
+        have_sorted = false; state_of_rejected_V = false;
         return PCR_OK;
     }
     int get_factors(double* U, double* V) override {
@@ -1141,14 +1139,13 @@ struct Solver final : pcr_solver {
         int cg_iters = 0, tries = 0, accepted = 0;
         if (!have_sorted) RC(launch_prepare(d_V.p));      // comp_m_new (:417); after a U step its line search left exactly this state
         double prev_obj = 0.0;
-        // objective_new(m, U, V) (:425): right after a U step it is that step's now_obj (sum_i obj_u + lambda/2 |V|^2, :835) --
-        // the same quantity over the same m -- so no reduction + read-back of its own
-        // (pipelined loop: that U step may still be running; its objective is read at the line search's first read-back)
-        const bool prev_later = ustep_pending;
-        if (prev_later) {}
-        else if (carry_obj_valid && have_sorted) prev_obj = carry_obj;
-        else RC(full_objective(d_V.p, &prev_obj));
-        carry_obj_valid = false;
+        // objective_new(m, U, V) (:425) of the starting point: its three sums are QUEUED here -- by the same kernels, in the
+        // same summation order as the objectives of the line search, so that "no strict decrease" (q5) compares like with
+        // like exactly as in the reference -- and read back together with the first line-search objective: no host round
+        // trip of its own.  (After a U step the per-user losses in objp are the ones k_ustep left.)
+        const bool prev_u = !unorm_valid;
+        const double unorm2_before = unorm2;
+        RC(objective_sums(d_objp.p, d_V.p, prev_u, 4));
         RC(device_gradient());                                     // obtain_g_new (:418)
         // solve_delta_new (:422).  No host round trip when the line search's prepare is the single-launch form: everything
         // up to the objective read-back is stream-ordered.  (With the per-class launches the host waits for the CG first: a
@@ -1164,11 +1161,10 @@ struct Solver final : pcr_solver {
             RC(launch_prepare(d_Vnew.p));
             RC(full_objective(d_Vnew.p, &obj));
             if (!cg_sync) cg_iters = h_cg->iters;                 // that read-back synchronised the stream
+            if (it == 0) prev_obj = h_scal[4] + prm.lambda * ((prev_u ? h_scal[6] : unorm2_before) + h_scal[5]) / 2.0;
             if (ustep_pending) {                                   // ... and with it the U step queued before this V step
                 RC(ustep_finish(&fin_obj, fin_info));
                 fin_ready = true;
-                prev_obj = carry_obj;
-                carry_obj_valid = false;
             }
             ++tries;
             if (obj < prev_obj) {
@@ -1249,9 +1245,7 @@ struct Solver final : pcr_solver {
             }
         }
 #endif
-        carry_obj = h_uobj[0] + prm.lambda / 2.0 * h_uobj[1];      // :835
-        carry_obj_valid = have_sorted;
-        if (now_obj) *now_obj = carry_obj;
+        if (now_obj) *now_obj = h_uobj[0] + prm.lambda / 2.0 * h_uobj[1];      // :835
         if (h_counters[3] != 0) { pcr_set_error("k_ustep: a workgroup cluster timed out at a hand-off (members not co-resident?)"); return PCR_ERR_DEVICE; }
         if (info) { info[0] = (int64_t)h_counters[0]; info[1] = (int64_t)h_counters[1]; }
         return PCR_OK;

@@ -380,3 +380,40 @@ def test_line_search_failure_quirks(oracle):
         assert (giu["cg"], giu["ls"]) == (iu["cg"], iu["ls"])
         assert abs(gU / objU - 1) < 1e-9 and rel(s.get_factors()[0], Un) < 1e-9
         U, V = Un, Vn
+
+
+def test_fuzz_small_shapes_against_oracle(oracle):
+    """Seeded random shapes around the corners of the launch logic: ranks that are not multiples of 4, 1..12 rating
+    levels (window cache on and off), real-valued ratings, users of 0..700 ratings, both solvers; two outer iterations in
+    fp64 must follow the oracle's trajectory (objectives, inner counts, factors)."""
+    rng = np.random.default_rng(2026)
+    for case in range(80):
+        d1 = int(rng.integers(3, 60)); d2 = int(rng.integers(20, 900))
+        r = int(rng.choice([1, 2, 3, 5, 7, 8, 12, 17, 33, 64]))
+        nlev = int(rng.choice([1, 2, 3, 5, 9, 10, 12]))
+        solver = int(rng.choice([1, 2]))
+        real = bool(rng.integers(0, 2)) and nlev > 1
+        lam = float(rng.choice([0.5, 5.0, 50.0, 500.0]))
+        lens = np.minimum(rng.choice([0, 1, 2, 3, 10, 40, 64, 65, 130, 256, 257, 300, 700], d1), d2)
+        lens[rng.integers(0, d1)] = min(d2, 64)
+        user = np.repeat(np.arange(d1), lens)
+        item = np.concatenate([rng.choice(d2, n, replace=False) for n in lens]) if user.size else np.zeros(0, np.int64)
+        val = rng.integers(1, nlev + 1, user.shape[0]).astype(np.float64)
+        if real:
+            val = val + rng.uniform(-0.49, 0.49, val.shape[0])           # same lround bucket (solver 2), distinct doubles (solver 1)
+        if user.size == 0:
+            continue
+        X = oracle.build_csr(d1, d2, user, item, val)
+        U0 = oracle.initial(d1, r) * 0.4; V0 = oracle.initial(d2, r) * 0.4
+        Uo, Vo, recs = oracle.train(X, U0, V0, lam, 2, solver=solver, do_predict=0)
+        s = pcr.Solver(pcr.Dataset.from_triplets(d1, d2, user, item, val),
+                       pcr.Parameter(k=r, solver_type=solver, precision=pcr.PCR_F64, **{"lambda": lam}))
+        s.set_factors(U0, V0)
+        got = s.iterate(2)
+        tag = dict(case=case, d1=d1, d2=d2, r=r, nlev=nlev, solver=solver, real=real, lam=lam, nnz=int(user.size))
+        for g, o in zip(got, recs[1:]):
+            assert abs(g["obj"] - o["obj"]) <= 1e-9 * max(abs(o["obj"]), 1.0), (tag, g["obj"], o["obj"])
+            assert (g["cg_v"], g["ls_v"], g["cg_u"], g["ls_u"]) == (o["cg_v"], o["ls_v"], o["cg_u"], o["ls_u"]), tag
+        Ug, Vg = s.get_factors()
+        scale = max(np.abs(Uo).max(), np.abs(Vo).max(), 1e-3)            # (a side without any comparable pair is driven to ~1e-17)
+        assert np.abs(Ug - Uo).max() < 1e-7 * scale and np.abs(Vg - Vo).max() < 1e-7 * scale, tag
