@@ -417,3 +417,30 @@ def test_fuzz_small_shapes_against_oracle(oracle):
         Ug, Vg = s.get_factors()
         scale = max(np.abs(Uo).max(), np.abs(Vo).max(), 1e-3)            # (a side without any comparable pair is driven to ~1e-17)
         assert np.abs(Ug - Uo).max() < 1e-7 * scale and np.abs(Vg - Vo).max() < 1e-7 * scale, tag
+
+
+def test_fuzz_evaluator_against_oracle(oracle):
+    """compute_pairwise_error_ndcg (util.cpp:434-542) on seeded random shapes: 1..100 distinct rating values per user (the
+    O(len T log len) evaluator and the O(len^2) one for > 64 values), users of 0..700 ratings, non-positive real ratings
+    (NDCG may exceed 1 or be NaN in the reference, q8), ndcg_k 1..20.  Scores are generic (no exact ties: the reference
+    leaves the tie order of its unstable sort unspecified)."""
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        d1 = int(rng.integers(2, 50)); d2 = int(rng.integers(30, 900)); r = int(rng.choice([1, 3, 8, 16, 33]))
+        nval = int(rng.choice([1, 2, 5, 9, 30, 65, 100]))
+        lens = np.minimum(rng.choice([0, 1, 2, 5, 20, 64, 65, 129, 256, 300, 700], d1), d2)
+        lens[rng.integers(0, d1)] = min(d2, 40)
+        user = np.repeat(np.arange(d1), lens)
+        item = np.concatenate([rng.choice(d2, n, replace=False) for n in lens])
+        pool = np.sort(rng.uniform(-2.0, 5.0, nval)) if rng.integers(0, 2) else np.arange(1, nval + 1, dtype=np.float64)
+        val = pool[rng.integers(0, nval, user.shape[0])]
+        k = int(rng.choice([1, 5, 10, 20]))
+        X = oracle.build_csr(d1, d2, user, item, val)
+        U = rng.normal(size=(d1, r)); V = rng.normal(size=(d2, r))
+        s = pcr.Solver(pcr.Dataset.from_triplets(d1, d2, user, item, val), pcr.Parameter(k=r, precision=pcr.PCR_F64, ndcg_k=k))
+        s.set_factors(U, V)
+        e, n = s.evaluate(0, k)
+        eo, no = oracle.eval(U, V, X, k)
+        tag = dict(case=case, d1=d1, d2=d2, r=r, nval=nval, k=k)
+        assert abs(e - eo) < 1e-12, (tag, e, eo)
+        assert (np.isnan(n) and np.isnan(no)) or abs(n - no) < 1e-9 * max(1.0, abs(no)), (tag, n, no)
