@@ -139,3 +139,34 @@ def test_dataset_cache_roundtrip_and_staleness(tmp_path):
     h = pcr.Dataset.load(d, cache=cache)
     assert all(np.array_equal(x, y) for x, y in zip(h.csr(0), g.csr(0)))
     assert len(open(cache, "rb").read()) == len(raw)
+
+
+def test_rating_parser_is_correctly_rounded(tmp_path):
+    """The reference reads ratings with scanf("%lf") (util.h:118-131), i.e. glibc's correctly rounded strtod; the fast
+    decimal path of the threaded parser must give the same doubles bit for bit on every notation a data file may use."""
+    rng = np.random.default_rng(5)
+    vals = []
+    for _ in range(4000):
+        x = float(rng.choice([rng.uniform(-5, 5), rng.integers(-3, 6), rng.uniform(0, 1) * 10.0 ** rng.integers(-20, 20),
+                              rng.normal() * 1e-300, rng.normal() * 1e300]))
+        fmt = rng.choice(["%.17g", "%g", "%.3f", "%e", "%.20f", "%.1f", "%d" if float(x).is_integer() and abs(x) < 1e9 else "%.17g", "%.12e"])
+        vals.append(fmt % (int(x) if fmt == "%d" else x))
+    vals += ["0", "-0", "+3", "5.", ".5", "1e0", "1E+2", "2.5e-3", "123456789012345678", "0.1000000000000000055511151231257827",
+             "4.9e-324", "1.7976931348623157e308", "9007199254740993", "3.000000000000000000000000000001"]
+    n = len(vals)
+    d = tmp_path / "d"; d.mkdir()
+    with open(d / "training.ratings", "w") as f:
+        for z, s in enumerate(vals):
+            f.write(f"{z % 50 + 1} {z // 50 + 1} {s}\n")
+    open(d / "meta", "w").write(f"50 {n // 50 + 1}\n{n} training.ratings\n")
+    ds = pcr.Dataset.load(str(d))
+    idx, item, val = ds.csr(0)
+    got = {}
+    for u in range(50):
+        for z in range(idx[u], idx[u + 1]):
+            got[(u, int(item[z]))] = val[z]
+    for z, s in enumerate(vals):
+        want = float(s)
+        have = got[(z % 50, z // 50)]
+        assert have == want or (np.isnan(have) and np.isnan(want)), (s, have, want)
+        assert np.signbit(have) == np.signbit(want), s
