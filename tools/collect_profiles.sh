@@ -14,7 +14,9 @@ echo "[1/5] kernel trace"; rocprofv3 --kernel-trace --stats --output-format csv 
 echo "[2/5] pmc FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" --no-cpu --no-profile --steps 10 > /dev/null 2> "$OUT/pmc_fetch.err" || exit 1
 echo "[3/5] pmc WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" --no-cpu --no-profile --steps 10 > /dev/null 2> "$OUT/pmc_write.err" || exit 1
 echo "[3b] pmc occupancy"; rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_occ" -- python3 "$REPO/bench.py" --no-cpu --no-profile --steps 10 > /dev/null 2> "$OUT/pmc_occ.err" || exit 1
+echo "[3c] pmc instruction mix"; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d "$OUT/pmc_mix" -- python3 "$REPO/bench.py" --no-cpu --no-profile --steps 10 > /dev/null 2> "$OUT/pmc_mix.err" || exit 1
 cd "$REPO"
+python3 tools/pmc_mix.py "$OUT/pmc_mix" > "$OUT/pmc_mix_table.txt" || exit 1
 python3 tools/pmc_occupancy.py "$OUT/pmc_occ" "$OUT/pmc_occupancy_table.txt" > /dev/null || exit 1
 python3 tools/pmc_traffic.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/traffic.json" > "$OUT/pmc_traffic_table.txt" || exit 1
 cp "$OUT/traffic.json" profiles/r01_traffic.json      # bench.py reads the PMC figures from here

@@ -32,6 +32,12 @@ if os.path.exists(occ):
     shutil.copy(occ, os.path.join(dst, f"{tag}_pmc_occupancy_table.txt"))
     out += ["", "Achieved occupancy (`rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`, its own pass; PMC runs "
             "serialise the kernels, so the concurrent U-step classes are shown alone):", "", open(occ).read().rstrip()]
+mix = os.path.join(src, "pmc_mix_table.txt")
+if os.path.exists(mix):
+    shutil.copy(mix, os.path.join(dst, f"{tag}_pmc_mix_table.txt"))
+    out += ["", "Where the wave cycles go (`rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY "
+            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD`, its own pass): every kernel waits on memory for 43-87 % of its wave cycles",
+            "", open(mix).read().rstrip()]
 extra = f"{dst}/{tag}_extra.md"          # hand-written notes on runs outside bench.py (kept across regenerations)
 if os.path.exists(extra):
     out += ["", open(extra).read().rstrip()]
