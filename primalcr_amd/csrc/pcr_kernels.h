@@ -72,9 +72,23 @@ struct Shard {
 // wave / block primitives (wave = 64 lanes)
 // ---------------------------------------------------------------------------------------
 
+// lane ^ 1 and lane ^ 2 exchanges as DPP quad permutes (a VALU modifier: no LDS-pipe ds_bpermute, no address arithmetic)
+__device__ __forceinline__ int dpp_xor1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }    // quad_perm [1,0,3,2]
+__device__ __forceinline__ int dpp_xor2(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); }    // quad_perm [2,3,0,1]
+__device__ __forceinline__ float lane_xor1(float v) { return __int_as_float(dpp_xor1(__float_as_int(v))); }
+__device__ __forceinline__ float lane_xor2(float v) { return __int_as_float(dpp_xor2(__float_as_int(v))); }
+__device__ __forceinline__ double lane_xor1(double v) {
+    return __hiloint2double(dpp_xor1(__double2hiint(v)), dpp_xor1(__double2loint(v)));
+}
+__device__ __forceinline__ double lane_xor2(double v) {
+    return __hiloint2double(dpp_xor2(__double2hiint(v)), dpp_xor2(__double2loint(v)));
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    for (int off = 32; off > 2; off >>= 1) v += __shfl_xor(v, off);
+    v += lane_xor2(v);
+    v += lane_xor1(v);
     return v;
 }
 
@@ -339,12 +353,12 @@ __device__ __forceinline__ T group_reduce8(const T (&a)[8], int g, int G) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const T send = b0 ? a[i] : a[i + 4], keep = b0 ? a[i + 4] : a[i];
-        b[i] = keep + __shfl_xor(send, 1);
+        b[i] = keep + lane_xor1(send);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const T send = b1 ? b[i] : b[i + 2], keep = b1 ? b[i + 2] : b[i];
-        c[i] = keep + __shfl_xor(send, 2);
+        c[i] = keep + lane_xor2(send);
     }
     {
         const T send = b2 ? c[0] : c[1], keep = b2 ? c[1] : c[0];
@@ -364,11 +378,11 @@ __device__ __forceinline__ T group_reduce4(const T (&a)[4], int g, int G) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const T send = b0 ? a[i] : a[i + 2], keep = b0 ? a[i + 2] : a[i];
-        b[i] = keep + __shfl_xor(send, 1);
+        b[i] = keep + lane_xor1(send);
     }
     {
         const T send = b1 ? b[0] : b[1], keep = b1 ? b[1] : b[0];
-        d = keep + __shfl_xor(send, 2);
+        d = keep + lane_xor2(send);
     }
     if (G > 4) d += __shfl_xor(d, 4);
     if (G > 8) d += __shfl_xor(d, 8);
