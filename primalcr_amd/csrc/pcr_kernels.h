@@ -75,6 +75,26 @@ struct Shard {
 // lane ^ 1 and lane ^ 2 exchanges as DPP quad permutes (a VALU modifier: no LDS-pipe ds_bpermute, no address arithmetic)
 __device__ __forceinline__ int dpp_xor1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }    // quad_perm [1,0,3,2]
 __device__ __forceinline__ int dpp_xor2(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); }    // quad_perm [2,3,0,1]
+// lane ^ 4, ^ 8: ds_swizzle in bit mode (LDS crossbar, but no address VGPR and no address arithmetic);
+// lane ^ 16, ^ 32: gfx950's v_permlane16_swap / v_permlane32_swap (VALU) + a select.  (tools/ubench/xor_probe.hip)
+__device__ __forceinline__ int swz_xor4(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x101F); }
+__device__ __forceinline__ int swz_xor8(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x201F); }
+__device__ __forceinline__ int perm_xor16(int v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (threadIdx.x & 16) ? (int)r[0] : (int)r[1];
+}
+__device__ __forceinline__ int perm_xor32(int v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (threadIdx.x & 32) ? (int)r[0] : (int)r[1];
+}
+template <int OFF> __device__ __forceinline__ int lane_xor_i(int v) {
+    static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "power of two below 64");
+    return OFF == 1 ? dpp_xor1(v) : OFF == 2 ? dpp_xor2(v) : OFF == 4 ? swz_xor4(v) : OFF == 8 ? swz_xor8(v) : OFF == 16 ? perm_xor16(v) : perm_xor32(v);
+}
+template <int OFF> __device__ __forceinline__ float lane_xor(float v) { return __int_as_float(lane_xor_i<OFF>(__float_as_int(v))); }
+template <int OFF> __device__ __forceinline__ double lane_xor(double v) {
+    return __hiloint2double(lane_xor_i<OFF>(__double2hiint(v)), lane_xor_i<OFF>(__double2loint(v)));
+}
 __device__ __forceinline__ float lane_xor1(float v) { return __int_as_float(dpp_xor1(__float_as_int(v))); }
 __device__ __forceinline__ float lane_xor2(float v) { return __int_as_float(dpp_xor2(__float_as_int(v))); }
 __device__ __forceinline__ double lane_xor1(double v) {
@@ -85,8 +105,7 @@ __device__ __forceinline__ double lane_xor2(double v) {
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 2; off >>= 1) v += __shfl_xor(v, off);
+    v += lane_xor<32>(v); v += lane_xor<16>(v); v += lane_xor<8>(v); v += lane_xor<4>(v);
     v += lane_xor2(v);
     v += lane_xor1(v);
     return v;
@@ -362,11 +381,11 @@ __device__ __forceinline__ T group_reduce8(const T (&a)[8], int g, int G) {
     }
     {
         const T send = b2 ? c[0] : c[1], keep = b2 ? c[1] : c[0];
-        d = keep + __shfl_xor(send, 4);
+        d = keep + lane_xor<4>(send);
     }
-    if (G > 8) d += __shfl_xor(d, 8);
-    if (G > 16) d += __shfl_xor(d, 16);
-    if (G > 32) d += __shfl_xor(d, 32);
+    if (G > 8) d += lane_xor<8>(d);
+    if (G > 16) d += lane_xor<16>(d);
+    if (G > 32) d += lane_xor<32>(d);
     return d;
 }
 
@@ -384,10 +403,10 @@ __device__ __forceinline__ T group_reduce4(const T (&a)[4], int g, int G) {
         const T send = b1 ? b[0] : b[1], keep = b1 ? b[1] : b[0];
         d = keep + lane_xor2(send);
     }
-    if (G > 4) d += __shfl_xor(d, 4);
-    if (G > 8) d += __shfl_xor(d, 8);
-    if (G > 16) d += __shfl_xor(d, 16);
-    if (G > 32) d += __shfl_xor(d, 32);
+    if (G > 4) d += lane_xor<4>(d);
+    if (G > 8) d += lane_xor<8>(d);
+    if (G > 16) d += lane_xor<16>(d);
+    if (G > 32) d += lane_xor<32>(d);
     return d;
 }
 
