@@ -104,6 +104,27 @@ __device__ __forceinline__ double lane_xor2(double v) {
     return __hiloint2double(dpp_xor2(__double2hiint(v)), dpp_xor2(__double2loint(v)));
 }
 
+// wave-wide inclusive scan with DPP only: Kogge-Stone inside each 16-lane row (row_shr 1, 2, 4, 8, zero fill), then lane 15
+// of rows 0 / 2 added to rows 1 / 3 (row_bcast15) and lane 31 to rows 2, 3 (row_bcast31): 6 VALU steps, no LDS crossbar
+// (tools/ubench/scan_probe.hip)
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_zero_fill(double v) {
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_incl_scan(double v) {
+    v += dpp_zero_fill<0x111, 0xF>(v);
+    v += dpp_zero_fill<0x112, 0xF>(v);
+    v += dpp_zero_fill<0x114, 0xF>(v);
+    v += dpp_zero_fill<0x118, 0xF>(v);
+    v += dpp_zero_fill<0x142, 0xA>(v);
+    v += dpp_zero_fill<0x143, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ double lane63(double v) {            // the last lane's value, wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
     v += lane_xor<32>(v); v += lane_xor<16>(v); v += lane_xor<8>(v); v += lane_xor<4>(v);
     v += lane_xor2(v);
@@ -147,12 +168,7 @@ __device__ __forceinline__ void block_excl_scan(F f, double* out, int n, double*
     for (int base = 0; base < n; base += BLOCK) {
         const int i = base + tid;
         const double v = (i < n) ? f(i) : 0.0;
-        double inc = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            double t = __shfl_up(inc, off);
-            if (lane >= off) inc += t;
-        }
+        const double inc = wave_incl_scan(v);
         double woff = 0.0, total;
         if (BLOCK > PCR_WAVE) {
             __syncthreads();
@@ -166,7 +182,7 @@ __device__ __forceinline__ void block_excl_scan(F f, double* out, int n, double*
                 total += x;
             }
         } else {
-            total = __shfl(inc, 63);
+            total = lane63(inc);
         }
         if (i < n) out[i] = carry + woff + inc - v;
         carry += total;
@@ -900,14 +916,9 @@ __device__ __forceinline__ void vsweep_wave_body(char* smem, const Shard<T>& S, 
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         const double v = (i < n) ? (double)xs[i] : 0.0;
-        double inc = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const double t = __shfl_up(inc, off);
-            if (lane >= off) inc += t;
-        }
+        const double inc = wave_incl_scan(v);
         if (i < n) Sx[i] = carry + inc - v;
-        carry += __shfl(inc, 63);
+        carry += lane63(inc);
     }
     if (lane == 0) Sx[n] = carry;
     wave_sync();
