@@ -975,7 +975,7 @@ __global__ __launch_bounds__(512) void k_vsweep_all(Shard<T> S, const int32_t* _
 // ---------------------------------------------------------------------------------------
 template <typename T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const int32_t* __restrict__ cinv,
-                                                const int32_t* __restrict__ cuser, const int32_t* __restrict__ crow,
+                                                const int32_t* __restrict__ cuf,
                                                 const int32_t* __restrict__ chunk_ptr, const int32_t* __restrict__ inc_base,
                                                 const int32_t* __restrict__ slot_id, const int2* __restrict__ blk_chunks,
                                                 const T* __restrict__ U, T* __restrict__ slab, Geo geo, const int* skip) {
@@ -996,7 +996,6 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const i
         T acc[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] = (T)0;
-        int cur = crow[z0];
         int inc = inc_base[gid];
         auto flush = [&]() {
             if (act) {
@@ -1011,26 +1010,25 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const i
         for (int64_t zb = z0; zb < z1; zb += G) {
             const int64_t zi = zb + g;
             T cr = (T)0;
-            int ur = 0, jr = 0;
-            if (zi < z1) { cr = c[cinv[zi]]; ur = cuser[zi]; jr = crow[zi]; }
+            int ur = 0;
+            if (zi < z1) { cr = c[cinv[zi]]; ur = cuf[zi]; }            // user id; sign bit: a new item starts here (not at the chunk start)
             const int cnt = (int)((z1 - zb < G) ? (z1 - zb) : G);
             for (int q = 0; q < cnt; q += PCR_UNR) {
                 V rv[PCR_UNR];
                 T cc[PCR_UNR];
-                int jj[PCR_UNR];
+                int uf[PCR_UNR];
 #pragma unroll
                 for (int e8 = 0; e8 < PCR_UNR; ++e8) {
                     if (q + e8 < cnt) {
                         cc[e8] = __shfl(cr, q + e8, G);
-                        const int uu = __shfl(ur, q + e8, G);
-                        jj[e8] = __shfl(jr, q + e8, G);
-                        if (act) rv[e8] = *reinterpret_cast<const V*>(U + (size_t)uu * geo.ld + ch * VEC);
+                        uf[e8] = __shfl(ur, q + e8, G);
+                        if (act) rv[e8] = *reinterpret_cast<const V*>(U + (size_t)(uf[e8] & 0x7fffffff) * geo.ld + ch * VEC);
                     }
                 }
 #pragma unroll
                 for (int e8 = 0; e8 < PCR_UNR; ++e8) {
                     if (q + e8 < cnt) {
-                        if (jj[e8] != cur) { flush(); cur = jj[e8]; }
+                        if (uf[e8] < 0) flush();
                         if (act) {
 #pragma unroll
                             for (int e = 0; e < VEC; ++e) acc[e] += cc[e8] * velem(rv[e8], e);

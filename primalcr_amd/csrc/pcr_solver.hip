@@ -156,6 +156,7 @@ struct Solver final : pcr_solver {
     DBuf<double> d_objr;
     DBuf<int32_t> d_item, d_cpos, d_runstart, d_sitem, d_cinv, d_cuser, d_crow, d_ruser, d_slot_base, d_item_slot, d_chunk_ptr, d_slot_id;
     DBuf<int2> d_blk_chunks;                      // k_spmm: first chunk and chunk count of every workgroup
+    DBuf<int32_t> d_cuf;                          // k_spmm: user id | new-item flag per CSC entry
     int spmm_blocks = 0, spmm_tiles = 1;
     bool sddmm_csc = false;                       // the CG's SDDMM walks the SpMM's tile-major CSC (item table beyond the L2s)
     DBuf<T> d_slab;                               // k_spmm partial rows, one per (chunk, item) incidence
@@ -477,6 +478,13 @@ struct Solver final : pcr_solver {
             for (int x = 0; x < 8; ++x)
                 for (size_t i = 0; i < per_xcd[x].size(); ++i) blk[i * 8 + x] = per_xcd[x][i];
             spmm_blocks = (int)blk.size();
+            {   // k_spmm's per-entry word: the user id, and in the sign bit "a new item starts here" (never at a chunk start)
+                std::vector<int32_t> cuf(cuser);
+                for (int64_t c = 0; c < nchunks; ++c)
+                    for (int64_t z = (int64_t)chunk_ptr[c] + 1; z < chunk_ptr[c + 1]; ++z)
+                        if (crow[z] != crow[z - 1]) cuf[z] |= (int32_t)0x80000000;
+                RC(d_cuf.upload(cuf, st));
+            }
             RC(d_chunk_ptr.upload(chunk_ptr, st)); RC(d_slot_base.upload(inc_base, st)); RC(d_slot_id.upload(slot_id, st));
             RC(d_blk_chunks.upload(blk, st)); RC(d_item_slot.upload(item_slot, st));
             RC(d_slab.alloc((size_t)std::max<size_t>(inc_item.size(), 1) * geo.ld));
@@ -940,7 +948,7 @@ struct Solver final : pcr_solver {
     int launch_spmm(T* out, const T* base, double beta, const int* skip = nullptr, const T* dots_rr = nullptr) {
         if (nnz_local > 0) {
             ProfScope ps(this, "spmm");
-            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(spmm_blocks), dim3(256), 0, st, d_c.p, d_cinv.p, d_cuser.p, d_crow.p,
+            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(spmm_blocks), dim3(256), 0, st, d_c.p, d_cinv.p, d_cuf.p,
                                d_chunk_ptr.p, d_slot_base.p, d_slot_id.p, d_blk_chunks.p, d_U.p, d_slab.p, geo, skip);
         }
         ProfScope ps2(this, "spmm_fin");
