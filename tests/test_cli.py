@@ -144,3 +144,26 @@ def test_cache_and_snapshots(tmp_path):
     assert not (tmp_path / "c2.model.iter1").exists() and not (tmp_path / "c2.model.iter3").exists()
     iters = lambda s: [re.sub(r"time \S+", "time T", l) for l in s.split("\n") if l.startswith("Iter ")]
     assert iters(plain.stdout) == iters(first.stdout) == iters(second.stdout)[:3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,args", [("s2_l5000", ["-s", "2", "-l", "5000"]), ("s2_l50", ["-s", "2", "-l", "50"]), ("s1_l50", ["-s", "1", "-l", "50"])])
+def test_train_cli_on_the_references_own_ml1m_ratings(tag, args, tmp_path):
+    """The reference's shipped ml1m/test.ratings (real MovieLens ratings) as training and test set: our omp-pmf-train --f64
+    must print the lines the unmodified reference prints (objective 187 644 = #Omega at lambda 5000,
+    NDCG@10 0.979346 at lambda 50) to the 6 printed digits."""
+    import json
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ml1m_test.npz"))
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "ml1m_test.json")))
+    u, i, v = g["user"].astype(np.int32), g["item"].astype(np.int32), g["val"].astype(np.float64)
+    R = synth.Ratings(meta["d1"], meta["d2"], u, i, v, u, i, v)
+    d = synth.write_dir(R, str(tmp_path / "data"))
+    out = run([TRAIN, *args, "-k", str(meta["k"]), "-n", "1", "-t", str(meta["iters"]), "-p", "1", "--f64", d, "m.model"], tmp_path)
+    assert out.returncode == 0, out.stderr
+    pick = lambda s: [l for l in s.split("\n") if l.startswith(("Iter", "(T"))]
+    ours, theirs = pick(out.stdout), pick(meta["stdout"][tag])
+    assert len(ours) == len(theirs) == 3 * (meta["iters"] + 1)
+    for a, b in zip(ours, theirs):
+        a = re.sub(r"time \S+", "time T", a); b = re.sub(r"time \S+", "time T", b)
+        assert re.sub(NUM, "#", a) == re.sub(NUM, "#", b), (a, b)
+        assert np.allclose([float(x) for x in re.findall(NUM, a)], [float(x) for x in re.findall(NUM, b)], rtol=6e-6, atol=6e-6), (a, b)

@@ -1,11 +1,12 @@
 """CPU tests: pin the C restatement (oracle/pcr_oracle.c) against golden vectors dumped from
 the unmodified reference (oracle/make_golden.py -> tests/golden/).  No GPU, no /root/reference."""
+import os
 import re
 
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, golden_csr, load_golden
+from conftest import GOLDEN_CASES, ROOT, golden_csr, load_golden
 
 RT = 1e-11   # the restatement follows the reference's loop order; only sort-tie order may differ
 
@@ -138,3 +139,35 @@ def test_known_answer_zero_model_counts_pairs(oracle):
     m = oracle.comp_m(U, V, X)
     assert oracle.objective_new(m, U, V, X, 5000.0) == float(g["n_pairs"]) == oracle.count_pairs(X)
     assert oracle.objective_new(m, U, V, X, 5000.0, solver=1) == float(g["n_pairs"])
+
+
+def _ml1m_test_case():
+    import json
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ml1m_test.npz"))
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "ml1m_test.json")))
+    return g["user"].astype(np.int64), g["item"].astype(np.int64), g["val"].astype(np.float64), meta
+
+
+def _printed(stdout):
+    import re
+    it = [float(x) for x in re.findall(r"^Iter \d+ time \S+ obj (\S+)$", stdout, re.M)]
+    ev = [(t, float(a), float(b)) for t, a, b in re.findall(r"^\((Training|Testing)\) pairwise error is (\S+) and ndcg is (\S+)$", stdout, re.M)]
+    return it, ev
+
+
+@pytest.mark.parametrize("tag,solver,lam", [("s2_l5000", 2, 5000.0), ("s2_l50", 2, 50.0), ("s1_l50", 1, 50.0)])
+def test_oracle_on_the_references_own_ml1m_ratings(oracle, tag, solver, lam):
+    """The only real MovieLens data the reference ships (ml1m/test.ratings, used as training and test set): the known
+    answers of BASELINE.md section 2 (objective 187 644 = #Omega at lambda 5000; NDCG@10 0.979346 at lambda 50), as printed
+    by the unmodified reference binary with -n 1."""
+    user, item, val, meta = _ml1m_test_case()
+    X = oracle.build_csr(meta["d1"], meta["d2"], user, item, val)
+    U0 = oracle.initial(meta["d1"], meta["k"]); V0 = oracle.initial(meta["d2"], meta["k"])
+    _, _, recs = oracle.train(X, U0, V0, lam, meta["iters"], XT=X, solver=solver, do_predict=1)
+    objs, evs = _printed(meta["stdout"][tag])
+    assert len(objs) == meta["iters"] + 1
+    for r, o in zip(recs, objs):
+        assert abs(r["obj"] / o - 1) < 6e-6                       # 6 printed digits (%g)
+    for r, (tr, te) in zip(recs, zip(evs[0::2], evs[1::2])):
+        assert abs(r["train_err"] - tr[1]) < 6e-6 and abs(r["train_ndcg"] - tr[2]) < 6e-6
+        assert abs(r["test_err"] - te[1]) < 6e-6 and abs(r["test_ndcg"] - te[2]) < 6e-6
