@@ -147,14 +147,15 @@ def test_cache_and_snapshots(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,args", [("s2_l5000", ["-s", "2", "-l", "5000"]), ("s2_l50", ["-s", "2", "-l", "50"]), ("s1_l50", ["-s", "1", "-l", "50"])])
-def test_train_cli_on_the_references_own_ml1m_ratings(tag, args, tmp_path):
-    """The reference's shipped ml1m/test.ratings (real MovieLens ratings) as training and test set: our omp-pmf-train --f64
-    must print the lines the unmodified reference prints (objective 187 644 = #Omega at lambda 5000,
-    NDCG@10 0.979346 at lambda 50) to the 6 printed digits."""
+@pytest.mark.parametrize("name,tag,args", [("ml1m_test", "s2_l5000", ["-s", "2", "-l", "5000"]), ("ml1m_test", "s2_l50", ["-s", "2", "-l", "50"]),
+                                           ("ml1m_test", "s1_l50", ["-s", "1", "-l", "50"]), ("toy_test", "s2", ["-s", "2"]), ("toy_test", "s1", ["-s", "1"])])
+def test_train_cli_on_the_references_own_rating_files(name, tag, args, tmp_path):
+    """The rating files the reference ships (ml1m/test.ratings: real MovieLens ratings; toy-example/test.ratings: real-valued
+    ratings, configs[0]) as training and test set: our omp-pmf-train --f64 must print the lines the unmodified reference prints
+    (objective 187 644 = #Omega at lambda 5000, NDCG@10 0.979346 at lambda 50) to the 6 printed digits."""
     import json
-    g = np.load(os.path.join(ROOT, "tests", "golden", "ml1m_test.npz"))
-    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "ml1m_test.json")))
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", name + ".json")))
     u, i, v = g["user"].astype(np.int32), g["item"].astype(np.int32), g["val"].astype(np.float64)
     R = synth.Ratings(meta["d1"], meta["d2"], u, i, v, u, i, v)
     d = synth.write_dir(R, str(tmp_path / "data"))
@@ -163,7 +164,14 @@ def test_train_cli_on_the_references_own_ml1m_ratings(tag, args, tmp_path):
     pick = lambda s: [l for l in s.split("\n") if l.startswith(("Iter", "(T"))]
     ours, theirs = pick(out.stdout), pick(meta["stdout"][tag])
     assert len(ours) == len(theirs) == 3 * (meta["iters"] + 1)
+    # toy_test: 112 of the 1500 users have all their (real-valued) ratings in ONE lround bucket: no comparable pair, PrimalCR++
+    # drives their u to ~1e-17 of rounding noise, and the evaluator -- which compares RAW ratings -- then ranks their 2-4 items
+    # by the sign of that noise.  The reference's printed metrics contain that noise (the oracle reproduces it only because it
+    # repeats the reference's operation order bit for bit); any other summation order moves them by up to ~112/1500 * 1/2.
+    # PrimalCR keeps those users' u (cc == 0, pcr.cpp:552), so its lines and every objective line are compared exactly.
+    noisy = name == "toy_test" and tag == "s2"
     for a, b in zip(ours, theirs):
         a = re.sub(r"time \S+", "time T", a); b = re.sub(r"time \S+", "time T", b)
         assert re.sub(NUM, "#", a) == re.sub(NUM, "#", b), (a, b)
-        assert np.allclose([float(x) for x in re.findall(NUM, a)], [float(x) for x in re.findall(NUM, b)], rtol=6e-6, atol=6e-6), (a, b)
+        tol = 4e-2 if (noisy and a.startswith("(T")) else 6e-6
+        assert np.allclose([float(x) for x in re.findall(NUM, a)], [float(x) for x in re.findall(NUM, b)], rtol=tol, atol=tol), (a, b)

@@ -141,10 +141,10 @@ def test_known_answer_zero_model_counts_pairs(oracle):
     assert oracle.objective_new(m, U, V, X, 5000.0, solver=1) == float(g["n_pairs"])
 
 
-def _ml1m_test_case():
+def _shipped_case(name="ml1m_test"):
     import json
-    g = np.load(os.path.join(ROOT, "tests", "golden", "ml1m_test.npz"))
-    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "ml1m_test.json")))
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", name + ".json")))
     return g["user"].astype(np.int64), g["item"].astype(np.int64), g["val"].astype(np.float64), meta
 
 
@@ -155,12 +155,14 @@ def _printed(stdout):
     return it, ev
 
 
-@pytest.mark.parametrize("tag,solver,lam", [("s2_l5000", 2, 5000.0), ("s2_l50", 2, 50.0), ("s1_l50", 1, 50.0)])
-def test_oracle_on_the_references_own_ml1m_ratings(oracle, tag, solver, lam):
-    """The only real MovieLens data the reference ships (ml1m/test.ratings, used as training and test set): the known
-    answers of BASELINE.md section 2 (objective 187 644 = #Omega at lambda 5000; NDCG@10 0.979346 at lambda 50), as printed
-    by the unmodified reference binary with -n 1."""
-    user, item, val, meta = _ml1m_test_case()
+@pytest.mark.parametrize("name,tag,solver,lam", [("ml1m_test", "s2_l5000", 2, 5000.0), ("ml1m_test", "s2_l50", 2, 50.0),
+                                                 ("ml1m_test", "s1_l50", 1, 50.0), ("toy_test", "s2", 2, 5000.0), ("toy_test", "s1", 1, 5000.0)])
+def test_oracle_on_the_references_own_rating_files(oracle, name, tag, solver, lam):
+    """The rating files the reference ships, used as training and test set, as printed by the unmodified binary with -n 1:
+    ml1m/test.ratings (real MovieLens ratings; the known answers of BASELINE.md section 2: objective 187 644 = #Omega at
+    lambda 5000, NDCG@10 0.979346 at lambda 50) and toy-example/test.ratings (real-valued ratings: 9 lround levels,
+    non-positive gains, NDCG beyond 1 -- configs[0])."""
+    user, item, val, meta = _shipped_case(name)
     X = oracle.build_csr(meta["d1"], meta["d2"], user, item, val)
     U0 = oracle.initial(meta["d1"], meta["k"]); V0 = oracle.initial(meta["d2"], meta["k"])
     _, _, recs = oracle.train(X, U0, V0, lam, meta["iters"], XT=X, solver=solver, do_predict=1)
