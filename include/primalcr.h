@@ -65,6 +65,12 @@ typedef struct pcr_params {
     /* extensions */
     int precision;     /* PCR_F32 (default) | PCR_F64                             */
     int device;        /* HIP device ordinal, default 0                           */
+    /* truncated-Newton knobs: the reference hard-codes 10 CG iterations at
+     * most and a residual tolerance of 1 % of ||g|| for both half steps
+     * (pcrpp.cpp:340,344 / :632,636).  cg_max_iter = r with a small cg_tol turns the U
+     * step into an exact Newton step.  The defaults reproduce the reference.   */
+    int cg_max_iter;   /* default 10                                              */
+    double cg_tol;     /* default 0.01                                            */
 } pcr_params;
 
 /* pmf.h:27-48 parameter::parameter() */

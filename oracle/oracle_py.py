@@ -101,6 +101,11 @@ class Oracle:
         self.lib.orc_initial(X, n, k)
         return X
 
+    def set_cg(self, max_iter=10, tol=0.01):
+        """CG cap / tolerance of every solve (the reference's constants by default); process-global."""
+        self.lib.orc_set_cg.argtypes = [C.c_int, C.c_double]
+        self.lib.orc_set_cg(max_iter, tol)
+
     def build_csr(self, d1, d2, user, item, val):
         nnz = len(user)
         idx = np.empty(d1 + 1, np.int64); it = np.empty(nnz, np.int64); v = np.empty(nnz, np.float64)

@@ -387,14 +387,20 @@ void orc_compute_Ha_new(const double *a, const double *m, const double *U,
  * (:628-647) / pcr.cpp:248-277, :498-520, parameterised by the Hv callback. */
 typedef void (*hv_fn)(const double *p, double *Hp, void *ctx);
 
+/* The reference hard-codes 10 iterations and 1 % (:340,344); tests of the product's cg_max_iter /
+ * cg_tol extension (include/primalcr.h) move them with orc_set_cg. */
+static int g_cg_max = 10;
+static double g_cg_tol = 0.01;
+void orc_set_cg(int max_iter, double tol) { g_cg_max = max_iter; g_cg_tol = tol; }
+
 static int cg_solve(const double *g, long n, hv_fn hv, void *ctx, double *delta) {
     double *rr = (double *)malloc((size_t)n * sizeof(double));
     double *p = (double *)malloc((size_t)n * sizeof(double));
     double *Hp = (double *)malloc((size_t)n * sizeof(double));
     for (long i = 0; i < n; ++i) { delta[i] = 0.0; rr[i] = g[i] * -1.0; p[i] = g[i]; }
-    double err = sqrt(norm2(rr, n)) * 0.01;
+    double err = sqrt(norm2(rr, n)) * g_cg_tol;
     int its = 0;
-    for (int k = 1; k <= 10; ++k) {
+    for (int k = 1; k <= g_cg_max; ++k) {
         hv(p, Hp, ctx);
         ++its;
         double prod_p_Hp = dotv(p, Hp, n);

@@ -89,6 +89,10 @@ void orc_update_U_new(long d1, long d2, const long *idx, const long *item,
                       const double *U, double *U_new, double *now_obj,
                       long *total_cg, long *total_ls);
 
+/* Not in the reference (it hard-codes 10 / 0.01): moves the CG cap and tolerance of every
+ * solve above, to check the product's cg_max_iter / cg_tol extension.  Process-global. */
+void orc_set_cg(int max_iter, double tol);
+
 /* util.cpp:434-542 */
 void orc_eval(const double *U, const double *V, long d1, const long *idx,
               const long *item, const double *val, int r, int ndcg_k,

@@ -25,7 +25,8 @@ class Parameter(C.Structure):
     """class parameter, pmf.h:9-49 (fields the PrimalCR/PrimalCR++ path reads) + device extensions."""
     _fields_ = [("solver_type", C.c_int), ("k", C.c_int), ("threads", C.c_int), ("maxiter", C.c_int),
                 ("lambda_", C.c_double), ("do_predict", C.c_int), ("verbose", C.c_int), ("stepsize", C.c_double),
-                ("ndcg_k", C.c_int), ("precision", C.c_int), ("device", C.c_int)]
+                ("ndcg_k", C.c_int), ("precision", C.c_int), ("device", C.c_int), ("cg_max_iter", C.c_int),
+                ("cg_tol", C.c_double)]
 
     def __init__(self, **kw):
         super().__init__()

@@ -10,6 +10,8 @@
 //   --cache F      binary side-car of the parsed data set: read F if it matches the text files' size and
 //                  modification time, else parse the text and (best effort) write F
 //   --snapshot-every N  also write <model>.iter<k> after every N-th outer iteration
+//   --cg-iters N / --cg-tol X  truncated-Newton knobs (the reference hard-codes 10 / 0.01); --cg-iters k with a
+//                       small --cg-tol makes the U step an exact Newton step
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -37,7 +39,9 @@ static void exit_with_help() {
         "    --device id : GPU to use (default 0)\n"
         "    --init-model file : warm start from a model file\n"
         "    --cache file : binary cache of the parsed data set (rebuilt when the text files change)\n"
-        "    --snapshot-every n : also write <model>.iter<k> after every n-th iteration\n");
+        "    --snapshot-every n : also write <model>.iter<k> after every n-th iteration\n"
+        "    --cg-iters n : CG iterations per Newton step at most (default 10, the reference's constant)\n"
+        "    --cg-tol x : CG residual tolerance relative to ||g|| (default 0.01, the reference's constant)\n");
     exit(1);
 }
 
@@ -79,6 +83,8 @@ int main(int argc, char** argv) {
         if (!strcmp(argv[i - 1], "--init-model")) { init_model = argv[i]; continue; }
         if (!strcmp(argv[i - 1], "--cache")) { cache = argv[i]; continue; }
         if (!strcmp(argv[i - 1], "--snapshot-every")) { snapshot_every = atoi(argv[i]); continue; }
+        if (!strcmp(argv[i - 1], "--cg-iters")) { param.cg_max_iter = atoi(argv[i]); continue; }
+        if (!strcmp(argv[i - 1], "--cg-tol")) { param.cg_tol = atof(argv[i]); continue; }
         switch (argv[i - 1][1]) {
             case 's': param.solver_type = atoi(argv[i]); break;
             case 'k': param.k = atoi(argv[i]); break;

@@ -36,6 +36,8 @@ extern "C" void pcr_params_default(pcr_params* p) {
     p->ndcg_k = 10;
     p->precision = PCR_F32;
     p->device = 0;
+    p->cg_max_iter = 10;
+    p->cg_tol = 0.01;
 }
 
 // util.cpp:80-93.  Init parity depends on libstdc++'s generate_canonical / polar method, so

@@ -1187,13 +1187,13 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_init(const T* __restrict__ 
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = x; part[2 * blockIdx.x + 1] = 0.0; }
 }
 
-__global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_init_fin(const double* __restrict__ part, int nblk, CGState* st) {
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_init_fin(const double* __restrict__ part, int nblk, CGState* st, double tol) {
     __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
     double a, b;
     reduce_partials2(part, nblk, &a, &b, red);
     if (threadIdx.x == 0) {
         st->g2 = a;
-        st->err = sqrt(a) * 0.01;            // pcrpp.cpp:340
+        st->err = sqrt(a) * tol;             // pcrpp.cpp:340 (tol = 0.01 there)
         st->done = 0;
         st->iters = 0;
         st->rr2buf[0] = a;                   // rr = -g
@@ -1341,7 +1341,7 @@ static inline size_t ustep_xch_bytes(int cap_pad, int ld, int K) {
 template <typename T, int BLOCK, bool BIG, int K, bool RES, int UNR>
 __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                  T* __restrict__ U, const T* __restrict__ Vm, double lambda, double stepsize0,
-                                                 int strict, int solver1, int cap, int cap_pad, int rs_cap, int rcap, int nchp,
+                                                 int cg_max, double cg_tol, int strict, int solver1, int cap, int cap_pad, int rs_cap, int rcap, int nchp,
                                                  char* scratch, size_t stride, unsigned long long* counters, ClusterBufs cb) {
     typedef typename LiSel<T, BIG>::type LI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1474,9 +1474,9 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         if (!skip) {
             // ---- CG, solve_delta_u_new (pcrpp.cpp:628-647)
             for (int t = tid; t < ld; t += BLOCK) { delta[t] = 0.0; rr[t] = gvec[t] * -1.0; pv[t] = gvec[t]; }
-            const double err = sqrt(gn2) * 0.01;
+            const double err = sqrt(gn2) * cg_tol;                              // 0.01 in the reference (:632)
             __syncthreads();
-            for (int k = 1; k <= 10; ++k) {
+            for (int k = 1; k <= cg_max; ++k) {                                 // 10 in the reference (:636)
                 for (int t = tid; t < ld; t += BLOCK) { vecT[t] = (T)pv[t]; Hp[t] = pv[t] * lambda; }
                 __syncthreads();
                 sddmm(key);                                                     // b = V_I p  (:592-594)

@@ -346,6 +346,9 @@ struct Solver final : pcr_solver {
 
     int init(const pcr_dataset* ds, const pcr_params* p, int rank_, int nranks_) {
         prm = *p; rank = rank_; nranks = nranks_;
+        if (prm.cg_max_iter == 0) prm.cg_max_iter = 10;      // zero-filled extension fields = the reference's constants
+        if (prm.cg_tol == 0.0) prm.cg_tol = 0.01;
+        if (prm.cg_max_iter < 0 || prm.cg_max_iter > 100000 || !(prm.cg_tol > 0.0)) { pcr_set_error("cg_max_iter / cg_tol out of range"); return PCR_ERR_ARG; }
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
             pcr_set_error("no HIP device available: libprimalcr has no CPU fallback for the training path");
@@ -1114,7 +1117,7 @@ struct Solver final : pcr_solver {
         {
             ProfScope ps(this, "cg");
             hipLaunchKernelGGL((k_cg_init<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_g.p, d_delta.p, d_rr.p, d_p.p, n, ew_per_block, d_partA.p);
-            hipLaunchKernelGGL(k_cg_init_fin, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, ew_blocks, d_cg.p);
+            hipLaunchKernelGGL(k_cg_init_fin, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, ew_blocks, d_cg.p, prm.cg_tol);
         }
         // All 10 iterations are queued without a host round trip; once the device-side stop test
         // (pcrpp.cpp:350) fires, the remaining kernels return immediately.  One sync at the end.
@@ -1122,7 +1125,7 @@ struct Solver final : pcr_solver {
         // one GPU: Hp is final when k_spmm_fin stores it, so that kernel also produces the p.Hp / rr.p partials;
         // with an all-reduce in between they need their own pass (k_cg_a)
         const bool fused_dots = (nranks == 1 && !comm) || local_only;
-        for (int k = 1; k <= 10; ++k) {
+        for (int k = 1; k <= prm.cg_max_iter; ++k) {
             RC(device_hv(d_p.p, d_Hp.p, skip, fused_dots ? d_rr.p : nullptr));
             {
                 ProfScope ps(this, "cg");
@@ -1202,7 +1205,7 @@ struct Solver final : pcr_solver {
             // clusters: grid <= one workgroup per CU so that every member of every cluster is resident
             const int grid = b.ugrid;
             char* scr = d_scratch.p + (size_t)b.scratch_ofs * scratch_stride;
-#define LU(BL, BG, KK, RS, UN) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb)
+#define LU(BL, BG, KK, RS, UN) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb)
             if (b.big) { if (b.K == 4) LU(512, true, 4, true, 8); else if (b.unr == 8) LU(512, true, 1, true, 8); else LU(512, true, 1, false, 4); }
             else if (b.block == 64) { if (b.rcap > 0) LU(64, false, 1, true, 4); else LU(64, false, 1, false, 4); }
             else if (b.block == 256) LU(256, false, 1, false, 4);

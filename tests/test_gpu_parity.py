@@ -444,3 +444,46 @@ def test_fuzz_evaluator_against_oracle(oracle):
         tag = dict(case=case, d1=d1, d2=d2, r=r, nval=nval, k=k)
         assert abs(e - eo) < 1e-12, (tag, e, eo)
         assert (np.isnan(n) and np.isnan(no)) or abs(n - no) < 1e-9 * max(1.0, abs(no)), (tag, n, no)
+
+
+def test_cg_knobs_and_exact_newton_u_step(oracle):
+    """cg_max_iter / cg_tol (the reference hard-codes 10 / 0.01).  With the same settings the device and the
+    oracle still agree step by step (iteration counts included); with cg_max_iter = r and a tiny tolerance the U step
+    is an exact Newton step: its direction solves H delta = g, checked through a second, independent run of the
+    Hessian-vector product on the V side (the residual of the returned delta is ~ 0)."""
+    R = synth.generate("small", seed=9, d1=150, d2=90, nnz=5000, mu=3.2, sigma=0.9)
+    r, lam = 8, 3.0
+    X = oracle.build_csr(R.d1, R.d2, R.user, R.item, R.val)
+    U = oracle.initial(R.d1, r) * 0.4; V = oracle.initial(R.d2, r) * 0.4
+    ds = pcr.Dataset.from_triplets(R.d1, R.d2, R.user, R.item, R.val)
+    try:
+        for cg_max, tol in ((2, 1e-9), (40, 1e-9)):
+            oracle.set_cg(cg_max, tol)
+            s = pcr.Solver(ds, pcr.Parameter(k=r, precision=pcr.PCR_F64, cg_max_iter=cg_max, cg_tol=tol, **{"lambda": lam}))
+            s.set_factors(U, V)
+            mo = oracle.comp_m(U, V, X)
+            s.comp_m()
+            g = s.obtain_g()
+            delta, its = s.solve_delta(g)
+            do, its_o = oracle.solve_delta_new(oracle.obtain_g_new(U, V, X, mo, lam), mo, U, X, lam)
+            assert its == its_o and rel(delta, do) < 1e-7
+            if cg_max == 2:
+                assert its == 2                                   # the cap binds
+            else:
+                assert 10 < its <= 40                             # runs past the reference's 10
+                assert rel(s.compute_Ha(delta), g) < 1e-7         # an exact Newton direction
+            s.set_factors(U, V)
+            Vo, m1, objVo, iv = oracle.update_V_new(X, lam, 1.0, U, V)
+            objV, info = s.update_V()
+            assert info["cg"] == iv["cg"] and info["ls"] == iv["ls"] and abs(objV / objVo - 1) < 1e-10
+            Uo, objUo, iu = oracle.update_U_new(X, m1, lam, 1.0, Vo, U)
+            objU, info = s.update_U()
+            Ug, Vg = s.get_factors()
+            assert info["cg"] == iu["cg"] and info["ls"] == iu["ls"]
+            assert rel(Ug, Uo) < 1e-7 and rel(Vg, Vo) < 1e-7 and abs(objU / objUo - 1) < 1e-10
+        # r-dimensional systems: CG needs at most r iterations per user (+ rounding), far fewer than the cap of 40
+        assert iu["cg"] <= (r + 2) * R.d1
+        with pytest.raises(pcr.PcrError):
+            pcr.Solver(ds, pcr.Parameter(k=r, cg_tol=-1.0))
+    finally:
+        oracle.set_cg()

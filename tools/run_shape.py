@@ -14,13 +14,14 @@ ap.add_argument("--nnz", type=int); ap.add_argument("--mu", type=float); ap.add_
 ap.add_argument("-k", type=int, default=100); ap.add_argument("-t", type=int, default=3); ap.add_argument("-l", type=float, default=5000.0)
 ap.add_argument("--f64", action="store_true"); ap.add_argument("--ref", action="store_true"); ap.add_argument("--predict", type=int, default=0)
 ap.add_argument("--threads", type=int, default=16); ap.add_argument("-s", type=int, default=2, help="1 PrimalCR, 2 PrimalCR++")
+ap.add_argument("--cg-iters", type=int, default=10); ap.add_argument("--cg-tol", type=float, default=0.01)
 a = ap.parse_args()
 t0 = time.time()
 R = synth.generate(a.shape, d1=a.d1, d2=a.d2, nnz=a.nnz, mu=a.mu, sigma=a.sigma)
 ds = pcr.Dataset.from_ratings(R)
 idx, _, _ = ds.csr(0); lens = np.diff(idx)
 print(f"[data] {R.d1}x{R.d2} nnz={R.nnz} pairs={ds.count_pairs()} len max={lens.max()} mean={lens.mean():.1f} >4096: {(lens>4096).sum()} ({time.time()-t0:.1f}s)", flush=True)
-p = pcr.Parameter(k=a.k, maxiter=a.t, do_predict=a.predict, solver_type=a.s, precision=pcr.PCR_F64 if a.f64 else pcr.PCR_F32, **{"lambda": a.l})
+p = pcr.Parameter(k=a.k, maxiter=a.t, do_predict=a.predict, solver_type=a.s, cg_max_iter=a.cg_iters, cg_tol=a.cg_tol, precision=pcr.PCR_F64 if a.f64 else pcr.PCR_F32, **{"lambda": a.l})
 s = pcr.Solver(ds, p)
 s.set_factors(pcr.initial(R.d1, a.k), pcr.initial(R.d2, a.k))
 s.profile(True, period=2)
