@@ -457,7 +457,7 @@ def test_cg_knobs_and_exact_newton_u_step(oracle):
     U = oracle.initial(R.d1, r) * 0.4; V = oracle.initial(R.d2, r) * 0.4
     ds = pcr.Dataset.from_triplets(R.d1, R.d2, R.user, R.item, R.val)
     try:
-        for cg_max, tol in ((2, 1e-9), (40, 1e-9)):
+        for cg_max, tol in ((2, 1e-9), (60, 1e-5)):       # (1e-5: far enough above the rounding floor for equal counts)
             oracle.set_cg(cg_max, tol)
             s = pcr.Solver(ds, pcr.Parameter(k=r, precision=pcr.PCR_F64, cg_max_iter=cg_max, cg_tol=tol, **{"lambda": lam}))
             s.set_factors(U, V)
@@ -470,8 +470,8 @@ def test_cg_knobs_and_exact_newton_u_step(oracle):
             if cg_max == 2:
                 assert its == 2                                   # the cap binds
             else:
-                assert 10 < its <= 40                             # runs past the reference's 10
-                assert rel(s.compute_Ha(delta), g) < 1e-7         # an exact Newton direction
+                assert 10 < its < 60                              # runs past the reference's 10, stops on the tolerance
+                assert rel(s.compute_Ha(delta), g) < 1e-4         # an (almost) exact Newton direction
             s.set_factors(U, V)
             Vo, m1, objVo, iv = oracle.update_V_new(X, lam, 1.0, U, V)
             objV, info = s.update_V()
@@ -481,7 +481,7 @@ def test_cg_knobs_and_exact_newton_u_step(oracle):
             Ug, Vg = s.get_factors()
             assert info["cg"] == iu["cg"] and info["ls"] == iu["ls"]
             assert rel(Ug, Uo) < 1e-7 and rel(Vg, Vo) < 1e-7 and abs(objU / objUo - 1) < 1e-10
-        # r-dimensional systems: CG needs at most r iterations per user (+ rounding), far fewer than the cap of 40
+        # r-dimensional systems: CG needs at most r iterations per user (+ rounding), far fewer than the cap of 60
         assert iu["cg"] <= (r + 2) * R.d1
         with pytest.raises(pcr.PcrError):
             pcr.Solver(ds, pcr.Parameter(k=r, cg_tol=-1.0))

@@ -24,12 +24,20 @@ def test_training_through_rccl_single_rank():
         s.set_factors(U0, V0)
         recs, _ = s.train()
         U, V = s.get_factors()
-        out.append((recs, U, V))
+        # the pipelined loop bench.py times (pcr_iterate), from the same start, then the evaluator
+        s.set_factors(U0, V0)
+        it = s.iterate(2)
+        Ui, Vi = s.get_factors()
+        out.append((recs, U, V, it, Ui, Vi, s.evaluate(1, 10)))
         s.close()
-    (r0, U_a, V_a), (r1, U_b, V_b) = out
+    (r0, U_a, V_a, i0, Ui_a, Vi_a, e0), (r1, U_b, V_b, i1, Ui_b, Vi_b, e1) = out
     assert np.array_equal(U_a, U_b) and np.array_equal(V_a, V_b)
+    assert np.array_equal(Ui_a, Ui_b) and np.array_equal(Vi_a, Vi_b) and e0 == e1
+    assert np.array_equal(Ui_a, U_a) and np.array_equal(Vi_a, V_a)      # pipelined == step by step
     for a, b in zip(r0, r1):
         assert a["obj"] == b["obj"] and a["test_ndcg"] == b["test_ndcg"] and a["cg_v"] == b["cg_v"]
+    for a, b in zip(i0, i1):
+        assert a["obj"] == b["obj"] and a["cg_v"] == b["cg_v"] and a["cg_u"] == b["cg_u"]
 
 
 def test_headline_config_matches_reference_binary(tmp_path):
