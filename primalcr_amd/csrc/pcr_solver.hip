@@ -795,13 +795,17 @@ struct Solver final : pcr_solver {
             for (size_t i = 0; i < nhead; ++i) plan.push_back({(int)i, MAXLANE});
             for (size_t i = nhead; i < order.size(); ++i) plan.push_back({(int)i, (int)((i - nhead) % nlane)});   // longest on the solver's stream
         }
+        // nothing in flight on the solver's stream (the usual case: the V step has just read its objective back): the lanes
+        // need no fork event, their kernels start as soon as they are launched
+        static const int idle_knob = getenv("PCR_IDLE_FORK") ? atoi(getenv("PCR_IDLE_FORK")) : 1;     // developer knob
+        const bool idle = idle_knob && hipStreamQuery(st) == hipSuccess;
         ProfScope wall(this, "wall:ustep", st);
         bool used[MAXLANE + 1] = {};
-        HIPCHK(hipEventRecord(ev_fork, st));
+        if (!idle) HIPCHK(hipEventRecord(ev_fork, st));
         for (auto& pr : plan) {
             Bin& b = *order[pr.first];
             hipStream_t q = pr.second == MAXLANE ? hi : lane[pr.second];
-            if (q != st && !used[pr.second]) HIPCHK(hipStreamWaitEvent(q, ev_fork, 0));
+            if (!idle && q != st && !used[pr.second]) HIPCHK(hipStreamWaitEvent(q, ev_fork, 0));
             used[pr.second] = true;
             ProfScope ps(this, pname("ustep", b), q, b.nnz, (int64_t)b.users.size());
             launch(b, q);
@@ -1170,6 +1174,7 @@ struct Solver final : pcr_solver {
         for (int it = 0; it < 20; ++it) {                          // :427-441
             hipLaunchKernelGGL((k_axpy_out<T>), dim3(cdiv(n, 256)), dim3(256), 0, st, d_Vnew.p, d_V.p, d_delta.p, -step, n);
             RC(launch_prepare(d_Vnew.p));
+            RC(zero_counters());                                   // (a pending U step's counters are already on their way to the host)
             RC(full_objective(d_Vnew.p, &obj));
             if (!cg_sync) cg_iters = h_cg->iters;                 // that read-back synchronised the stream
             if (it == 0) prev_obj = h_scal[4] + prm.lambda * ((prev_u ? h_scal[6] : unorm2_before) + h_scal[5]) / 2.0;
@@ -1192,8 +1197,18 @@ struct Solver final : pcr_solver {
         return PCR_OK;
     }
 
+    // counters + cluster barriers of the next U step.  update_V queues this in front of its objective read-back, so that the
+    // U step that follows finds the solver's stream idle and starts without a fork (for_ubins)
+    bool counters_zeroed = false;
+    int zero_counters() {
+        if (counters_zeroed) return PCR_OK;
+        HIPCHK(hipMemsetAsync(d_counters.p, 0, (4 + 64 + (bar_n + 1) / 2) * sizeof(unsigned long long), st));
+        counters_zeroed = true;
+        return PCR_OK;
+    }
     int launch_ustep() {
-        HIPCHK(hipMemsetAsync(d_counters.p, 0, (4 + 64 + (bar_n + 1) / 2) * sizeof(unsigned long long), st));   // counters + cluster barriers
+        RC(zero_counters());
+        counters_zeroed = false;
         auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
             const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
