@@ -793,7 +793,14 @@ struct Solver final : pcr_solver {
         if (plan.size() != order.size()) {                            // default (also when the knob does not name every class)
             plan.clear();
             for (size_t i = 0; i < nhead; ++i) plan.push_back({(int)i, MAXLANE});
-            for (size_t i = nhead; i < order.size(); ++i) plan.push_back({(int)i, (int)((i - nhead) % nlane)});   // longest on the solver's stream
+            // round-robin over the lanes, longest class first -- with the first two lanes swapped: the solver's stream takes
+            // the SECOND class (on the headline shape the many-user 256-thread class that finishes last, and the shortest
+            // class behind it), so the join at the end finds the other lanes' events already signalled (1.803 -> 1.785 ms)
+            for (size_t i = nhead; i < order.size(); ++i) {
+                int l = (int)((i - nhead) % nlane);
+                if (nlane >= 2 && l < 2) l ^= 1;
+                plan.push_back({(int)i, l});
+            }
         }
         // nothing in flight on the solver's stream (the usual case: the V step has just read its objective back): the lanes
         // need no fork event, their kernels start as soon as they are launched
