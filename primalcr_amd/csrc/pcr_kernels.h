@@ -1796,33 +1796,44 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_sum4_stage1(const double* __re
         if (threadIdx.x == 0) part[4 * blockIdx.x + c] = s;
     }
 }
-// the three sums of an objective in one pass: sum(objx[0..nx)), |a|^2 over na elements, |b|^2 over nb (b may be null);
-// block-sliced partials part[blk][4] for k_fin4 (deterministic two-stage sums, as k_sum_stage1 / k_dots)
+// the three sums of an objective in one pass: sum(objx[0..nx)), |a|^2 over na elements, |b|^2 over nb (b may be null),
+// and optionally a second per-user sum, sum(objx2[0..nx)); block-sliced partials part[blk][4] for k_fin4 (deterministic
+// two-stage sums, as k_sum_stage1 / k_dots)
 template <typename T>
-__global__ __launch_bounds__(PCR_EW_BLOCK) void k_obj3(const double* __restrict__ objx, int64_t nx, const T* __restrict__ a, int64_t na,
-                                                        const T* __restrict__ b, int64_t nb, double* __restrict__ part) {
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_obj3(const double* __restrict__ objx, const double* __restrict__ objx2, int64_t nx,
+                                                        const T* __restrict__ a, int64_t na, const T* __restrict__ b, int64_t nb,
+                                                        double* __restrict__ part) {
     __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
     const int64_t G = gridDim.x, blk = blockIdx.x;
-    double s[3] = {0.0, 0.0, 0.0};
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
     { const int64_t per = (nx + G - 1) / G, lo = blk * per, hi = lo + per < nx ? lo + per : nx;
-      for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) s[0] += objx[i]; }
+      for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) s[0] += objx[i];
+      if (objx2) for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) s[3] += objx2[i]; }
     { const int64_t per = (na + G - 1) / G, lo = blk * per, hi = lo + per < na ? lo + per : na;
       for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) { const double v = (double)a[i]; s[1] += v * v; } }
     if (b) { const int64_t per = (nb + G - 1) / G, lo = blk * per, hi = lo + per < nb ? lo + per : nb;
       for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) { const double v = (double)b[i]; s[2] += v * v; } }
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < 4; ++c) {
         const double t = block_sum<PCR_EW_BLOCK>(s[c], red);
         if (threadIdx.x == 0) part[4 * blk + c] = t;
     }
-    if (threadIdx.x == 0) part[4 * blk + 3] = 0.0;
 }
-__global__ __launch_bounds__(PCR_EW_BLOCK) void k_fin4(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+// cnt != nullptr (the sums that follow a U step): also hands the U step's counters on -- cnt_out[0..2] = CG iterations, line
+// search evaluations, cluster time-outs -- and resets the counter block (cnt[0..nzero)) for the next U step: no memset and
+// no second copy on the critical path of the training loop.
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_fin4(const double* __restrict__ part, int nblk, double* __restrict__ out,
+                                                        unsigned long long* cnt = nullptr, double* cnt_out = nullptr, int nzero = 0) {
     __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
     for (int c = 0; c < 4; ++c) {
         double x = 0.0;
         for (int i = threadIdx.x; i < nblk; i += PCR_EW_BLOCK) x += part[4 * i + c];
         x = block_sum<PCR_EW_BLOCK>(x, red);
         if (threadIdx.x == 0) out[c] = x;
+    }
+    if (cnt) {
+        if (threadIdx.x == 0) { cnt_out[0] = (double)cnt[0]; cnt_out[1] = (double)cnt[1]; cnt_out[2] = (double)cnt[3]; }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nzero; i += PCR_EW_BLOCK) cnt[i] = 0ull;
     }
 }
 

@@ -677,7 +677,7 @@ struct Solver final : pcr_solver {
         RC(d_counters.alloc(4 + 64 + (bar_n + 1) / 2));
         bar_p = reinterpret_cast<unsigned*>(d_counters.p + 4 + 64);
         HIPCHK(hipHostMalloc((void**)&h_scal, 64 * sizeof(double)));
-        HIPCHK(hipHostMalloc((void**)&h_uobj, 4 * sizeof(double)));
+        HIPCHK(hipHostMalloc((void**)&h_uobj, 16 * sizeof(double)));
         HIPCHK(hipHostMalloc((void**)&h_cg, sizeof(CGState)));
         HIPCHK(hipHostMalloc((void**)&h_counters, (4 + 64) * sizeof(unsigned long long)));
 
@@ -1025,14 +1025,18 @@ struct Solver final : pcr_solver {
 
     // loss (all ranks) of the last prepare + lambda/2 (|U|^2 + |Vm|^2)   (pcrpp.cpp:410)
     // d_scal[0] = sum objx (all ranks), [1] = |Vm|^2, [2] = |U|^2 (all ranks; only if with_u): one pass + one finish
-    int objective_sums(const double* objx, const T* Vm, bool with_u, int slot = 0) {
+    // objx2 (optional): a second per-user sum -> [3].  after_ustep: the finishing kernel also moves the U step's counters to
+    // d_scal[12..14] and resets the counter block (k_fin4).
+    int objective_sums(const double* objx, const T* Vm, bool with_u, int slot = 0, const double* objx2 = nullptr, bool after_ustep = false) {
         const int64_t nV = (int64_t)d2 * geo.ld, nU = (int64_t)n_users * geo.ld;
         const int nb = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv(std::max(nV, nU), 4096)));
-        hipLaunchKernelGGL((k_obj3<T>), dim3(nb), dim3(PCR_EW_BLOCK), 0, st, objx, n_users, Vm, nV, with_u ? d_U.p : (const T*)nullptr, nU, d_partA.p);
-        hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + slot);
+        hipLaunchKernelGGL((k_obj3<T>), dim3(nb), dim3(PCR_EW_BLOCK), 0, st, objx, objx2, n_users, Vm, nV, with_u ? d_U.p : (const T*)nullptr, nU, d_partA.p);
+        if (after_ustep) hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + slot, d_counters.p, d_scal.p + 12, counter_words());
+        else hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + slot, (unsigned long long*)nullptr, (double*)nullptr, 0);
         HIPCHK(hipGetLastError());
         RC(allreduce_f64(d_scal.p + slot, 1));
         if (with_u) RC(allreduce_f64(d_scal.p + slot + 2, 1));
+        if (objx2) RC(allreduce_f64(d_scal.p + slot + 3, 1));
         return PCR_OK;
     }
     int full_objective(const T* Vm, double* obj) {
@@ -1167,7 +1171,8 @@ struct Solver final : pcr_solver {
         // trip of its own.  (After a U step the per-user losses in objp are the ones k_ustep left.)
         const bool prev_u = !unorm_valid;
         const double unorm2_before = unorm2;
-        RC(objective_sums(d_objp.p, d_V.p, prev_u, 4));
+        if (start_sums_queued) start_sums_queued = false;          // ... already, by the U step this V step follows (prev_u is true then)
+        else RC(objective_sums(d_objp.p, d_V.p, prev_u, 4));
         RC(device_gradient());                                     // obtain_g_new (:418)
         // solve_delta_new (:422).  No host round trip when the line search's prepare is the single-launch form: everything
         // up to the objective read-back is stream-ordered.  (With the per-class launches the host waits for the CG first: a
@@ -1181,7 +1186,6 @@ struct Solver final : pcr_solver {
         for (int it = 0; it < 20; ++it) {                          // :427-441
             hipLaunchKernelGGL((k_axpy_out<T>), dim3(cdiv(n, 256)), dim3(256), 0, st, d_Vnew.p, d_V.p, d_delta.p, -step, n);
             RC(launch_prepare(d_Vnew.p));
-            RC(zero_counters());                                   // (a pending U step's counters are already on their way to the host)
             RC(full_objective(d_Vnew.p, &obj));
             if (!cg_sync) cg_iters = h_cg->iters;                 // that read-back synchronised the stream
             if (it == 0) prev_obj = h_scal[4] + prm.lambda * ((prev_u ? h_scal[6] : unorm2_before) + h_scal[5]) / 2.0;
@@ -1204,12 +1208,14 @@ struct Solver final : pcr_solver {
         return PCR_OK;
     }
 
-    // counters + cluster barriers of the next U step.  update_V queues this in front of its objective read-back, so that the
-    // U step that follows finds the solver's stream idle and starts without a fork (for_ubins)
+    // counters + cluster barriers of the next U step: reset by the kernel that finishes the previous U step's sums (k_fin4),
+    // by a memset only before the first one -- the U step then finds the solver's stream idle and starts without a fork
+    // (for_ubins)
     bool counters_zeroed = false;
+    int counter_words() const { return 4 + 64 + (bar_n + 1) / 2; }
     int zero_counters() {
         if (counters_zeroed) return PCR_OK;
-        HIPCHK(hipMemsetAsync(d_counters.p, 0, (4 + 64 + (bar_n + 1) / 2) * sizeof(unsigned long long), st));
+        HIPCHK(hipMemsetAsync(d_counters.p, 0, (size_t)counter_words() * sizeof(unsigned long long), st));
         counters_zeroed = true;
         return PCR_OK;
     }
@@ -1250,16 +1256,25 @@ struct Solver final : pcr_solver {
         HIPCHK(hipStreamSynchronize(st));
         return ustep_finish(now_obj, info);
     }
-    int ustep_launch_async() {
+    bool uobj_merged = false, start_sums_queued = false;
+    int ustep_launch_async(bool v_step_follows = false) {
         RC(need_sorted());
         RC(launch_ustep());
         unorm_valid = false;
         // U changed, and k_ustep left the sorted state of (U_new, V) behind: still valid for the next V step -- unless
         // it started from the state of a rejected V_new, which the users it skipped still carry
         if (state_of_rejected_V) { have_sorted = false; state_of_rejected_V = false; }
-        RC(objective_sums(d_objr.p, d_V.p, false));                 // sum_i obj_u(i), |V|^2
+#ifdef PCR_USTEP_PROF
         HIPCHK(hipMemcpyAsync(h_counters, d_counters.p, (4 + 64) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(h_uobj, d_scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+#endif
+        // sum_i obj_u(i), |V|^2 (:835).  When a V step follows at once from the state this U step left (the pipelined loop),
+        // the three sums of ITS starting objective -- the per-user losses, |V|^2, |U|^2 -- ride on the same pass
+        // (slots 4..6, where update_V expects them; the U step's own sum in slot 7).
+        uobj_merged = v_step_follows && have_sorted;
+        if (uobj_merged) { RC(objective_sums(d_objp.p, d_V.p, true, 4, d_objr.p, true)); start_sums_queued = true; }
+        else RC(objective_sums(d_objr.p, d_V.p, false, 0, nullptr, true));
+        counters_zeroed = true;                                     // k_fin4 has reset them
+        HIPCHK(hipMemcpyAsync(h_uobj, d_scal.p, 16 * sizeof(double), hipMemcpyDeviceToHost, st));
         ustep_pending = true;
         return PCR_OK;
     }
@@ -1278,9 +1293,9 @@ struct Solver final : pcr_solver {
             }
         }
 #endif
-        if (now_obj) *now_obj = h_uobj[0] + prm.lambda / 2.0 * h_uobj[1];      // :835
-        if (h_counters[3] != 0) { pcr_set_error("k_ustep: a workgroup cluster timed out at a hand-off (members not co-resident?)"); return PCR_ERR_DEVICE; }
-        if (info) { info[0] = (int64_t)h_counters[0]; info[1] = (int64_t)h_counters[1]; }
+        if (now_obj) *now_obj = (uobj_merged ? h_uobj[7] : h_uobj[0]) + prm.lambda / 2.0 * (uobj_merged ? h_uobj[5] : h_uobj[1]);      // :835
+        if (h_uobj[14] != 0.0) { pcr_set_error("k_ustep: a workgroup cluster timed out at a hand-off (members not co-resident?)"); return PCR_ERR_DEVICE; }
+        if (info) { info[0] = (int64_t)h_uobj[12]; info[1] = (int64_t)h_uobj[13]; }
         return PCR_OK;
     }
 
@@ -1424,6 +1439,7 @@ struct Solver final : pcr_solver {
             on_done(k, rec[k]);
             return PCR_OK;
         };
+        static const int pipe = getenv("PCR_PIPELINE") ? atoi(getenv("PCR_PIPELINE")) : 1;       // developer knob
         for (int k = 1; k <= n && rc == PCR_OK; ++k) {
             int vinfo[3] = {0, 0, 0};
             double vobj = 0.0;
@@ -1431,10 +1447,9 @@ struct Solver final : pcr_solver {
             if (rc != PCR_OK) break;
             if (fin_ready) { rc = close(k - 1); if (rc != PCR_OK) break; }
             rec[k].cg_v = vinfo[0]; rec[k].ls_v = vinfo[1];
-            rc = ustep_launch_async();
+            rc = ustep_launch_async(pipe && k < n);
             if (rc != PCR_OK) break;
             HIPCHK(hipEventRecord(evk[k & 1], st));
-            static const int pipe = getenv("PCR_PIPELINE") ? atoi(getenv("PCR_PIPELINE")) : 1;       // developer knob
             if (!pipe) { HIPCHK(hipStreamSynchronize(st)); rc = ustep_finish(&fin_obj, fin_info); if (rc == PCR_OK) rc = close(k); }
         }
         device_join = false;
