@@ -192,7 +192,7 @@ struct Solver final : pcr_solver {
     DBuf<double> d_out4;
     // ---- factors and CG vectors (d2 x ld, nu x ld)
     DBuf<T> d_U, d_V, d_Vnew, d_g, d_delta, d_rr, d_p, d_Hp;
-    DBuf<CGState> d_cg;
+    CGState* d_cgp = nullptr;                     // the CG scalars live in d_scal[32..43): they come back with the objective's read-back
     DBuf<double> d_partA, d_partB, d_scal;       // reduction partials, small scalar block
     DBuf<unsigned long long> d_counters;
     DBuf<char> d_scratch;
@@ -206,7 +206,7 @@ struct Solver final : pcr_solver {
     int64_t fin_info[2] = {0, 0};
     bool fin_ready = false;
     bool device_join = false;                     // pipelined loop: the solver's stream waits for the lanes on the device
-    CGState* h_cg = nullptr;                      // pinned
+    CGState* h_cg = nullptr;                      // = h_scal + 32
     unsigned long long* h_counters = nullptr;     // pinned
     int ew_blocks = 1, ew_per_block = 1;          // elementwise decomposition over d2*ld
     bool have_sorted = false;
@@ -237,7 +237,6 @@ struct Solver final : pcr_solver {
         if (comm) ncclCommDestroy(comm);
         if (h_scal) (void)hipHostFree(h_scal);
         if (h_uobj) (void)hipHostFree(h_uobj);
-        if (h_cg) (void)hipHostFree(h_cg);
         if (h_counters) (void)hipHostFree(h_counters);
         for (int i = 0; i < NSIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -670,7 +669,6 @@ struct Solver final : pcr_solver {
         RC(d_rr.alloc(nV)); RC(d_p.alloc(nV)); RC(d_Hp.alloc(nV));
         HIPCHK(hipMemsetAsync(d_U.p, 0, std::max<size_t>(nU, 1) * sizeof(T), st));
         HIPCHK(hipMemsetAsync(d_V.p, 0, std::max<size_t>(nV, 1) * sizeof(T), st));
-        RC(d_cg.alloc(1));
         ew_blocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, cdiv((int64_t)nV, 1024)));   // 4 elements per thread: these kernels are latency-bound
         ew_per_block = cdiv((int64_t)nV, ew_blocks);
         RC(d_partA.alloc(4 * 2048)); RC(d_partB.alloc(4 * 2048)); RC(d_scal.alloc(64));
@@ -678,7 +676,9 @@ struct Solver final : pcr_solver {
         bar_p = reinterpret_cast<unsigned*>(d_counters.p + 4 + 64);
         HIPCHK(hipHostMalloc((void**)&h_scal, 64 * sizeof(double)));
         HIPCHK(hipHostMalloc((void**)&h_uobj, 16 * sizeof(double)));
-        HIPCHK(hipHostMalloc((void**)&h_cg, sizeof(CGState)));
+        static_assert(sizeof(CGState) <= 12 * sizeof(double), "CGState must fit d_scal[32..44)");
+        h_cg = reinterpret_cast<CGState*>(h_scal + 32);
+        d_cgp = reinterpret_cast<CGState*>(d_scal.p + 32);
         HIPCHK(hipHostMalloc((void**)&h_counters, (4 + 64) * sizeof(unsigned long long)));
 
         // ---- scratch for users that do not fit in LDS
@@ -1006,7 +1006,7 @@ struct Solver final : pcr_solver {
         return PCR_OK;
     }
     int fetch_scal(int count) {
-        HIPCHK(hipMemcpyAsync(h_scal, d_scal.p, count * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_scal, d_scal.p, std::max(count, 44) * sizeof(double), hipMemcpyDeviceToHost, st));   // [32..44): the CG scalars
         HIPCHK(hipStreamSynchronize(st));
         return PCR_OK;
     }
@@ -1132,11 +1132,11 @@ struct Solver final : pcr_solver {
         {
             ProfScope ps(this, "cg");
             hipLaunchKernelGGL((k_cg_init<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_g.p, d_delta.p, d_rr.p, d_p.p, n, ew_per_block, d_partA.p);
-            hipLaunchKernelGGL(k_cg_init_fin, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, ew_blocks, d_cg.p, prm.cg_tol);
+            hipLaunchKernelGGL(k_cg_init_fin, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, ew_blocks, d_cgp, prm.cg_tol);
         }
         // All 10 iterations are queued without a host round trip; once the device-side stop test
         // (pcrpp.cpp:350) fires, the remaining kernels return immediately.  One sync at the end.
-        const int* skip = &d_cg.p->done;
+        const int* skip = &d_cgp->done;
         // one GPU: Hp is final when k_spmm_fin stores it, so that kernel also produces the p.Hp / rr.p partials;
         // with an all-reduce in between they need their own pass (k_cg_a)
         const bool fused_dots = (nranks == 1 && !comm) || local_only;
@@ -1144,13 +1144,16 @@ struct Solver final : pcr_solver {
             RC(device_hv(d_p.p, d_Hp.p, skip, fused_dots ? d_rr.p : nullptr));
             {
                 ProfScope ps(this, "cg");
-                if (!fused_dots) hipLaunchKernelGGL((k_cg_a<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, n, ew_per_block, d_partA.p, d_cg.p);
-                hipLaunchKernelGGL((k_cg_bc<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, d_delta.p, n, ew_per_block, fused_dots ? fin_blocks() : ew_blocks, d_partA.p, d_cg.p, k);
+                if (!fused_dots) hipLaunchKernelGGL((k_cg_a<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, n, ew_per_block, d_partA.p, d_cgp);
+                hipLaunchKernelGGL((k_cg_bc<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, d_delta.p, n, ew_per_block, fused_dots ? fin_blocks() : ew_blocks, d_partA.p, d_cgp, k);
             }
             HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipMemcpyAsync(h_cg, d_cg.p, sizeof(CGState), hipMemcpyDeviceToHost, st));
-        if (iters) { HIPCHK(hipStreamSynchronize(st)); *iters = h_cg->iters; }
+        if (iters) {
+            HIPCHK(hipMemcpyAsync(h_cg, d_cgp, sizeof(CGState), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            *iters = h_cg->iters;
+        }
         return PCR_OK;
     }
     int solve_delta(const double* g, double* delta, int* iters) override {
