@@ -487,3 +487,36 @@ def test_cg_knobs_and_exact_newton_u_step(oracle):
             pcr.Solver(ds, pcr.Parameter(k=r, cg_tol=-1.0))
     finally:
         oracle.set_cg()
+
+
+@pytest.mark.parametrize("precision,r", [(pcr.PCR_F32, 200), (pcr.PCR_F32, 260), (pcr.PCR_F64, 140), (pcr.PCR_F64, 257)])
+def test_wide_ranks_against_oracle(oracle, precision, r):
+    """Ranks at and beyond one pass of a 64-lane group (64 16-byte chunks = 256 floats / 128 doubles per row): k = 200 is
+    configs[4]'s rank (one pass, 64 lanes); 260 (fp32) and 140, 257 (fp64) take two or three passes through the row in every
+    gather kernel and the per-user r-vectors of k_ustep are longer than a wave.  One outer iteration against the oracle."""
+    R = synth.generate("small", seed=21, d1=90, d2=160, nnz=4000, mu=3.3, sigma=1.0)
+    lam = 40.0
+    X = oracle.build_csr(R.d1, R.d2, R.user, R.item, R.val)
+    U0 = oracle.initial(R.d1, r) * 0.1; V0 = oracle.initial(R.d2, r) * 0.1
+    ds = pcr.Dataset.from_ratings(R)
+    s = pcr.Solver(ds, pcr.Parameter(k=r, precision=precision, **{"lambda": lam}))
+    t = TOL[precision]
+    s.set_factors(U0, V0)
+    mo = oracle.comp_m(U0, V0, X)
+    assert rel(s.comp_m(), mo) < t["m"]
+    assert rel(s.obtain_g(), oracle.obtain_g_new(U0, V0, X, mo, lam)) < t["vec"]
+    a = np.random.default_rng(2).normal(size=V0.shape)
+    assert rel(s.compute_Ha(a), oracle.compute_Ha_new(a, mo, U0, X, lam)) < t["vec"]
+    V1, m1, objVo, iv = oracle.update_V_new(X, lam, 1.0, U0, V0)
+    U1, objUo, iu = oracle.update_U_new(X, m1, lam, 1.0, V1, U0)
+    s.set_factors(U0, V0)
+    objV, info_v = s.update_V()
+    objU, info_u = s.update_U()
+    Ug, Vg = s.get_factors()
+    assert abs(objV / objVo - 1) < max(t["obj"], t["cg"] * 1e-2) and abs(objU / objUo - 1) < max(t["obj"], t["fac"] * 1e-2)
+    assert rel(Vg, V1) < t["fac"] and rel(Ug, U1) < t["fac"]
+    if precision == pcr.PCR_F64:
+        assert info_v["cg"] == iv["cg"] and info_v["ls"] == iv["ls"] and info_u["cg"] == iu["cg"] and info_u["ls"] == iu["ls"]
+    e, n = s.evaluate(0)
+    eo, no = oracle.eval(Ug, Vg, X)
+    assert abs(e - eo) < (1e-12 if precision == pcr.PCR_F64 else 2e-3) and abs(n - no) < (1e-12 if precision == pcr.PCR_F64 else 2e-3)
