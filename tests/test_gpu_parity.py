@@ -520,3 +520,60 @@ def test_wide_ranks_against_oracle(oracle, precision, r):
     e, n = s.evaluate(0)
     eo, no = oracle.eval(Ug, Vg, X)
     assert abs(e - eo) < (1e-12 if precision == pcr.PCR_F64 else 2e-3) and abs(n - no) < (1e-12 if precision == pcr.PCR_F64 else 2e-3)
+
+
+@pytest.mark.parametrize("solver", [2, 1])
+def test_empty_rating_set(oracle, solver):
+    """No ratings at all: the objective is the regulariser alone, the first V step is one CG iteration that lands on
+    V = 0 (to rounding), the second one finds nothing to gain and exhausts its 20 line-search tries (q5), users keep
+    their factors (q6), the training metrics are 0/0 (util.cpp:537).  Same records as the oracle."""
+    d1, d2, r = 5, 7, 4
+    e32, e64 = np.zeros(0, np.int32), np.zeros(0)
+    X = oracle.build_csr(d1, d2, e32, e32, e64)
+    U0 = oracle.initial(d1, r); V0 = oracle.initial(d2, r)
+    Uo, Vo, ro = oracle.train(X, U0, V0, 3.0, 2, solver=solver, do_predict=1)
+    ds = pcr.Dataset.from_triplets(d1, d2, e32, e32, e64)
+    s = pcr.Solver(ds, pcr.Parameter(k=r, precision=pcr.PCR_F64, solver_type=solver, maxiter=2, do_predict=1, **{"lambda": 3.0}))
+    s.set_factors(U0, V0)
+    recs, _ = s.train()
+    Ug, Vg = s.get_factors()
+    assert len(recs) == len(ro) == 3
+    for a, b in zip(recs, ro):
+        assert abs(a["obj"] - b["obj"]) <= 1e-12 * abs(b["obj"])
+        assert (a["cg_v"], a["ls_v"], a["cg_u"], a["ls_u"]) == (b["cg_v"], b["ls_v"], b["cg_u"], b["ls_u"])
+        assert np.isnan(a["train_err"]) and np.isnan(a["train_ndcg"])
+    assert np.array_equal(Ug, U0) and np.abs(Vg).max() < 1e-14
+
+
+def test_users_beyond_65535_ratings(oracle):
+    """Yahoo-shaped data has users with more than 2^16 ratings: positions inside such a user no longer fit 16
+    bits and the user lives in the global-scratch classes.  One user who rated every one of 70 000 items, one with 66 000,
+    next to short ones; one outer iteration in fp64 against the oracle, counts included."""
+    rng = np.random.default_rng(8)
+    d2, r, lam = 70000, 4, 10.0
+    lens = np.array([66000, d2, 10, 0, 300, 5000])
+    d1 = len(lens)
+    user = np.repeat(np.arange(d1), lens)
+    item = np.concatenate([rng.choice(d2, n, replace=False) for n in lens])
+    val = rng.integers(1, 6, user.shape[0]).astype(np.float64)
+    X = oracle.build_csr(d1, d2, user, item, val)
+    U0 = oracle.initial(d1, r) * 0.2; V0 = oracle.initial(d2, r) * 0.2
+    ds = pcr.Dataset.from_triplets(d1, d2, user, item, val)
+    s = pcr.Solver(ds, pcr.Parameter(k=r, precision=pcr.PCR_F64, **{"lambda": lam}))
+    s.set_factors(U0, V0)
+    mo = oracle.comp_m(U0, V0, X)
+    assert rel(s.comp_m(), mo) < 1e-13
+    assert abs(s.objective() / oracle.objective_new(mo, U0, V0, X, lam) - 1) < 1e-11
+    assert rel(s.obtain_g(), oracle.obtain_g_new(U0, V0, X, mo, lam)) < 1e-10
+    V1, m1, objVo, iv = oracle.update_V_new(X, lam, 1.0, U0, V0)
+    U1, objUo, iu = oracle.update_U_new(X, m1, lam, 1.0, V1, U0)
+    s.set_factors(U0, V0)
+    objV, info_v = s.update_V()
+    objU, info_u = s.update_U()
+    Ug, Vg = s.get_factors()
+    assert abs(objV / objVo - 1) < 1e-10 and abs(objU / objUo - 1) < 1e-10
+    assert rel(Vg, V1) < 1e-7 and rel(Ug, U1) < 1e-7
+    assert (info_v["cg"], info_v["ls"], info_u["cg"], info_u["ls"]) == (iv["cg"], iv["ls"], iu["cg"], iu["ls"])
+    e, n = s.evaluate(0)
+    eo, no = oracle.eval(Ug, Vg, X)
+    assert abs(e - eo) < 1e-12 and abs(n - no) < 1e-12
