@@ -1822,13 +1822,16 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_obj3(const double* __restrict_
 // search evaluations, cluster time-outs -- and resets the counter block (cnt[0..nzero)) for the next U step: no memset and
 // no second copy on the critical path of the training loop.
 __global__ __launch_bounds__(PCR_EW_BLOCK) void k_fin4(const double* __restrict__ part, int nblk, double* __restrict__ out,
-                                                        unsigned long long* cnt = nullptr, double* cnt_out = nullptr, int nzero = 0) {
+                                                        unsigned long long* cnt = nullptr, double* cnt_out = nullptr, int nzero = 0,
+                                                        int keep1 = 1) {
     __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
     for (int c = 0; c < 4; ++c) {
         double x = 0.0;
         for (int i = threadIdx.x; i < nblk; i += PCR_EW_BLOCK) x += part[4 * i + c];
         x = block_sum<PCR_EW_BLOCK>(x, red);
-        if (threadIdx.x == 0) out[c] = x;
+        // keep1 == 0 (objective sums on ranks > 0): column 1 is the norm of a REPLICATED matrix; only rank 0 contributes it, so
+        // that one all-reduce of the four columns leaves it unchanged
+        if (threadIdx.x == 0) out[c] = (c == 1 && !keep1) ? 0.0 : x;
     }
     if (cnt) {
         if (threadIdx.x == 0) { cnt_out[0] = (double)cnt[0]; cnt_out[1] = (double)cnt[1]; cnt_out[2] = (double)cnt[3]; }

@@ -1031,12 +1031,14 @@ struct Solver final : pcr_solver {
         const int64_t nV = (int64_t)d2 * geo.ld, nU = (int64_t)n_users * geo.ld;
         const int nb = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv(std::max(nV, nU), 4096)));
         hipLaunchKernelGGL((k_obj3<T>), dim3(nb), dim3(PCR_EW_BLOCK), 0, st, objx, objx2, n_users, Vm, nV, with_u ? d_U.p : (const T*)nullptr, nU, d_partA.p);
-        if (after_ustep) hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + slot, d_counters.p, d_scal.p + 12, counter_words());
-        else hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + slot, (unsigned long long*)nullptr, (double*)nullptr, 0);
+        // N ranks: ONE all-reduce of the four columns -- the per-user sums and |U|^2 are shard partials, |Vm|^2 (replicated) is
+        // contributed by rank 0 alone
+        const bool reduce = !((nranks == 1 && !comm) || local_only);
+        const int keep1 = (!reduce || rank == 0) ? 1 : 0;
+        if (after_ustep) hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + slot, d_counters.p, d_scal.p + 12, counter_words(), keep1);
+        else hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + slot, (unsigned long long*)nullptr, (double*)nullptr, 0, keep1);
         HIPCHK(hipGetLastError());
-        RC(allreduce_f64(d_scal.p + slot, 1));
-        if (with_u) RC(allreduce_f64(d_scal.p + slot + 2, 1));
-        if (objx2) RC(allreduce_f64(d_scal.p + slot + 3, 1));
+        RC(allreduce_f64(d_scal.p + slot, 4));
         return PCR_OK;
     }
     int full_objective(const T* Vm, double* obj) {
