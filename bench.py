@@ -196,6 +196,11 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if local_rank == 0 and not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "primalcr_amd", "lib", "libprimalcr.so")):
+        import __graft_entry__                   # clean checkout: compile the product first (no fallback exists)
+        __graft_entry__.build()
+    if N > 1:
+        dist.barrier()                           # (every rank, whether or not it saw the library missing)
     import primalcr_amd as pcr
     from primalcr_amd import synth
 

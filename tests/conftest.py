@@ -15,6 +15,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A clean checkout has no built artefacts (they are git-ignored): compile the product and the checker once, exactly as
+    __graft_entry__.build() does (an up-to-date tree is a no-op of make).  The product itself never builds or falls back on
+    its own: without the library it fails loudly (tests/test_host_abi.py)."""
+    need = [os.path.join(ROOT, "primalcr_amd", "lib", "libprimalcr.so"), os.path.join(ROOT, "primalcr_amd", "bin", "omp-pmf-train"),
+            os.path.join(ROOT, "primalcr_amd", "bin", "omp-pmf-predict")]
+    if not all(os.path.exists(p) for p in need):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The plain-C CPU restatement (oracle/pcr_oracle.c) -- the checker."""
