@@ -505,18 +505,21 @@ __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const
     for (int k = 0; k * G < geo.nchunk; ++k) {
         const int ch = g + k * G;
         const bool act = ch < geo.nchunk;
-        double acc[VEC];
+        // A lane group's running sum (its 1/ngrp share of the user's rows, a few hundred terms at most) is kept in T, as the
+        // running row of k_spmm is; the sums across groups and workgroups are fp64.  For T = float the fp64 multiply-adds
+        // and conversions were most of this loop's VALU work and four more registers per lane.
+        T acc[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
+        for (int e = 0; e < VEC; ++e) acc[e] = (T)0;
         for (int base = r0 + grp; base < n; base += ngrp * UNR) {
             V rv[UNR];
-            double cc[UNR];
+            T cc[UNR];
 #pragma unroll
             for (int q = 0; q < UNR; ++q) {
                 const int row = base + q * ngrp;
-                cc[q] = 0.0;
+                cc[q] = (T)0;
                 if (row < n && act) {
-                    cc[q] = (double)c[row];
+                    cc[q] = (T)c[row];
                     if (LROWS) rv[q] = lds_load_vec(M + (row - r0) * lstride + ch * VEC);
                     else rv[q] = *reinterpret_cast<const V*>(M + (size_t)rows[row] * geo.ld + ch * VEC);
                 }
@@ -526,19 +529,22 @@ __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const
                 const int row = base + q * ngrp;
                 if (row < n && act) {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[e] += cc[q] * (double)velem(rv[q], e);
+                    for (int e = 0; e < VEC; ++e) acc[e] += cc[q] * velem(rv[q], e);
                 }
             }
         }
         // groups of one wave -> one vector
+        double accd[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) accd[e] = (double)acc[e];
         for (int off = G; off < PCR_WAVE; off <<= 1) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] += __shfl_xor(acc[e], off);
+            for (int e = 0; e < VEC; ++e) accd[e] += __shfl_xor(accd[e], off);
         }
         if (k == 0) __syncthreads();
         if (lane < G && act) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) wbuf[wid * geo.ld + ch * VEC + e] = acc[e];
+            for (int e = 0; e < VEC; ++e) wbuf[wid * geo.ld + ch * VEC + e] = accd[e];
         }
     }
     __syncthreads();
