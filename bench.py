@@ -176,6 +176,9 @@ def main():
     ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--profile-period", type=int, default=0,
+                    help="event-time every n-th launch of each kernel (the first one included); 0 = as sparse as leaves a dozen "
+                         "samples of the most frequent kernel (11 launches per step): min(16, 11 * steps / 12)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -235,7 +238,10 @@ def main():
 
     objs = [r["obj"] for r in s.iterate(args.warmup)]
     if not args.no_profile:
-        s.profile(True, period=4)       # sampled: every 4th launch of each kernel carries an event pair
+        # sampled: every n-th launch of each kernel carries an event pair (an event pair costs ~3 us of queue time: every 4th
+        # launch adds 6.6 % to the timed region, every 16th 1.9 %, with the same per-kernel averages)
+        prof_period = args.profile_period if args.profile_period > 0 else max(1, min(16, 11 * args.steps // 12))
+        s.profile(True, period=prof_period)
         s.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -274,14 +280,18 @@ def main():
         # sum of their durations overstates their part of the wall clock: the fork..join wall time of each group
         # ("wall:<class>" slots, timed on the solver's stream) is attributed to its bins in proportion to their
         # durations.  Kernels launched back to back on the solver's stream count with their own duration.
-        wall = {k[5:]: v for k, v in prof.items() if k.startswith("wall:")}
+        # Launches are SAMPLED (every prof_period-th, the first included), so a slot's time in the region is its average
+        # times ALL its launches -- not the sum of its samples, which would favour the slots with few launches.
+        est = {name: ((ms / n) * max(s.profile_launches(name), n) if n else 0.0) for name, (ms, n) in prof.items()}
+        prof_est = {name: (est[name], n) for name, (ms, n) in prof.items()}
+        wall = {k[5:]: v for k, v in prof_est.items() if k.startswith("wall:")}
         cls_sum = {}
-        for name, (ms, n) in prof.items():
+        for name, (ms, n) in prof_est.items():
             cls = name.partition("/")[0]
             if cls in wall:
                 cls_sum[cls] = cls_sum.get(cls, 0.0) + ms
         eff = {}
-        for name, (ms, n) in prof.items():
+        for name, (ms, n) in prof_est.items():
             cls = name.partition("/")[0]
             if name.startswith("wall:"):
                 continue
@@ -319,7 +329,7 @@ def main():
                 "launches_timed": kd["timed_launches"], "algorithmic_bytes_per_launch": kd["algorithmic_bytes"],
                 "share_of_timed_region": kd["share"],
                 "note": "dominant = largest share of the wall clock of the timed region (concurrent length bins share their "
-                        "group's fork..join wall time); event-timed every 4th launch; per-kernel table in 'kernels' "
+                        f"group's fork..join wall time); every {prof_period}th launch of a kernel is event-timed; per-kernel table in 'kernels' "
                         "(DESIGN.md 3.5, 4)"}
     cpu = None
     if N == 1 and not args.no_cpu:

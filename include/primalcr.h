@@ -216,13 +216,15 @@ int pcr_predict(const double *U, int64_t d1, const double *V, int64_t d2, int64_
  * pcr_profile_list writes the comma-separated names of the slots seen so far.
  * pcr_profile_enable(s, n): n = 0 off, 1 time every launch, n > 1 time every n-th launch of each
  * slot (an event pair costs ~3 us of queue time, so sampling keeps the timed region honest);
- * pcr_profile_get returns the summed time and the number of TIMED launches;
+ * pcr_profile_get returns the summed time and the number of TIMED launches, pcr_profile_launches the number of
+ * launches of the slot since the last reset, timed or not (total time of a sampled slot = average x launches);
  * pcr_profile_scope what ONE launch of the slot covers on this rank: the ratings and users of its length
  * class (the whole shard for the rating-/item-parallel kernels), so that a caller can price a launch
  * without mirroring the class layout. */
 int pcr_profile_enable(pcr_solver *s, int on);
 int pcr_profile_list(pcr_solver *s, char *buf, int64_t cap);
 int pcr_profile_get(pcr_solver *s, const char *name, double *total_ms, int64_t *launches);
+int pcr_profile_launches(pcr_solver *s, const char *name, int64_t *launches);
 int pcr_profile_scope(pcr_solver *s, const char *name, int64_t *ratings, int64_t *users);
 int pcr_profile_reset(pcr_solver *s);
 /* blocks until the solver's stream is idle */

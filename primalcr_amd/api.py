@@ -102,6 +102,7 @@ def lib():
     L.pcr_profile_enable.argtypes = [vp, ci]
     L.pcr_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(cd), C.POINTER(i64)]
     L.pcr_profile_scope.argtypes = [vp, C.c_char_p, C.POINTER(i64), C.POINTER(i64)]
+    L.pcr_profile_launches.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
     L.pcr_profile_reset.argtypes = [vp]
     L.pcr_profile_list.argtypes = [vp, C.c_char_p, i64]
     L.pcr_solver_sync.argtypes = [vp]
@@ -327,6 +328,12 @@ class Solver:
         ms, n = C.c_double(), C.c_int64()
         _chk(lib().pcr_profile_get(self._h, name.encode(), ms, n))
         return ms.value, n.value
+
+    def profile_launches(self, name):
+        """Launches of the slot since the last reset, timed or not."""
+        n = C.c_int64()
+        _chk(lib().pcr_profile_launches(self._h, name.encode(), n))
+        return n.value
 
     def profile_scope(self, name):
         """(ratings, users) one launch of the slot covers on this rank."""

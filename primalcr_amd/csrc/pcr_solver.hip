@@ -1564,6 +1564,13 @@ int pcr_profile_get(pcr_solver* s, const char* name, double* total_ms, int64_t* 
     return PCR_OK;
 }
 
+int pcr_profile_launches(pcr_solver* s, const char* name, int64_t* launches) {
+    S_OR_ARG;
+    auto it = s->prof.find(name ? name : "");
+    if (launches) *launches = it == s->prof.end() ? 0 : it->second.seen;
+    return PCR_OK;
+}
+
 int pcr_profile_scope(pcr_solver* s, const char* name, int64_t* ratings, int64_t* users) {
     S_OR_ARG;
     auto it = s->prof.find(name ? name : "");

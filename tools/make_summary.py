@@ -23,7 +23,7 @@ out = [f"# {title}", "",
 rows = list(csv.DictReader(open(f"{src}/kernel_stats.csv")))
 for r in rows[:28]:
     out.append(f"| `{r['Name'][:64]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
-out += ["", "HIP-event averages from the same build inside bench.py (every 4th launch timed; share = wall-clock share of the timed region, concurrent length classes share their group's fork..join wall time):", "",
+out += ["", "HIP-event averages from the same build inside bench.py (sampled launches timed, see the roofline note; share = wall-clock share of the timed region, concurrent length classes share their group's fork..join wall time):", "",
         "| slot | avg us | share | algorithmic MB | algorithmic GB/s | frac of 8 TB/s | PMC bytes/launch (FETCH raw + WRITE) |", "|---|---|---|---|---|---|---|"]
 for k, v in sorted(b["kernels"].items(), key=lambda kv: -kv[1]["share"]):
     out.append(f"| {k} | {v['avg_us']} | {v['share']} | {v['algorithmic_bytes']/1e6:.2f} | {v['achieved_GBs']} | {v['frac_hbm_peak']} | {v['traffic_bytes']} |")
