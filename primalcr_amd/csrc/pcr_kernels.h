@@ -38,6 +38,10 @@ __device__ __forceinline__ float  velem(const float4& a, int e)  { return e == 0
 __device__ __forceinline__ double velem(const double2& a, int e) { return e == 0 ? a.x : a.y; }
 
 struct Geo { int r, ld, nchunk, G; };   // rank, padded row length, 16-byte chunks per row, lanes per row
+// element offset of row `row` of a factor matrix: ONE v_mad_u64_u32.  (size_t)row * geo.ld with the two ints sign-extended is
+// a full 64 x 64-bit multiply -- seven VALU instructions per gathered row in kernels that sit at the issue limit.
+// Row indices are never negative and ld > 0.
+__device__ __forceinline__ size_t row_off(int row, const Geo& geo) { return (size_t)((unsigned long long)(unsigned)row * (unsigned)geo.ld); }
 
 // this rank's training shard on the device
 template <typename T>
@@ -466,7 +470,7 @@ __device__ __forceinline__ void block_sddmm(const T* __restrict__ M, const T* ve
                 const int row = base + q * ngrp;
                 if (row < n && act) {
                     if (LROWS) rv[q] = lds_load_vec(M + (row - r0) * lstride + ch * VEC);
-                    else rv[q] = *reinterpret_cast<const V*>(M + (size_t)rows[row] * geo.ld + ch * VEC);
+                    else rv[q] = *reinterpret_cast<const V*>(M + row_off(rows[row], geo) + ch * VEC);
                 }
             }
             T part[UNR];
@@ -521,7 +525,7 @@ __device__ __forceinline__ void block_gather_axpy(const T* __restrict__ M, const
                 if (row < n && act) {
                     cc[q] = (T)c[row];
                     if (LROWS) rv[q] = lds_load_vec(M + (row - r0) * lstride + ch * VEC);
-                    else rv[q] = *reinterpret_cast<const V*>(M + (size_t)rows[row] * geo.ld + ch * VEC);
+                    else rv[q] = *reinterpret_cast<const V*>(M + row_off(rows[row], geo) + ch * VEC);
                 }
             }
 #pragma unroll
@@ -572,7 +576,7 @@ __device__ __forceinline__ void stage_rows(const T* __restrict__ M, const int32_
     for (int base = (int)(threadIdx.x & ~63u); base < total; base += BLOCK) {
         const int ubase = __builtin_amdgcn_readfirstlane(base);
         if (ubase + lane < total && col < geo.nchunk) {
-            const T* src = M + (size_t)rows[q0 + row] * geo.ld + col * VEC;
+            const T* src = M + row_off(rows[q0 + row], geo) + col * VEC;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (PCR_LDS void*)((PCR_LDS char*)img + (size_t)ubase * 16), 16, 0, 0);
         }
@@ -651,10 +655,10 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(const T* __restrict__ U, const 
                 const int4 u0 = *reinterpret_cast<const int4*>(s_usr + q0), u1 = *reinterpret_cast<const int4*>(s_usr + q0 + 4);
                 const int ri[PCR_UNR] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
 #pragma unroll
-                for (int e = 0; e < PCR_UNR; ++e) rv[e] = *reinterpret_cast<const V*>(M + (size_t)ri[e] * geo.ld + chv * VEC);
+                for (int e = 0; e < PCR_UNR; ++e) rv[e] = *reinterpret_cast<const V*>(M + row_off(ri[e], geo) + chv * VEC);
                 if (u0.x != cur) {                      // at most one reload in front of a same-user batch
                     cur = u0.x;
-                    uv = *reinterpret_cast<const V*>(U + (size_t)cur * geo.ld + chv * VEC);
+                    uv = *reinterpret_cast<const V*>(U + row_off(cur, geo) + chv * VEC);
                     if (!act) uv = V{};
                 }
                 fast = (u0.y == cur) & (u0.z == cur) & (u0.w == cur) & (u1.x == cur) & (u1.y == cur) & (u1.z == cur) & (u1.w == cur);
@@ -667,7 +671,7 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(const T* __restrict__ U, const 
                     for (int e = 0; e < PCR_UNR; ++e) {
                         if (ui8[e] != cur) {
                             cur = ui8[e];
-                            uv = *reinterpret_cast<const V*>(U + (size_t)cur * geo.ld + chv * VEC);
+                            uv = *reinterpret_cast<const V*>(U + row_off(cur, geo) + chv * VEC);
                             if (!act) uv = V{};
                         }
                         part[e] = vdot(rv[e], uv);
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(const T* __restrict__ U, const 
             if (!fast) {                                // ragged tail of the tile
 #pragma unroll
                 for (int e = 0; e < PCR_UNR; ++e)
-                    if (q0 + e < l1) rv[e] = *reinterpret_cast<const V*>(M + (size_t)s_row[q0 + e] * geo.ld + chv * VEC);
+                    if (q0 + e < l1) rv[e] = *reinterpret_cast<const V*>(M + row_off(s_row[q0 + e], geo) + chv * VEC);
 #pragma unroll
                 for (int e = 0; e < PCR_UNR; ++e) {
                     part[e] = (T)0;
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(const T* __restrict__ U, const 
                         const int uu = s_usr[q0 + e];
                         if (uu != cur) {
                             cur = uu;
-                            uv = *reinterpret_cast<const V*>(U + (size_t)uu * geo.ld + chv * VEC);
+                            uv = *reinterpret_cast<const V*>(U + row_off(uu, geo) + chv * VEC);
                             if (!act) uv = V{};
                         }
                         part[e] = vdot(rv[e], uv);
@@ -1009,7 +1013,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const i
                 T* op = reinterpret_cast<T*>(&o);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) { op[e] = (T)acc[e]; acc[e] = (T)0; }
-                *reinterpret_cast<V*>(slab + (size_t)slot_id[inc] * geo.ld + ch * VEC) = o;
+                *reinterpret_cast<V*>(slab + row_off(slot_id[inc], geo) + ch * VEC) = o;
             }
             inc += 1;
         };
@@ -1028,7 +1032,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const i
                     if (q + e8 < cnt) {
                         cc[e8] = __shfl(cr, q + e8, G);
                         uf[e8] = __shfl(ur, q + e8, G);
-                        if (act) rv[e8] = *reinterpret_cast<const V*>(U + (size_t)(uf[e8] & 0x7fffffff) * geo.ld + ch * VEC);
+                        if (act) rv[e8] = *reinterpret_cast<const V*>(U + row_off(uf[e8] & 0x7fffffff, geo) + ch * VEC);
                     }
                 }
 #pragma unroll
@@ -1065,11 +1069,11 @@ __global__ __launch_bounds__(BLOCK) void k_spmm_fin(const T* __restrict__ slab, 
         const int s0 = item_slot[j], s1 = item_slot[j + 1];
         for (int ch = g; ch < geo.nchunk; ch += G) {
             double acc[VEC];
-            const V bv = *reinterpret_cast<const V*>(base + (size_t)j * geo.ld + ch * VEC);
+            const V bv = *reinterpret_cast<const V*>(base + row_off(j, geo) + ch * VEC);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[e] = beta * (double)velem(bv, e);
             for (int sl = s0; sl < s1; ++sl) {
-                const V pv = *reinterpret_cast<const V*>(slab + (size_t)sl * geo.ld + ch * VEC);
+                const V pv = *reinterpret_cast<const V*>(slab + row_off(sl, geo) + ch * VEC);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc[e] += (double)velem(pv, e);
             }
@@ -1077,9 +1081,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmm_fin(const T* __restrict__ slab, 
             T* op = reinterpret_cast<T*>(&o);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) op[e] = (T)acc[e];
-            *reinterpret_cast<V*>(out + (size_t)j * geo.ld + ch * VEC) = o;
+            *reinterpret_cast<V*>(out + row_off(j, geo) + ch * VEC) = o;
             if (DOTS) {
-                const V rv = *reinterpret_cast<const V*>(rr + (size_t)j * geo.ld + ch * VEC);
+                const V rv = *reinterpret_cast<const V*>(rr + row_off(j, geo) + ch * VEC);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     const double pe = (double)velem(bv, e), he = (double)op[e], re = (double)velem(rv, e);
