@@ -1072,10 +1072,18 @@ __global__ __launch_bounds__(BLOCK) void k_spmm_fin(const T* __restrict__ slab, 
             const V bv = *reinterpret_cast<const V*>(base + row_off(j, geo) + ch * VEC);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[e] = beta * (double)velem(bv, e);
-            for (int sl = s0; sl < s1; ++sl) {
-                const V pv = *reinterpret_cast<const V*>(slab + row_off(sl, geo) + ch * VEC);
+            // the item's slab rows are consecutive: eight loads in flight, added in slot order (the same sum as one by one)
+            for (int sl = s0; sl < s1; sl += 8) {
+                V pv[8];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[e] += (double)velem(pv, e);
+                for (int q = 0; q < 8; ++q)
+                    if (sl + q < s1) pv[q] = *reinterpret_cast<const V*>(slab + row_off(sl + q, geo) + ch * VEC);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (sl + q < s1) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[e] += (double)velem(pv[q], e);
+                    }
             }
             V o;
             T* op = reinterpret_cast<T*>(&o);
