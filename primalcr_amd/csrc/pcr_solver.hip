@@ -497,13 +497,32 @@ struct Solver final : pcr_solver {
         make_bins(uptr, nu, &lv.run_ofs, bins);
         for (auto& b : bins) RC(b.d_users.upload(b.users, st));
         // sweep / prepare classes: class 0 = one wave per user, class 1 = one 512-thread workgroup, class 2 = global scratch.
-        // The sweeps keep 12 B per rating in LDS, so a wave can take users of up to 512 ratings (48 KB per 8-wave
-        // workgroup = what a 4096-rating user needs).  That pays when many users lie between 256 and 512 ratings
-        // (long-tailed data: 10 M-rating Netflix-shaped slice 181 -> 163 us per sweep) and costs when few do (ml1m 22.5 -> 25.9 us).
-        int64_t n_256_512 = 0;
-        for (int64_t u = 0; u < nu; ++u) { const int64_t len = uptr[u + 1] - uptr[u]; n_256_512 += len > 256 && len <= 512; }
-        const int sweep_wave_cap = getenv("PCR_SWEEP_WAVE_CAP") ? std::max(64, atoi(getenv("PCR_SWEEP_WAVE_CAP")))     // developer knob
-                                                                 : (n_256_512 > 8 * (int64_t)ncu ? 512 : 256);
+        // The sweeps keep 12 B per rating in LDS.  Where to cut between "a wave per user, eight users per workgroup" and "a
+        // workgroup per user": a higher cut turns whole workgroups into waves (fewer workgroups to run through the CUs) but
+        // lengthens the one-wave chains and, past 384, the LDS of eight waves leaves 3 instead of 4 workgroups per CU.
+        // Cost model = rounds of workgroups through the chip x (1 + cut / 1024), over the candidate cuts (measured: ml1m 256:
+        // 20.4-22.7 us per sweep, 320: 19.4, 384: 20.1-21.0, 512: 25.9; 10 M-rating Netflix-shaped slice 256: 181, 512: 163).
+        int sweep_wave_cap = 256;
+        {
+            std::vector<int64_t> lens(nu);
+            for (int64_t u = 0; u < nu; ++u) lens[u] = uptr[u + 1] - uptr[u];
+            std::sort(lens.begin(), lens.end());
+            const int64_t max_lds = std::upper_bound(lens.begin(), lens.end(), (int64_t)4096) - lens.begin();     // users that fit LDS
+            const int64_t cap_b = max_lds > 0 ? lens[max_lds - 1] : 0;
+            double best = 0.0;
+            for (int c : {256, 320, 384, 448, 512}) {
+                const int64_t n_wave = std::upper_bound(lens.begin(), lens.end(), (int64_t)c) - lens.begin();
+                const int64_t n_blk = std::max<int64_t>(0, max_lds - n_wave);
+                const size_t wave_lds = 8 * ((size_t)c * sizeof(T) + (size_t)(c + 1) * 8 + 64);
+                const size_t blk_lds = n_blk > 0 ? (size_t)cap_b * sizeof(T) + (size_t)(cap_b + 1) * 8 + 1024 : 0;
+                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, ((size_t)160 << 10) / std::max<size_t>(1, std::max(wave_lds, blk_lds))));
+                const double rounds = (double)(cdiv(n_wave, 8) + n_blk) / ((double)ncu * per_cu);
+                const double cost = std::max(rounds, 1.0) * (1.0 + c / 1024.0);
+                if (best == 0.0 || cost < best) { best = cost; sweep_wave_cap = c; }
+            }
+        }
+        if (const char* e = getenv("PCR_SWEEP_WAVE_CAP")) sweep_wave_cap = std::max(64, atoi(e));     // developer knob
+        if (getenv("PCR_DEBUG_LANES")) fprintf(stderr, "[pcr] sweep wave cap %d\n", sweep_wave_cap);
         make_bins(uptr, nu, &lv.run_ofs, sbins, {std::min(sweep_wave_cap, 4095), 4096}, {64, 512, 512});
         for (auto& b : sbins) RC(b.d_users.upload(b.users, st));
         make_bins(uptr, nu, &lv.run_ofs, pbins, {256, 4096}, {64, 512, 512});
