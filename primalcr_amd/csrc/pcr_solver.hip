@@ -525,7 +525,8 @@ struct Solver final : pcr_solver {
         if (getenv("PCR_DEBUG_LANES")) fprintf(stderr, "[pcr] sweep wave cap %d\n", sweep_wave_cap);
         make_bins(uptr, nu, &lv.run_ofs, sbins, {std::min(sweep_wave_cap, 4095), 4096}, {64, 512, 512});
         for (auto& b : sbins) RC(b.d_users.upload(b.users, st));
-        make_bins(uptr, nu, &lv.run_ofs, pbins, {256, 4096}, {64, 512, 512});
+        const int prep_wave_cap = getenv("PCR_PREP_WAVE_CAP") ? std::max(64, std::min(4095, atoi(getenv("PCR_PREP_WAVE_CAP")))) : 256;     // developer knob
+        make_bins(uptr, nu, &lv.run_ofs, pbins, {prep_wave_cap, 4096}, {64, 512, 512});
         for (auto& b : pbins) RC(b.d_users.upload(b.users, st));
         // U step: users with more than 1024 ratings are bound by one CU's gather bandwidth -> clusters of 4 workgroups
         // The U step keeps each user's rows of V in LDS (k_ustep, stage_rows), so its occupancy is set by LDS bytes, not
