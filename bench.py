@@ -337,6 +337,20 @@ def main():
 
     value = n_pairs * args.steps / secs
     passes = (1 + (inner["cg_v"] + inner["ls_v"]) / args.steps) + (1 + (inner["cg_u"] + inner["ls_u"]) / args.steps / max(R.d1, 1))
+    # SURVEY 8d, the whole-iteration figure: compulsory bytes W of one outer iteration with ideal caching (esz-byte factors,
+    # int32 item, uint8 level, esz-byte m, uint32 permutation) at the EXECUTED inner counts, over the measured time per
+    # iteration -- all ranks' bytes over the job's time, against N x 8 TB/s.
+    esz_w = 4 if prec == pcr.PCR_F32 else 8
+    n_cg, n_ls = inner["cg_v"] / args.steps, inner["ls_v"] / args.steps
+    B_csr, F_U, F_V = 5 * R.nnz + 8 * (R.d1 + 1), esz_w * r * R.d1, esz_w * r * R.d2 * N      # V is replicated on every rank
+    P_m, P_sort = B_csr + F_U + F_V + esz_w * R.nnz, 8 * R.nnz
+    P_hv, P_obj, P_u = B_csr + 8 * R.nnz + F_U + 2 * F_V, B_csr + 8 * R.nnz, B_csr + esz_w * R.nnz + 2 * F_U + F_V
+    W = P_m + P_sort + P_hv + n_cg * P_hv + P_obj + n_ls * (P_m + P_sort + P_obj) + P_u
+    it_roof = {"bound": "hbm", "algorithmic_bytes_per_iteration": int(W), "achieved": round(W / (secs / args.steps) / 1e9, 2),
+               "peak": HBM_PEAK_GBS * N, "unit": "GB/s", "frac": round(W / (secs / args.steps) / 1e9 / (HBM_PEAK_GBS * N), 5),
+               "note": "SURVEY 8d: W = P_m + P_sort + P_g + n_cg P_Hv + P_obj + n_ls (P_m + P_sort + P_obj) + P_U at the executed "
+                       "n_cg, n_ls; the factor tables of this shape are L2-resident, so the path is gather/latency-bound and "
+                       "this fraction is small by construction (DESIGN.md 3.5)"}
     out = {
         "metric": "pairwise-comparisons/sec", "value": value, "unit": "pairs/s", "n_gpus": N, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps, "higher_is_better": True, "scaling": scaling,
@@ -351,7 +365,7 @@ def main():
         # SURVEY 8d, kernel-level figure: ordered pairs swept per second over the EXECUTED sweep passes of a step
         # (V side: gradient + Hessian-vector products + line-search objectives; U side the same per user, averaged)
         "passes_per_step": passes, "sweep_pairs_per_s": value * passes, "s_per_iter": secs / args.steps,
-        "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+        "roofline": roof, "roofline_iteration": it_roof, "cpu_baseline": cpu, "kernels": kernels,
     }
     if cpu:
         out["speedup_vs_cpu_baseline"] = value / cpu["value"]
