@@ -351,6 +351,17 @@ def main():
                "note": "SURVEY 8d: W = P_m + P_sort + P_g + n_cg P_Hv + P_obj + n_ls (P_m + P_sort + P_obj) + P_U at the executed "
                        "n_cg, n_ls; the factor tables of this shape are L2-resident, so the path is gather/latency-bound and "
                        "this fraction is small by construction (DESIGN.md 3.5)"}
+    # SURVEY 8d, secondary (diagnostic) figure: row-gather bytes.  One SDDMM or SpMM half-pass moves G = esz * r bytes per
+    # rating; per outer iteration the V side makes (1 + n_ls) SDDMMs of the prepares + n_cg of the CG + (1 + n_cg) SpMMs, the
+    # U side per rating 1 (gradient) + 2 per CG iteration + 1 per line-search try.
+    G = esz_w * r * R.nnz
+    n_cg_u, n_ls_u = inner["cg_u"] / args.steps / max(R.d1, 1), inner["ls_u"] / args.steps / max(R.d1, 1)
+    gather_passes = (n_ls + n_cg) + (1 + n_cg) + (1 + 2 * n_cg_u + n_ls_u)
+    gather = {"bytes_per_half_pass": int(G), "half_passes_per_iteration": round(gather_passes, 2),
+              "achieved_GBs": round(gather_passes * G / (secs / args.steps) / 1e9, 1),
+              "note": "row gathers (one esz*r-byte factor row per rating and half-pass) sustained over the WHOLE iteration, all "
+                      "ranks; on this shape they are served by the L2s (user-average CG / line-search counts on the U side; the U step "
+                      "of users with <= 64 ratings loads its rows once and re-reads them from LDS)"}
     out = {
         "metric": "pairwise-comparisons/sec", "value": value, "unit": "pairs/s", "n_gpus": N, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps, "higher_is_better": True, "scaling": scaling,
@@ -365,7 +376,7 @@ def main():
         # SURVEY 8d, kernel-level figure: ordered pairs swept per second over the EXECUTED sweep passes of a step
         # (V side: gradient + Hessian-vector products + line-search objectives; U side the same per user, averaged)
         "passes_per_step": passes, "sweep_pairs_per_s": value * passes, "s_per_iter": secs / args.steps,
-        "roofline": roof, "roofline_iteration": it_roof, "cpu_baseline": cpu, "kernels": kernels,
+        "roofline": roof, "roofline_iteration": it_roof, "gather": gather, "cpu_baseline": cpu, "kernels": kernels,
     }
     if cpu:
         out["speedup_vs_cpu_baseline"] = value / cpu["value"]
