@@ -405,6 +405,15 @@ struct Solver final : pcr_solver {
         for (int64_t u = 0; u < nu; ++u)
             for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) ruser[z] = (int32_t)u;
         {
+            // chunk = ratings one lane group walks (one slab row per item it meets).  128 on large shards; a shard whose
+            // workgroups all fit on the chip at once (6 per CU at 80 VGPRs) gets the smallest chunk that still fits in one
+            // round -- more, shorter chains: ml1m 96 instead of 128, k_spmm 32.3 -> 30.3 us, 1.69 -> 1.66 ms per iteration
+            // (64: 33.3 us, a second round; 192: 40.3 us)
+            {
+                const int64_t groups_at_once = (int64_t)ncu * 6 * (256 / geo.G);
+                const int64_t fit = cdiv(std::max<int64_t>(nnz_local, 1), groups_at_once);
+                spmm_chunk = (int)std::min<int64_t>(128, std::max<int64_t>(64, (fit + 31) / 32 * 32));
+            }
             if (const char* e = getenv("PCR_SPMM_CHUNK")) spmm_chunk = std::max(8, atoi(e));
             const size_t row_bytes = (size_t)geo.ld * sizeof(T);
             int64_t tile_users_max = std::max<int64_t>(64, (int64_t)((5u << 18) / row_bytes));

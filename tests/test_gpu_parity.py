@@ -263,6 +263,7 @@ VARIANTS = [
     {"PCR_UBINS": "64:64:0,512:256:0"},                          # no LDS-resident rows, coarser classes
     {"PCR_UBINS": "16:64:1,48:64:1,200:256:0,700:256:0"},        # other class bounds
     {"PCR_SPMM_TILES": "5"}, {"PCR_SPMM_TILES": "16"}, {"PCR_SPMM_TILES": "64"},   # user tiles of the SpMM (incl. more tiles than XCDs)
+    {"PCR_SPMM_CHUNK": "32"}, {"PCR_SPMM_CHUNK": "128"},         # ratings per SpMM lane group (the default adapts to the shard: 64 here)
     {"PCR_LANES": "1"},                                          # every class on the solver's stream
     {"PCR_SDDMM_CSC": "1"}, {"PCR_SDDMM_CSC": "1", "PCR_SPMM_TILES": "16"},   # the CG's SDDMM over the tile-major CSC (wide item tables)
 ]
@@ -412,7 +413,9 @@ def test_fuzz_small_shapes_against_oracle(oracle):
         got = s.iterate(2)
         tag = dict(case=case, d1=d1, d2=d2, r=r, nlev=nlev, solver=solver, real=real, lam=lam, nnz=int(user.size))
         for g, o in zip(got, recs[1:]):
-            assert abs(g["obj"] - o["obj"]) <= 1e-9 * max(abs(o["obj"]), 1.0), (tag, g["obj"], o["obj"])
+            # (1e-8: case 17 -- solver 1, r = 64, the objective falls 1e7 -> 1e5 -> 1e4 -- amplifies summation-order rounding to
+            # 1.0e-9 / 1.3e-9 depending on the SpMM chunk length, with identical inner counts; see tools/dbg_fuzz.py)
+            assert abs(g["obj"] - o["obj"]) <= 1e-8 * max(abs(o["obj"]), 1.0), (tag, g["obj"], o["obj"])
             assert (g["cg_v"], g["ls_v"], g["cg_u"], g["ls_u"]) == (o["cg_v"], o["ls_v"], o["cg_u"], o["ls_u"]), tag
         Ug, Vg = s.get_factors()
         scale = max(np.abs(Uo).max(), np.abs(Vo).max(), 1e-3)            # (a side without any comparable pair is driven to ~1e-17)
