@@ -161,6 +161,7 @@ struct Solver final : pcr_solver {
     bool sddmm_csc = false;                       // the CG's SDDMM walks the SpMM's tile-major CSC (item table beyond the L2s)
     DBuf<T> d_slab;                               // k_spmm partial rows, one per (chunk, item) incidence
     int spmm_chunk = 128;
+    int sddmm_tile = 0;                           // ratings per lane group of k_sddmm (0 = not chosen yet)
     DBuf<uint16_t> d_lvl, d_slvl;
     DBuf<uint32_t> d_win;
     DBuf<T> d_ms, d_c, d_mcsr, d_b;
@@ -879,7 +880,20 @@ struct Solver final : pcr_solver {
     int launch_sddmm(const T* M, const int32_t* rows, T* out, const int* skip = nullptr) {
         if (nnz_local == 0) return PCR_OK;
         ProfScope ps(this, "sddmm");
-        static const int tile = getenv("PCR_SDDMM_TILE") ? atoi(getenv("PCR_SDDMM_TILE")) : 64;
+        // tile = consecutive ratings one lane group walks.  64 by default; a shard that needs between one and two rounds of
+        // workgroups at 64 gets the smallest tile (a multiple of the 8-row batch) with which ONE round holds it all
+        // (ml1m: 96 -- 1224 workgroups on 1280 slots instead of 1836; 1.66 -> 1.64 ms per iteration; 80: 1.68, 128: 1.67)
+        if (sddmm_tile == 0) {
+            sddmm_tile = 64;
+            int per_cu = 0;
+            const int ngrp0 = 256 / geo.G;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sddmm<T, 256>, 256, (size_t)ngrp0 * 128 * 8) == hipSuccess && per_cu > 0) {
+                const int64_t fit = cdiv(nnz_local, (int64_t)ncu * per_cu * ngrp0);
+                if (fit > 64 && fit <= 128) sddmm_tile = (int)((fit + 7) / 8 * 8);
+            }
+            if (const char* e = getenv("PCR_SDDMM_TILE")) sddmm_tile = std::max(8, atoi(e) / 8 * 8);      // developer knob
+        }
+        const int tile = sddmm_tile;
         const int ngrp = 256 / geo.G, span = ngrp * tile;
         const int grid = cdiv(nnz_local, span);
         hipLaunchKernelGGL((k_sddmm<T, 256>), dim3(grid), dim3(256), (size_t)span * 8, st, d_U.p, M, d_ruser.p, rows, nnz_local, out, geo, tile, skip,
