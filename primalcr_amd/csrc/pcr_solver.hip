@@ -574,7 +574,7 @@ struct Solver final : pcr_solver {
         ucap.push_back(4096); ublk.push_back(512); ublk.push_back(512);
         make_bins(uptr, nu, &lv.run_ofs, ubins, ucap, ublk);
         // Workgroup clusters trade throughput for latency: only the longest users of the shard (the critical path, more than
-        // 1024 ratings) get them, ncu/(2K) users so that all their workgroups fit the chip at once -- ONE extra class
+        // 1024 ratings) get them, ncu/(4K) users (all their workgroups fit the chip at once, see below) -- ONE extra class
         // whatever length class they came from (in global scratch if any of them needs it).  PCR_CLUSTER_K=1 disables.
         int cluster_k = 4;
         if (const char* e = getenv("PCR_CLUSTER_K")) cluster_k = atoi(e) == 4 ? 4 : 1;
@@ -582,7 +582,11 @@ struct Solver final : pcr_solver {
         if (cluster_k > 1) {
             Bin head;
             head.block = 512; head.K = cluster_k;
-            size_t budget = (size_t)std::max(1, ncu / (2 * cluster_k));
+            // ncu / (4K) users = a quarter of the CUs: every cluster workgroup keeps a CU to itself (its LDS image) for the
+            // whole launch, CUs the many short users cannot use meanwhile -- ml1m: 8 users 1.610 ms, 12-20: 1.59-1.61, 24: 1.63,
+            // 32: 1.645, 48: 1.79 per iteration; 10 M-rating Netflix-shaped slice: U step 7.24 (32) -> 6.98 ms (16)
+            size_t budget = (size_t)std::max(1, ncu / (4 * cluster_k));
+            if (const char* e = getenv("PCR_CLUSTER_USERS")) budget = (size_t)std::max(1, std::min(atoi(e), ncu / cluster_k));     // developer knob
             for (size_t q = ubins.size(); q-- > nsmall + 1 && budget > 0;) {       // longest class first; users are sorted longest first
                 Bin& b = ubins[q];
                 const size_t take = std::min(budget, b.users.size());
