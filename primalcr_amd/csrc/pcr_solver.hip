@@ -542,10 +542,12 @@ struct Solver final : pcr_solver {
         // The U step keeps each user's rows of V in LDS (k_ustep, stage_rows), so its occupancy is set by LDS bytes, not
         // registers: finer length classes than the V side, and a workgroup size that grows with the class.
         // PCR_UBINS="cap:block,..." overrides the classes below 1024 (developer knob).
-        // Measured (ml1m shape, k = 100): residency pays for users of <= 64 ratings (7 / 4 one-wave workgroups per CU still
-        // fit); above that the LDS image leaves 1-2 workgroups per CU and the lost occupancy costs more than the faster
-        // passes gain, so those classes gather from L2 with 16 waves per CU.
-        std::vector<int> ucap = {32, 64, 128, 512}, ublk = {64, 64, 64, 256}, ures = {1, 1, 0, 0};
+        // Measured (ml1m shape, k = 100): residency pays for users of <= 32 ratings (13 KB of rows: 10 one-wave workgroups
+        // per CU still fit); above that the LDS image costs more occupancy than the faster passes gain -- the 33..64 class
+        // was resident until its non-resident form got leaner (108 VGPRs against 124): 1.622 -> 1.604 ms, 10 M-rating
+        // Netflix-shaped slice 82.5 -> 80.9 ms over 4 iterations; 65..128 resident: 1.80 ms -- so those classes gather from
+        // the L2s with 16 waves per CU.
+        std::vector<int> ucap = {32, 64, 128, 512}, ublk = {64, 64, 64, 256}, ures = {1, 0, 0, 0};
         if (const char* e = getenv("PCR_UBINS")) {                 // "cap:block:resident,..."
             ucap.clear(); ublk.clear(); ures.clear();
             for (const char* q = e; *q;) {
