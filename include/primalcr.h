@@ -110,6 +110,11 @@ int pcr_dataset_from_triplets(int64_t d1, int64_t d2,
                               int64_t nnz, const int32_t *user, const int32_t *item, const double *val,
                               int64_t tnnz, const int32_t *tuser, const int32_t *titem, const double *tval,
                               pcr_dataset **out);                          /* [host] */
+/* the same from arrays already in the reference's SparseMat layout (util.h:390-413, what convert() leaves,
+ * util.cpp:219-274): index[d1+1], item[nnz] ascending inside a user, val[nnz]; the test CSR (tindex may be NULL) is
+ * taken as given. */
+int pcr_dataset_from_csr(int64_t d1, int64_t d2, const int64_t *index, const int32_t *item, const double *val,
+                         const int64_t *tindex, const int32_t *titem, const double *tval, pcr_dataset **out);   /* [host] */
 void pcr_dataset_free(pcr_dataset *ds);                                    /* [host] */
 /* sizes: d1, d2, nnz (train), tnnz (test entries assigned by convert()) */
 int pcr_dataset_dims(const pcr_dataset *ds, int64_t *d1, int64_t *d2, int64_t *nnz, int64_t *tnnz);
@@ -132,6 +137,31 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
 /* ------------------------------------------------------------------------- */
 /* device solver                                                             */
 /* ------------------------------------------------------------------------- */
+
+/* Launch knobs.  The reference has none (its only scheduling choice is `#pragma omp ... schedule(dynamic,500)`,
+ * pcrpp.cpp:825); the device solver chooses its launch configuration from the shape of the shard, and these process-wide
+ * key/value pairs override single choices -- for the parity tests (every configuration must give the same trajectory)
+ * and for A/B measurements.  Read once by pcr_solver_create; value NULL removes a key; unknown keys are PCR_ERR_ARG.
+ * No environment variable is read anywhere on the product path.
+ *   ustep_mode      1 = latency form of k_ustep for every long class, 2 = throughput form (default: by user count)
+ *   ustep_many      user count above which a long class counts as throughput-bound (default CUs/4)
+ *   ustep_seq       1 = the U step's length classes back to back on one stream
+ *   ustep_lockstep  U step as rating-parallel lock-step passes over all users: 1 on, 0 off (default: by shard size)
+ *   ustep_gram      dual (Gram-matrix, MFMA) U step for users with at most that many ratings; 0 off (default by rank)
+ *   cluster_k       4 (default) or 1: workgroups per clustered long user;  cluster_users: how many users get clusters
+ *   ubins           "cap:block:resident,..." length classes of the U step below 1024 ratings
+ *   spmm_tiles, spmm_chunk, sddmm_tile, sddmm_csc   tiling of the rating-parallel kernels
+ *   sweep_wave_cap  ratings up to which a sweep gives a user one wave
+ *   window_cache    0 = sweeps search their hinge windows instead of caching them
+ *   prepare_merged  0 = one prepare launch per length class
+ *   cg_fused        persistent one-launch CG iteration: 1 on, 0 off (default: by shard size)
+ *   lanes           concurrent streams for length classes (1 = none);  pipeline: 0 = host round trip after every U step
+ *   eval_brute      1 = O(len^2) evaluator
+ *   comm            "rccl" (default) | "p2p": all-reduce of the V-side vectors through peer-mapped buffers
+ *   debug           1 = print launch decisions to stderr
+ *   fault_cluster_member   test hook: one member of every workgroup cluster leaves early (the launch must report
+ *                   PCR_ERR_DEVICE through the bounded hand-off wait instead of hanging) */
+int pcr_tune(const char *key, const char *value);                          /* [host] */
 
 typedef struct pcr_solver pcr_solver;
 

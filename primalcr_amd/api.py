@@ -72,7 +72,9 @@ def lib():
     L.pcr_dataset_load_cache.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.pcr_dataset_save_cache.argtypes = [vp, C.c_char_p]
     L.pcr_dataset_from_triplets.argtypes = [i64, i64, i64, vp, vp, vp, i64, vp, vp, vp, C.POINTER(vp)]
+    L.pcr_dataset_from_csr.argtypes = [i64, i64, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
     L.pcr_dataset_free.argtypes = [vp]
+    L.pcr_tune.argtypes = [C.c_char_p, C.c_char_p]
     L.pcr_dataset_dims.argtypes = [vp] + [C.POINTER(i64)] * 4
     L.pcr_dataset_csr.argtypes = [vp, ci, vp, vp, vp]
     L.pcr_dataset_count_pairs.argtypes = [vp, ci]
@@ -113,6 +115,28 @@ def lib():
 def _chk(rc):
     if rc != 0:
         raise PcrError(f"libprimalcr error {rc}: {lib().pcr_last_error().decode()}")
+
+
+def tune(key, value=None):
+    """pcr_tune(): a process-wide launch knob read by the next Solver (value None removes it)."""
+    _chk(lib().pcr_tune(key.encode(), None if value is None else str(value).encode()))
+
+
+class tuned:
+    """with tuned(spmm_tiles=16, lanes=1): ... -- knobs set for the block, removed afterwards."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            tune(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            tune(k, None)
+        return False
 
 
 def initial(n, k):
@@ -199,7 +223,23 @@ class Dataset:
         return cls(h)
 
     @classmethod
+    def from_csr(cls, d1, d2, index, item, val, tindex=None, titem=None, tval=None):
+        """From arrays already in the SparseMat layout (index int64[d1+1], item int32 ascending per user, val float64)."""
+        index = np.ascontiguousarray(index, np.int64); item = np.ascontiguousarray(item, np.int32)
+        val = np.ascontiguousarray(val, np.float64)
+        targs = (None, None, None)
+        if tindex is not None:
+            tindex = np.ascontiguousarray(tindex, np.int64); titem = np.ascontiguousarray(titem, np.int32)
+            tval = np.ascontiguousarray(tval, np.float64)
+            targs = (tindex.ctypes.data, titem.ctypes.data, tval.ctypes.data)
+        h = C.c_void_p()
+        _chk(lib().pcr_dataset_from_csr(d1, d2, index.ctypes.data, item.ctypes.data, val.ctypes.data, *targs, C.byref(h)))
+        return cls(h)
+
+    @classmethod
     def from_ratings(cls, R):
+        if hasattr(R, "index"):                       # synth.CsrRatings (the C++ generator): no triplet round trip
+            return cls.from_csr(R.d1, R.d2, R.index, R.item, R.val, R.tindex, R.titem, R.tval)
         return cls.from_triplets(R.d1, R.d2, R.user, R.item, R.val, R.tuser, R.titem, R.tval)
 
     def dims(self):

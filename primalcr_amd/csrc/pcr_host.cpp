@@ -129,6 +129,75 @@ extern "C" int pcr_dataset_from_triplets(int64_t d1, int64_t d2, int64_t nnz, co
     return PCR_OK;
 }
 
+// The same data set from arrays that already ARE the reference's SparseMat layout (util.h:390-413: what convert() leaves,
+// util.cpp:219-274): index[d1+1], item[nnz], val[nnz], items ascending inside a user for the training set (checked; the
+// test set is taken as given).  No triplet round trip for callers that hold CSRs (100 M-rating synthetic sets).
+extern "C" int pcr_dataset_from_csr(int64_t d1, int64_t d2, const int64_t* index, const int32_t* item, const double* val,
+                                    const int64_t* tindex, const int32_t* titem, const double* tval, pcr_dataset** out) {
+    if (!out || d1 < 0 || d2 < 0 || !index || index[0] != 0 || (tindex && tindex[0] != 0)) {
+        pcr_set_error("pcr_dataset_from_csr: bad argument");
+        return PCR_ERR_ARG;
+    }
+    const int64_t nnz = index[d1], tnnz = tindex ? tindex[d1] : 0;
+    if (nnz < 0 || tnnz < 0 || (nnz > 0 && (!item || !val)) || (tnnz > 0 && (!titem || !tval))) {
+        pcr_set_error("pcr_dataset_from_csr: bad argument");
+        return PCR_ERR_ARG;
+    }
+    for (int64_t u = 0; u < d1; ++u) {
+        if (index[u + 1] < index[u] || (tindex && tindex[u + 1] < tindex[u])) { pcr_set_error("pcr_dataset_from_csr: index not monotone"); return PCR_ERR_ARG; }
+        for (int64_t z = index[u]; z < index[u + 1]; ++z)
+            if (item[z] < 0 || item[z] >= d2 || (z > index[u] && item[z] <= item[z - 1])) {
+                pcr_set_error("pcr_dataset_from_csr: user " + std::to_string(u) + ": item ids must be ascending and inside [0, d2)");
+                return PCR_ERR_ARG;
+            }
+    }
+    for (int64_t z = 0; z < tnnz; ++z)
+        if (titem[z] < 0 || titem[z] >= d2) { pcr_set_error("pcr_dataset_from_csr: test item id outside [0, d2)"); return PCR_ERR_ARG; }
+    pcr_dataset* ds = new (std::nothrow) pcr_dataset();
+    if (!ds) { pcr_set_error("out of memory"); return PCR_ERR_NOMEM; }
+    ds->train.d1 = ds->test.d1 = d1; ds->train.d2 = ds->test.d2 = d2;
+    ds->train.index.assign(index, index + d1 + 1);
+    ds->train.item.assign(item, item + nnz);
+    ds->train.val.assign(val, val + nnz);
+    if (tindex) ds->test.index.assign(tindex, tindex + d1 + 1); else ds->test.index.assign(d1 + 1, 0);
+    ds->test.item.assign(titem, titem + tnnz);
+    ds->test.val.assign(tval, tval + tnnz);
+    ds->tnnz_file = tnnz;
+    *out = ds;
+    return PCR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// launch knobs (pcr_tune): a process-wide key/value table the solver consults when it is created
+// ------------------------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+static std::mutex g_tune_mu;
+static std::map<std::string, std::string>& tune_table() { static std::map<std::string, std::string> t; return t; }
+static const char* const TUNE_KEYS[] = {"ustep_mode", "ustep_many", "cluster_k", "cluster_users", "ubins", "spmm_tiles", "spmm_chunk", "sddmm_tile",
+                                        "sddmm_csc", "lanes", "window_cache", "prepare_merged", "sweep_wave_cap", "eval_brute", "pipeline",
+                                        "ustep_seq", "ustep_lockstep", "ustep_gram", "cg_fused", "comm", "debug", "fault_cluster_member", nullptr};
+extern "C" int pcr_tune(const char* key, const char* value) {
+    if (!key) { pcr_set_error("pcr_tune: null key"); return PCR_ERR_ARG; }
+    bool known = false;
+    for (const char* const* k = TUNE_KEYS; *k; ++k) known = known || !strcmp(*k, key);
+    if (!known) { pcr_set_error(std::string("pcr_tune: unknown key '") + key + "'"); return PCR_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    if (value) tune_table()[key] = value; else tune_table().erase(key);
+    return PCR_OK;
+}
+bool pcr_tune_get(const char* key, std::string* out) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = tune_table().find(key);
+    if (it == tune_table().end()) return false;
+    if (out) *out = it->second;
+    return true;
+}
+int pcr_tune_int(const char* key, int dflt) {
+    std::string v;
+    return pcr_tune_get(key, &v) ? atoi(v.c_str()) : dflt;
+}
+
 // ------------------------------------------------------------------------------------------
 // text loader (util.cpp:6-25, util.h:118-131, util.h:360-371)
 // ------------------------------------------------------------------------------------------

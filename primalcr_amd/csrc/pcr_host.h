@@ -34,3 +34,7 @@ struct PcrLevels {
 int pcr_build_levels(const PcrCsr& X, int64_t u0, int64_t u1, int solver_type, PcrLevels& out, std::string& err);
 
 void pcr_set_error(const std::string& msg);
+
+// launch knobs set through pcr_tune() (include/primalcr.h): consulted by the solver when it is created
+bool pcr_tune_get(const char* key, std::string* out);
+int pcr_tune_int(const char* key, int dflt);

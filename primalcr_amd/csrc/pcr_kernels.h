@@ -1128,6 +1128,7 @@ struct CGState {
     double g2, err, pHp, rp, alpha, rr2, rHp, beta;
     double rr2buf[2];      // |rr|^2 after iteration k lives in rr2buf[k & 1] (double-buffered: readers and the writer of one launch never share a slot)
     int done, iters;
+    int done_at, pad_;     // iteration whose update met the stop test (0: none yet)
 };
 
 #define PCR_EW_BLOCK 256
@@ -1214,6 +1215,7 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_init_fin(const double* __re
         st->err = sqrt(a) * tol;             // pcrpp.cpp:340 (tol = 0.01 there)
         st->done = 0;
         st->iters = 0;
+        st->done_at = 0;
         st->rr2buf[0] = a;                   // rr = -g
     }
 }
@@ -1245,12 +1247,19 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_a(const T* __restrict__ p, 
 //     |rr + a Hp|^2 = |rr|^2 + 2 a rr.Hp + a^2 Hp.Hp,      (rr + a Hp).Hp = rr.Hp + a Hp.Hp,
 // so beta and the stop test are known before the update and one kernel does what took two (and a grid-wide reduction
 // between them).  Every block reduces the short partial array identically: deterministic.
-template <typename T>
+// EXACT (a caller-set cg_tol below 1e-5): the recurrence for |rr|^2 cancels catastrophically once the residual has dropped
+// by many orders of magnitude, so the stop test is taken on the directly summed |rr_new|^2 instead: this kernel leaves its
+// partials in part_rr and always updates p, k_cg_stop (one block) decides.
+template <typename T, bool EXACT>
 __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_bc(T* __restrict__ p, const T* __restrict__ Hp, T* __restrict__ rr,
                                                          T* __restrict__ delta, int64_t n, int per_block, int nblk,
-                                                         const double* __restrict__ part, CGState* st, int k) {
+                                                         const double* __restrict__ part, CGState* st, int k,
+                                                         double* __restrict__ part_rr) {
     __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
-    if (st->done) return;     // CG already converged: later iterations are queued but idle
+    // CG already converged in an EARLIER launch: later iterations are queued but idle.  (done_at == k can only have been
+    // written by the last block of THIS launch: a block that starts late must still do its slice.)
+    const int da = st->done_at;
+    if (da != 0 && da < k) return;
     double s4[4];
     for (int c = 0; c < 4; ++c) {
         double x = 0.0;
@@ -1263,23 +1272,43 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_bc(T* __restrict__ p, const
     double rr2 = rr2_old + 2.0 * alpha * rHp0 + alpha * alpha * HpHp;
     rr2 = rr2 > 0.0 ? rr2 : 0.0;
     const double rHp = rHp0 + alpha * HpHp;
-    const bool conv = sqrt(rr2) < st->err;                  // pcrpp.cpp:350
+    const bool conv = !EXACT && sqrt(rr2) < st->err;        // pcrpp.cpp:350
     const double beta = rHp / pHp;
     const int64_t lo = (int64_t)blockIdx.x * per_block;
     const int64_t hi = (lo + per_block < n) ? lo + per_block : n;
+    double x2 = 0.0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += PCR_EW_BLOCK) {
         const double pv = (double)p[i], hv = (double)Hp[i];
         delta[i] = (T)((double)delta[i] + pv * alpha);
         const T rn = (T)((double)rr[i] + hv * alpha);
         rr[i] = rn;
+        if (EXACT) x2 += (double)rn * (double)rn;
         if (!conv) p[i] = (T)((double)rn * -1.0 + pv * beta);
     }
+    if (EXACT) {
+        x2 = block_sum<PCR_EW_BLOCK>(x2, red);
+        if (threadIdx.x == 0) { part_rr[2 * blockIdx.x] = x2; part_rr[2 * blockIdx.x + 1] = 0.0; }
+    }
     // The host queues all 10 iterations without waiting; once `done` is set every later kernel of the solve returns at
-    // once.  Blocks of THIS launch read `done` and rr2buf[(k-1)&1] only, which nobody writes during this launch.
+    // once.  Blocks of THIS launch read done_at (see above) and rr2buf[(k-1)&1] only.
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         st->pHp = pHp; st->rp = rp; st->alpha = alpha; st->rr2 = rr2; st->rHp = rHp; st->beta = beta;
-        st->rr2buf[k & 1] = rr2; st->iters += 1;
-        if (conv) st->done = 1;
+        st->iters += 1;
+        if (!EXACT) {
+            st->rr2buf[k & 1] = rr2;
+            if (conv) { st->done_at = k; st->done = 1; }
+        }
+    }
+}
+// stop test of iteration k on the directly summed residual (k_cg_bc<EXACT>)
+__global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_stop(const double* __restrict__ part_rr, int nblk, CGState* st, int k) {
+    __shared__ double red[PCR_EW_BLOCK / PCR_WAVE + 1];
+    if (st->done) return;
+    double a, b;
+    reduce_partials2(part_rr, nblk, &a, &b, red);
+    if (threadIdx.x == 0) {
+        st->rr2 = a; st->rr2buf[k & 1] = a;
+        if (sqrt(a) < st->err) { st->done_at = k; st->done = 1; }
     }
 }
 
@@ -1360,9 +1389,12 @@ template <typename T, int BLOCK, bool BIG, int K, bool RES, int UNR>
 __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                  T* __restrict__ U, const T* __restrict__ Vm, double lambda, double stepsize0,
                                                  int cg_max, double cg_tol, int strict, int solver1, int cap, int cap_pad, int rs_cap, int rcap, int nchp,
-                                                 char* scratch, size_t stride, unsigned long long* counters, ClusterBufs cb) {
+                                                 char* scratch, size_t stride, unsigned long long* counters, ClusterBufs cb, int fault) {
     typedef typename LiSel<T, BIG>::type LI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // test hook (pcr_tune "fault_cluster_member"): the last member of every cluster leaves at once, so that the others run
+    // into the bounded wait of cluster_barrier and the launch reports a time-out instead of hanging
+    if (K > 1 && fault && (int)(blockIdx.x % K) == K - 1) return;
     Carver small(smem);
     T* vecT = small.take<T>(geo.ld);
     double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
@@ -1852,7 +1884,7 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_fin4(const double* __restrict_
         if (threadIdx.x == 0) out[c] = (c == 1 && !keep1) ? 0.0 : x;
     }
     if (cnt) {
-        if (threadIdx.x == 0) { cnt_out[0] = (double)cnt[0]; cnt_out[1] = (double)cnt[1]; cnt_out[2] = (double)cnt[3]; }
+        if (threadIdx.x == 0) { cnt_out[0] = (double)cnt[0]; cnt_out[1] = (double)cnt[1]; cnt_out[2] = (double)cnt[3]; cnt_out[3] = 0.0; }
         __syncthreads();
         for (int i = threadIdx.x; i < nzero; i += PCR_EW_BLOCK) cnt[i] = 0ull;
     }

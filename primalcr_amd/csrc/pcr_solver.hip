@@ -126,9 +126,27 @@ struct pcr_solver {
     virtual void prof_prewarm(int n) = 0;
 };
 
+// launch knobs: pcr_tune() values read once when the solver is created (include/primalcr.h lists them)
+struct Tune {
+    int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
+        cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = 1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
+        fault_cluster_member = 0;
+    std::string ubins;
+    void read() {
+        lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
+        sddmm_csc = pcr_tune_int("sddmm_csc", -1); sddmm_tile = pcr_tune_int("sddmm_tile", 0); sweep_wave_cap = pcr_tune_int("sweep_wave_cap", 0);
+        ustep_mode = pcr_tune_int("ustep_mode", 0); ustep_many = pcr_tune_int("ustep_many", 0); cluster_k = pcr_tune_int("cluster_k", 4);
+        cluster_users = pcr_tune_int("cluster_users", 0); window_cache = pcr_tune_int("window_cache", 1);
+        prepare_merged = pcr_tune_int("prepare_merged", 1); ustep_seq = pcr_tune_int("ustep_seq", 0); eval_brute = pcr_tune_int("eval_brute", 0);
+        pipeline = pcr_tune_int("pipeline", 1); debug = pcr_tune_int("debug", 0); fault_cluster_member = pcr_tune_int("fault_cluster_member", 0);
+        ubins.clear(); pcr_tune_get("ubins", &ubins);
+    }
+};
+
 template <typename T>
 struct Solver final : pcr_solver {
     pcr_params prm;
+    Tune tune;
     int rank = 0, nranks = 1;
     int64_t d1 = 0, d2 = 0, tnnz_file = 0;
     Geo geo;
@@ -308,15 +326,15 @@ struct Solver final : pcr_solver {
         const long long ticks = (long long)khz * 300 / 1000;       // 300 us
         for (int i = 0; i < MAXLANE; ++i) HIPCHK(hipEventCreateWithFlags(&ev_lane[i], hipEventDisableTiming));
         lane[0] = st; nlane = 1;
-        if (const char* e = getenv("PCR_LANES")) if (atoi(e) == 1) return PCR_OK;               // developer knob: no concurrency
+        if (tune.lanes == 1) return PCR_OK;                                                      // pcr_tune("lanes", "1"): no concurrency
         bool dummy = false;
         RC(shares_queue(st, side[0], ticks / 30, ev_lane[0], &dummy));                          // warm up: first launches are slow
-        const int want = getenv("PCR_LANES") ? std::min(MAXLANE, std::max(1, atoi(getenv("PCR_LANES")))) : 4;
+        const int want = tune.lanes > 0 ? std::min(MAXLANE, tune.lanes) : 4;
         for (int c = 0; c < NSIDE && nlane < want; ++c) {
             bool clash = false;
             for (int l = 0; l < nlane && !clash; ++l) RC(shares_queue(lane[l], side[c], ticks, ev_lane[0], &clash));
             if (!clash) lane[nlane++] = side[c];
-            if (getenv("PCR_DEBUG_LANES")) fprintf(stderr, "[pcr] side stream %d %s\n", c, clash ? "shares a queue with a lane" : "is a lane");
+            if (tune.debug) fprintf(stderr, "[pcr] side stream %d %s\n", c, clash ? "shares a queue with a lane" : "is a lane");
         }
         return PCR_OK;
     }
@@ -346,6 +364,7 @@ struct Solver final : pcr_solver {
 
     int init(const pcr_dataset* ds, const pcr_params* p, int rank_, int nranks_) {
         prm = *p; rank = rank_; nranks = nranks_;
+        tune.read();
         if (prm.cg_max_iter == 0) prm.cg_max_iter = 10;      // zero-filled extension fields = the reference's constants
         if (prm.cg_tol == 0.0) prm.cg_tol = 0.01;
         if (prm.cg_max_iter < 0 || prm.cg_max_iter > 100000 || !(prm.cg_tol > 0.0)) { pcr_set_error("cg_max_iter / cg_tol out of range"); return PCR_ERR_ARG; }
@@ -415,7 +434,7 @@ struct Solver final : pcr_solver {
                 const int64_t fit = cdiv(std::max<int64_t>(nnz_local, 1), groups_at_once);
                 spmm_chunk = (int)std::min<int64_t>(128, std::max<int64_t>(64, (fit + 31) / 32 * 32));
             }
-            if (const char* e = getenv("PCR_SPMM_CHUNK")) spmm_chunk = std::max(8, atoi(e));
+            if (tune.spmm_chunk > 0) spmm_chunk = std::max(8, tune.spmm_chunk);
             const size_t row_bytes = (size_t)geo.ld * sizeof(T);
             int64_t tile_users_max = std::max<int64_t>(64, (int64_t)((5u << 18) / row_bytes));
             int64_t ntiles = std::max<int64_t>(cdiv(nu, tile_users_max), std::min<int64_t>(8, nu / 256));
@@ -424,7 +443,7 @@ struct Solver final : pcr_solver {
             // gather.  Keep at least 16 ratings per pair on average (ml1m 32, Netflix shape 37: unaffected).
             ntiles = std::min<int64_t>(ntiles, std::max<int64_t>(8, nnz_local / (16 * std::max<int64_t>(d2, 1))));
             if (ntiles > 1) ntiles = (ntiles + 7) / 8 * 8;             // every XCD the same number of tiles
-            if (const char* e = getenv("PCR_SPMM_TILES")) if (atoi(e) > 0) ntiles = atoi(e);      // developer knob
+            if (tune.spmm_tiles > 0) ntiles = tune.spmm_tiles;
             ntiles = std::max<int64_t>(1, std::min<int64_t>(ntiles, std::max<int64_t>(nu, 1)));
             tile_users_max = std::max<int64_t>(tile_users_max, 2 * (int64_t)cdiv(nu, ntiles));       // (the density bound may ask for larger tiles)
             std::vector<int64_t> tile_u(1, 0);                       // user boundaries: equal ratings, at most tile_users_max users
@@ -502,7 +521,7 @@ struct Solver final : pcr_solver {
             RC(d_slab.alloc((size_t)std::max<size_t>(inc_item.size(), 1) * geo.ld));
             spmm_tiles = (int)ntiles;
             sddmm_csc = (size_t)d2 * geo.ld * sizeof(T) > ((size_t)32 << 20) && spmm_tiles >= 8;     // item table larger than all L2s together
-            if (const char* e = getenv("PCR_SDDMM_CSC")) sddmm_csc = atoi(e) != 0;                    // developer / test knob
+            if (tune.sddmm_csc >= 0) sddmm_csc = tune.sddmm_csc != 0;
         }
         make_bins(uptr, nu, &lv.run_ofs, bins);
         for (auto& b : bins) RC(b.d_users.upload(b.users, st));
@@ -531,29 +550,29 @@ struct Solver final : pcr_solver {
                 if (best == 0.0 || cost < best) { best = cost; sweep_wave_cap = c; }
             }
         }
-        if (const char* e = getenv("PCR_SWEEP_WAVE_CAP")) sweep_wave_cap = std::max(64, atoi(e));     // developer knob
-        if (getenv("PCR_DEBUG_LANES")) fprintf(stderr, "[pcr] sweep wave cap %d\n", sweep_wave_cap);
+        if (tune.sweep_wave_cap > 0) sweep_wave_cap = std::max(64, tune.sweep_wave_cap);
+        if (tune.debug) fprintf(stderr, "[pcr] sweep wave cap %d\n", sweep_wave_cap);
         make_bins(uptr, nu, &lv.run_ofs, sbins, {std::min(sweep_wave_cap, 4095), 4096}, {64, 512, 512});
         for (auto& b : sbins) RC(b.d_users.upload(b.users, st));
-        const int prep_wave_cap = getenv("PCR_PREP_WAVE_CAP") ? std::max(64, std::min(4095, atoi(getenv("PCR_PREP_WAVE_CAP")))) : 256;     // developer knob
+        const int prep_wave_cap = 256;
         make_bins(uptr, nu, &lv.run_ofs, pbins, {prep_wave_cap, 4096}, {64, 512, 512});
         for (auto& b : pbins) RC(b.d_users.upload(b.users, st));
         // U step: users with more than 1024 ratings are bound by one CU's gather bandwidth -> clusters of 4 workgroups
         // The U step keeps each user's rows of V in LDS (k_ustep, stage_rows), so its occupancy is set by LDS bytes, not
         // registers: finer length classes than the V side, and a workgroup size that grows with the class.
-        // PCR_UBINS="cap:block,..." overrides the classes below 1024 (developer knob).
+        // pcr_tune("ubins", "cap:block:resident,...") overrides the classes below 1024.
         // Measured (ml1m shape, k = 100): residency pays for users of <= 32 ratings (13 KB of rows: 10 one-wave workgroups
         // per CU still fit); above that the LDS image costs more occupancy than the faster passes gain -- the 33..64 class
         // was resident until its non-resident form got leaner (108 VGPRs against 124): 1.622 -> 1.604 ms, 10 M-rating
         // Netflix-shaped slice 82.5 -> 80.9 ms over 4 iterations; 65..128 resident: 1.80 ms -- so those classes gather from
         // the L2s with 16 waves per CU.
         std::vector<int> ucap = {32, 64, 128, 512}, ublk = {64, 64, 64, 256}, ures = {1, 0, 0, 0};
-        if (const char* e = getenv("PCR_UBINS")) {                 // "cap:block:resident,..."
+        if (const char* e = tune.ubins.empty() ? nullptr : tune.ubins.c_str()) {                 // "cap:block:resident,..."
             ucap.clear(); ublk.clear(); ures.clear();
             for (const char* q = e; *q;) {
                 int c = 0, bl = 0, rs = 1, used = 0;
                 if (sscanf(q, "%d:%d:%d%n", &c, &bl, &rs, &used) != 3 || (bl != 64 && bl != 256) || c < 1 || c >= 1024 || (rs && bl != 64) ||
-                    (!ucap.empty() && c <= ucap.back())) { pcr_set_error("bad PCR_UBINS"); return PCR_ERR_ARG; }
+                    (!ucap.empty() && c <= ucap.back())) { pcr_set_error("bad pcr_tune ubins"); return PCR_ERR_ARG; }
                 ucap.push_back(c); ublk.push_back(bl); ures.push_back(rs);
                 q += used; if (*q == ',') ++q;
             }
@@ -566,8 +585,8 @@ struct Solver final : pcr_solver {
         // 124 VGPRs, and a class boundary at 2048 so that the per-rating arrays of two fit the LDS).  "Many" is more than
         // CUs/4 users: the greedy one-per-CU workgroups of all long classes together must leave CUs for the short classes
         // (ml1m: 88 + 221 users in throughput form 2.09 -> 2.03 ms per iteration; Netflix shape: U step 87 -> 69 ms).
-        const int force_mode = getenv("PCR_USTEP_MODE") ? atoi(getenv("PCR_USTEP_MODE")) : 0;   // developer / test knob: 1 latency, 2 throughput
-        const int64_t many_users = getenv("PCR_USTEP_MANY") ? atoll(getenv("PCR_USTEP_MANY")) : std::max<int64_t>(1, ncu / 4);   // developer knob
+        const int force_mode = tune.ustep_mode;                                                  // 1 latency, 2 throughput
+        const int64_t many_users = tune.ustep_many > 0 ? tune.ustep_many : std::max<int64_t>(1, ncu / 4);
         auto many = [&](int64_t users) { return force_mode ? force_mode == 2 : users > many_users; };
         int64_t n_mid = 0;
         for (int64_t u = 0; u < nu; ++u) { const int64_t len = uptr[u + 1] - uptr[u]; n_mid += len > 1024 && len <= 4096; }
@@ -577,9 +596,9 @@ struct Solver final : pcr_solver {
         make_bins(uptr, nu, &lv.run_ofs, ubins, ucap, ublk);
         // Workgroup clusters trade throughput for latency: only the longest users of the shard (the critical path, more than
         // 1024 ratings) get them, ncu/(4K) users (all their workgroups fit the chip at once, see below) -- ONE extra class
-        // whatever length class they came from (in global scratch if any of them needs it).  PCR_CLUSTER_K=1 disables.
+        // whatever length class they came from (in global scratch if any of them needs it).  pcr_tune("cluster_k", "1") disables.
         int cluster_k = 4;
-        if (const char* e = getenv("PCR_CLUSTER_K")) cluster_k = atoi(e) == 4 ? 4 : 1;
+        if (tune.cluster_k != 4) cluster_k = 1;
         max_clusters = std::max(1, ncu / 2);
         if (cluster_k > 1) {
             Bin head;
@@ -588,7 +607,7 @@ struct Solver final : pcr_solver {
             // whole launch, CUs the many short users cannot use meanwhile -- ml1m: 8 users 1.610 ms, 12-20: 1.59-1.61, 24: 1.63,
             // 32: 1.645, 48: 1.79 per iteration; 10 M-rating Netflix-shaped slice: U step 7.24 (32) -> 6.98 ms (16)
             size_t budget = (size_t)std::max(1, ncu / (4 * cluster_k));
-            if (const char* e = getenv("PCR_CLUSTER_USERS")) budget = (size_t)std::max(1, std::min(atoi(e), ncu / cluster_k));     // developer knob
+            if (tune.cluster_users > 0) budget = (size_t)std::max(1, std::min(tune.cluster_users, ncu / cluster_k));
             for (size_t q = ubins.size(); q-- > nsmall + 1 && budget > 0;) {       // longest class first; users are sorted longest first
                 Bin& b = ubins[q];
                 const size_t take = std::min(budget, b.users.size());
@@ -615,6 +634,13 @@ struct Solver final : pcr_solver {
             if (b.K > 1 || lds_bound || !many((int64_t)b.users.size())) { b.unr = 8; continue; }
             b.unr = 4;
             if (b.limit == 1024 && !b.big) b.block = 256;
+        }
+        // A class whose per-rating arrays + r-vectors do not fit the 160 KB of LDS (fp64 at wide ranks with users near 4096
+        // ratings, or thousands of rating levels under PrimalCR) runs the global-scratch form of the kernel instead.
+        for (auto& b : ubins) {
+            if (b.big || b.users.empty()) continue;
+            const size_t fixed = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + ustep_big_bytes<T>(b.cap, host_pow2(b.cap), b.max_lev + 2, 4);
+            if (fixed > (size_t)160 * 1024) { b.big = true; b.block = 512; }
         }
         u_big_blocks = 0;
         for (auto& b : ubins) {
@@ -661,7 +687,7 @@ struct Solver final : pcr_solver {
         sh.scpos = d_scpos.p; sh.objr = d_objr.p;
         // window cache (pcr_kernels.h, Shard::win): one slot per other level, up to 9 levels
         sh.ws = (lv.max_levels >= 2 && lv.max_levels <= 9) ? lv.max_levels - 1 : 0;
-        if (const char* e = getenv("PCR_NO_WINDOW_CACHE")) if (atoi(e)) sh.ws = 0;
+        if (!tune.window_cache) sh.ws = 0;
         RC(d_win.alloc((size_t)nnz_local * sh.ws));
         sh.win = d_win.p;
 
@@ -718,19 +744,20 @@ struct Solver final : pcr_solver {
         HIPCHK(hipHostMalloc((void**)&h_counters, (4 + 64) * sizeof(unsigned long long)));
 
         // ---- scratch for users that do not fit in LDS
+        // (every class that can run the BIG form is sized with ITS OWN longest user and level count: the cluster class mixes
+        // users of several length classes, and a mid-length user may hold more rating levels than any long one)
         size_t need = 0;
-        if (!bins[3].users.empty()) {
-            int cp = host_pow2(bins[3].cap), rsc = bins[3].max_lev + 2;
-            need = std::max(need, prepare_bytes<T>(cp, cp, rsc, 8));   // LI is 8 bytes in scratch
-            need = std::max(need, vsweep_bytes<T>(bins[3].cap, rsc, true));
-            need = std::max(need, ustep_big_bytes<T>(cp, cp, rsc, 8));
-        }
+        size_t nbig = 0;
+        for (const Bin* b : {&bins[3], &pbins[2]})
+            if (!b->users.empty()) { need = std::max(need, prepare_bytes<T>(b->cap, host_pow2(b->cap), b->max_lev + 2, 8)); nbig = std::max(nbig, b->users.size()); }
+        for (const Bin* b : {&bins[3], &sbins[2]})
+            if (!b->users.empty()) { need = std::max(need, vsweep_bytes<T>(b->cap, b->max_lev + 2, true)); nbig = std::max(nbig, b->users.size()); }
+        for (auto& b : ubins)
+            if (b.big && !b.users.empty()) need = std::max(need, ustep_big_bytes<T>(b.cap, host_pow2(b.cap), b.max_lev + 2, 8));
         for (int w = 0; w < 2; ++w)
-            if (!ev[w].bins[3].users.empty()) need = std::max(need, eval_bytes<T>(ev[w].bins[3].cap));
+            if (!ev[w].bins[3].users.empty()) { need = std::max(need, eval_bytes<T>(ev[w].bins[3].cap)); nbig = std::max(nbig, ev[w].bins[3].users.size()); }
         if (need) {
             scratch_stride = (need + 255) & ~(size_t)255;
-            size_t nbig = bins[3].users.size();
-            for (int w = 0; w < 2; ++w) nbig = std::max(nbig, ev[w].bins[3].users.size());
             scratch_blocks = std::max((int)std::min<size_t>(std::max<size_t>(nbig, 1), (size_t)ncu * 2), u_big_blocks);
             RC(d_scratch.alloc(scratch_stride * (size_t)scratch_blocks));
         }
@@ -781,8 +808,7 @@ struct Solver final : pcr_solver {
             const int l = nlane > 1 ? 1 + next++ % (nlane - 1) : 0;      // side lanes in turn; classes sharing a lane run back to back
             // cross-stream waits on events that are still pending are slow here (see update_V): drain the solver's
             // stream on the host before the fork, and join on the host too (join())
-            static const int fork_sync = getenv("PCR_FORK_SYNC") ? atoi(getenv("PCR_FORK_SYNC")) : 1;     // developer knob
-            if (l > 0 && !forked) { if (fork_sync) HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipEventRecord(ev_fork, st)); forked = true; }
+            if (l > 0 && !forked) { HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipEventRecord(ev_fork, st)); forked = true; }
             if (l > 0 && !used[l]) HIPCHK(hipStreamWaitEvent(lane[l], ev_fork, 0));
             used[l] = true;
             ProfScope ps(this, pname(cls, bs[i]), lane[l], bs[i].nnz, (int64_t)bs[i].users.size());
@@ -796,8 +822,7 @@ struct Solver final : pcr_solver {
     }
     // the solver's stream continues after `ev`
     int join(hipEvent_t ev) {
-        static const int host_join = getenv("PCR_HOST_JOIN") ? atoi(getenv("PCR_HOST_JOIN")) : 1;      // developer knob
-        if (host_join && !device_join) HIPCHK(hipEventSynchronize(ev)); else HIPCHK(hipStreamWaitEvent(st, ev, 0));
+        if (!device_join) HIPCHK(hipEventSynchronize(ev)); else HIPCHK(hipStreamWaitEvent(st, ev, 0));
         return PCR_OK;
     }
     // U step: the hardware runs only a few queues side by side (streams beyond that share a queue and serialise), so the
@@ -814,20 +839,9 @@ struct Solver final : pcr_solver {
         std::stable_sort(order.begin() + nhead, order.end(), [](const Bin* a, const Bin* b) { return a->cap > b->cap; });
         // plan: (class, stream) in launch order.  Streams: 0..MAXLANE-1 = lane[], MAXLANE = hi.
         std::vector<std::pair<int, int>> plan;
-        static const char* sched = getenv("PCR_USTEP_SCHED");        // developer knob: "class:stream,..." (stream: 0-3 lane, h)
-        if (sched && *sched) {
-            for (const char* q = sched; *q;) {
-                int c = 0, used = 0; char ch = 0;
-                if (sscanf(q, "%d:%c%n", &c, &ch, &used) != 2) break;
-                const int sidx = ch == 'h' ? MAXLANE : std::min(nlane - 1, std::max(0, ch - '0'));
-                if (c >= 0 && c < (int)order.size()) plan.push_back({c, sidx});
-                q += used; if (*q == ',') ++q;
-            }
-        }
         // (A longest-processing-time-first plan from class durations measured in the first U steps was tried: 2.10 ms
         // against 2.01 ms per iteration for this one -- durations measured side by side mislead it.)
-        if (plan.size() != order.size()) {                            // default (also when the knob does not name every class)
-            plan.clear();
+        {
             for (size_t i = 0; i < nhead; ++i) plan.push_back({(int)i, MAXLANE});
             // round-robin over the lanes, longest class first -- with the first two lanes swapped: the solver's stream takes
             // the SECOND class (on the headline shape the many-user 256-thread class that finishes last, and the shortest
@@ -840,8 +854,7 @@ struct Solver final : pcr_solver {
         }
         // nothing in flight on the solver's stream (the usual case: the V step has just read its objective back): the lanes
         // need no fork event, their kernels start as soon as they are launched
-        static const int idle_knob = getenv("PCR_IDLE_FORK") ? atoi(getenv("PCR_IDLE_FORK")) : 1;     // developer knob
-        const bool idle = idle_knob && hipStreamQuery(st) == hipSuccess;
+        const bool idle = hipStreamQuery(st) == hipSuccess;
         ProfScope wall(this, "wall:ustep", st);
         bool used[MAXLANE + 1] = {};
         if (!idle) HIPCHK(hipEventRecord(ev_fork, st));
@@ -897,7 +910,7 @@ struct Solver final : pcr_solver {
                 const int64_t fit = cdiv(nnz_local, (int64_t)ncu * per_cu * ngrp0);
                 if (fit > 64 && fit <= 128) sddmm_tile = (int)((fit + 7) / 8 * 8);
             }
-            if (const char* e = getenv("PCR_SDDMM_TILE")) sddmm_tile = std::max(8, atoi(e) / 8 * 8);      // developer knob
+            if (tune.sddmm_tile > 0) sddmm_tile = std::max(8, tune.sddmm_tile / 8 * 8);
         }
         const int tile = sddmm_tile;
         const int ngrp = 256 / geo.G, span = ngrp * tile;
@@ -921,8 +934,7 @@ struct Solver final : pcr_solver {
     }
 
     bool prepare_is_single_launch() const {
-        static const int merged = getenv("PCR_PREPARE_MERGED") ? atoi(getenv("PCR_PREPARE_MERGED")) : 1;     // developer knob
-        return merged && !pbins[0].users.empty() && !pbins[1].users.empty();
+        return tune.prepare_merged && !pbins[0].users.empty() && !pbins[1].users.empty();
     }
     int launch_prepare(const T* Vm) {
         RC(launch_sddmm(Vm, d_item.p, d_mcsr.p));
@@ -1075,7 +1087,7 @@ struct Solver final : pcr_solver {
     // loss (all ranks) of the last prepare + lambda/2 (|U|^2 + |Vm|^2)   (pcrpp.cpp:410)
     // d_scal[0] = sum objx (all ranks), [1] = |Vm|^2, [2] = |U|^2 (all ranks; only if with_u): one pass + one finish
     // objx2 (optional): a second per-user sum -> [3].  after_ustep: the finishing kernel also moves the U step's counters to
-    // d_scal[12..14] and resets the counter block (k_fin4).
+    // d_scal[slot + 4 .. slot + 7) and resets the counter block (k_fin4).
     int objective_sums(const double* objx, const T* Vm, bool with_u, int slot = 0, const double* objx2 = nullptr, bool after_ustep = false) {
         const int64_t nV = (int64_t)d2 * geo.ld, nU = (int64_t)n_users * geo.ld;
         const int nb = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv(std::max(nV, nU), 4096)));
@@ -1084,10 +1096,12 @@ struct Solver final : pcr_solver {
         // contributed by rank 0 alone
         const bool reduce = !((nranks == 1 && !comm) || local_only);
         const int keep1 = (!reduce || rank == 0) ? 1 : 0;
-        if (after_ustep) hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + slot, d_counters.p, d_scal.p + 12, counter_words(), keep1);
+        if (after_ustep) hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + slot, d_counters.p, d_scal.p + slot + 4, counter_words(), keep1);
         else hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + slot, (unsigned long long*)nullptr, (double*)nullptr, 0, keep1);
         HIPCHK(hipGetLastError());
-        RC(allreduce_f64(d_scal.p + slot, 4));
+        // (after a U step the shard's CG / line-search counts and its cluster time-out flag ride on the same all-reduce:
+        // every rank then sees the job's totals and the same error, and all of them leave the loop together)
+        RC(allreduce_f64(d_scal.p + slot, after_ustep ? 8 : 4));
         return PCR_OK;
     }
     int full_objective(const T* Vm, double* obj) {
@@ -1191,12 +1205,18 @@ struct Solver final : pcr_solver {
         // one GPU: Hp is final when k_spmm_fin stores it, so that kernel also produces the p.Hp / rr.p partials;
         // with an all-reduce in between they need their own pass (k_cg_a)
         const bool fused_dots = (nranks == 1 && !comm) || local_only;
+        const bool exact_rr = prm.cg_tol < 1e-5;                   // the residual recurrence of k_cg_bc cancels below that
         for (int k = 1; k <= prm.cg_max_iter; ++k) {
             RC(device_hv(d_p.p, d_Hp.p, skip, fused_dots ? d_rr.p : nullptr));
             {
                 ProfScope ps(this, "cg");
                 if (!fused_dots) hipLaunchKernelGGL((k_cg_a<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, n, ew_per_block, d_partA.p, d_cgp);
-                hipLaunchKernelGGL((k_cg_bc<T>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, d_delta.p, n, ew_per_block, fused_dots ? fin_blocks() : ew_blocks, d_partA.p, d_cgp, k);
+                if (exact_rr) {
+                    hipLaunchKernelGGL((k_cg_bc<T, true>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, d_delta.p, n, ew_per_block, fused_dots ? fin_blocks() : ew_blocks, d_partA.p, d_cgp, k, d_partB.p);
+                    hipLaunchKernelGGL(k_cg_stop, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partB.p, ew_blocks, d_cgp, k);
+                } else {
+                    hipLaunchKernelGGL((k_cg_bc<T, false>), dim3(ew_blocks), dim3(PCR_EW_BLOCK), 0, st, d_p.p, d_Hp.p, d_rr.p, d_delta.p, n, ew_per_block, fused_dots ? fin_blocks() : ew_blocks, d_partA.p, d_cgp, k, (double*)nullptr);
+                }
             }
             HIPCHK(hipGetLastError());
         }
@@ -1232,8 +1252,7 @@ struct Solver final : pcr_solver {
         // up to the objective read-back is stream-ordered.  (With the per-class launches the host waits for the CG first: a
         // fork whose event is still pending when the lanes reach it costs far more here than the round trip -- measured
         // 2.19 -> 2.40 ms per iteration.)
-        static const int cg_sync_knob = getenv("PCR_CG_SYNC") ? atoi(getenv("PCR_CG_SYNC")) : -1;           // developer knob
-        const bool cg_sync = cg_sync_knob >= 0 ? cg_sync_knob != 0 : !prepare_is_single_launch();
+        const bool cg_sync = !prepare_is_single_launch();
         RC(device_cg(cg_sync ? &cg_iters : nullptr));
         double step = prm.stepsize, obj = prev_obj;
         const int64_t n = (int64_t)d2 * geo.ld;
@@ -1287,7 +1306,7 @@ struct Solver final : pcr_solver {
             // clusters: grid <= one workgroup per CU so that every member of every cluster is resident
             const int grid = b.ugrid;
             char* scr = d_scratch.p + (size_t)b.scratch_ofs * scratch_stride;
-#define LU(BL, BG, KK, RS, UN) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb)
+#define LU(BL, BG, KK, RS, UN) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb, tune.fault_cluster_member)
             if (b.big) { if (b.K == 4) LU(512, true, 4, true, 8); else if (b.unr == 8) LU(512, true, 1, true, 8); else LU(512, true, 1, false, 4); }
             else if (b.block == 64) { if (b.rcap > 0) LU(64, false, 1, true, 4); else LU(64, false, 1, false, 4); }
             else if (b.block == 256) LU(256, false, 1, false, 4);
@@ -1296,8 +1315,7 @@ struct Solver final : pcr_solver {
             else LU(512, false, 1, false, 4);
 #undef LU
         };
-        static const int seq = getenv("PCR_USTEP_SEQ") ? atoi(getenv("PCR_USTEP_SEQ")) : 0;     // developer knob
-        if (seq) RC(for_bins_seq(ubins, "ustep", fn)); else RC(for_ubins(fn));
+        if (tune.ustep_seq) RC(for_bins_seq(ubins, "ustep", fn)); else RC(for_ubins(fn));
         return PCR_OK;
     }
 
@@ -1348,8 +1366,9 @@ struct Solver final : pcr_solver {
         }
 #endif
         if (now_obj) *now_obj = (uobj_merged ? h_uobj[7] : h_uobj[0]) + prm.lambda / 2.0 * (uobj_merged ? h_uobj[5] : h_uobj[1]);      // :835
-        if (h_uobj[14] != 0.0) { pcr_set_error("k_ustep: a workgroup cluster timed out at a hand-off (members not co-resident?)"); return PCR_ERR_DEVICE; }
-        if (info) { info[0] = (int64_t)h_uobj[12]; info[1] = (int64_t)h_uobj[13]; }
+        const int cb = uobj_merged ? 8 : 4;                         // counters follow the four sums (objective_sums)
+        if (h_uobj[cb + 2] != 0.0) { pcr_set_error("k_ustep: a workgroup cluster timed out at a hand-off (members not co-resident?)"); return PCR_ERR_DEVICE; }
+        if (info) { info[0] = (int64_t)h_uobj[cb]; info[1] = (int64_t)h_uobj[cb + 1]; }
         return PCR_OK;
     }
 
@@ -1377,7 +1396,7 @@ struct Solver final : pcr_solver {
         }
         // dcg uses gain/discount products in the reference's order: gain / log2(k+1); keep the division exact
         {
-            const bool fast_eval = es.max_raw_levels <= 64 && !(getenv("PCR_EVAL_BRUTE") && atoi(getenv("PCR_EVAL_BRUTE")));
+            const bool fast_eval = es.max_raw_levels <= 64 && !tune.eval_brute;
             const int64_t* up = which == 0 ? d_uptr.p : es.uptr.p;
             const int32_t* it = which == 0 ? d_item.p : es.item.p;
             auto fn = [&](Bin& b, hipStream_t q) {
@@ -1482,7 +1501,7 @@ struct Solver final : pcr_solver {
         std::vector<pcr_iter_stats> rec(n + 1);
         for (auto& r : rec) memset(&r, 0, sizeof r);
         int rc = PCR_OK;
-        device_join = getenv("PCR_PIPELINE") ? atoi(getenv("PCR_PIPELINE")) != 0 : true;
+        device_join = tune.pipeline != 0;
         HIPCHK(hipEventRecord(ev0, st));
         auto close = [&](int k) -> int {                         // iteration k's U step has been finished (fin_*)
             float ms = 0.f;
@@ -1493,7 +1512,7 @@ struct Solver final : pcr_solver {
             on_done(k, rec[k]);
             return PCR_OK;
         };
-        static const int pipe = getenv("PCR_PIPELINE") ? atoi(getenv("PCR_PIPELINE")) : 1;       // developer knob
+        const int pipe = tune.pipeline;
         for (int k = 1; k <= n && rc == PCR_OK; ++k) {
             int vinfo[3] = {0, 0, 0};
             double vobj = 0.0;

@@ -168,6 +168,87 @@ def generate(shape: str = "ml1m", seed: int = SEED, *, d1=None, d2=None, nnz=Non
                    user[is_test], item[is_test], np.ascontiguousarray(val[is_test]))
 
 
+# ---------------------------------------------------------------------------------------
+# C++ generator (primalcr_amd/csrc/pcr_synth.cpp -> lib/libpcrsynth.so): the same recipe with one counter-based random
+# stream per user -- any user range on its own, multi-threaded, 100 M ratings in seconds.  The large shapes (netflix,
+# yahoo) use it; the numpy generator above stays the definition of the ml1m / toy / small sets (BASELINE configs[0..2]).
+# ---------------------------------------------------------------------------------------
+class _SynthParams(__import__("ctypes").Structure):
+    import ctypes as _C
+    _fields_ = [("d1", _C.c_int64), ("d2", _C.c_int64), ("nnz", _C.c_int64), ("mu", _C.c_double), ("sigma", _C.c_double),
+                ("real_valued", _C.c_int32), ("n_test", _C.c_int32), ("min_count", _C.c_int32), ("reserved", _C.c_int32),
+                ("seed", _C.c_uint64)]
+
+
+@dataclass
+class CsrRatings:
+    """A user range [u0, u1) of a shape, as CSRs (users renumbered from 0; items ascending inside a user)."""
+    d1: int
+    d2: int
+    index: np.ndarray    # int64[d1 + 1]
+    item: np.ndarray     # int32
+    val: np.ndarray      # float64
+    tindex: np.ndarray
+    titem: np.ndarray
+    tval: np.ndarray
+    u0: int = 0
+    shape_d1: int = 0    # users of the whole shape
+
+    @property
+    def nnz(self) -> int:
+        return int(self.index[-1])
+
+    @property
+    def user(self):
+        return np.repeat(np.arange(self.d1, dtype=np.int32), np.diff(self.index))
+
+    @property
+    def tuser(self):
+        return np.repeat(np.arange(self.d1, dtype=np.int32), np.diff(self.tindex))
+
+
+_synth_lib = None
+
+
+def _slib():
+    global _synth_lib
+    if _synth_lib is None:
+        import ctypes as C
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpcrsynth.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with make -C primalcr_amd/csrc")
+        L = C.CDLL(path)
+        L.pcr_synth_counts.argtypes = [C.POINTER(_SynthParams), C.c_void_p, C.c_void_p]
+        L.pcr_synth_fill.argtypes = [C.POINTER(_SynthParams), C.c_int64, C.c_int64] + [C.c_void_p] * 6 + [C.c_int]
+        _synth_lib = L
+    return _synth_lib
+
+
+def generate_fast(shape: str = "netflix", seed: int = SEED, *, d1=None, d2=None, nnz=None, mu=None, sigma=None,
+                  real_valued=None, n_test=None, min_count=None, users=None, threads=0) -> CsrRatings:
+    """The shape (or overrides) from the C++ generator; users=(u0, u1) generates only that user range of it."""
+    s = SHAPES[shape]
+    d1 = s[0] if d1 is None else d1
+    d2 = s[1] if d2 is None else d2
+    nnz = s[2] if nnz is None else nnz
+    P = _SynthParams(d1, d2, nnz, s[3] if mu is None else mu, s[4] if sigma is None else sigma,
+                     int(s[5] if real_valued is None else real_valued), s[6] if n_test is None else n_test,
+                     ((10 if d2 >= 64 else 2) if min_count is None else min_count), 0, seed)
+    L = _slib()
+    ctr, cte = np.empty(d1, np.int64), np.empty(d1, np.int64)
+    if L.pcr_synth_counts(P, ctr.ctypes.data, cte.ctypes.data) != 0:
+        raise RuntimeError("pcr_synth_counts failed")
+    u0, u1 = (0, d1) if users is None else users
+    index = np.concatenate([[0], np.cumsum(ctr[u0:u1])]).astype(np.int64)
+    tindex = np.concatenate([[0], np.cumsum(cte[u0:u1])]).astype(np.int64)
+    item, val = np.empty(int(index[-1]), np.int32), np.empty(int(index[-1]), np.float64)
+    titem, tval = np.empty(int(tindex[-1]), np.int32), np.empty(int(tindex[-1]), np.float64)
+    if L.pcr_synth_fill(P, u0, u1, ctr.ctypes.data, cte.ctypes.data, item.ctypes.data, val.ctypes.data, titem.ctypes.data,
+                        tval.ctypes.data, threads) != 0:
+        raise RuntimeError("pcr_synth_fill failed")
+    return CsrRatings(u1 - u0, d2, index, item, val, tindex, titem, tval, u0, d1)
+
+
 def _write_ratings(path, user, item, val, real_valued):
     with open(path, "w") as f:
         B = 1 << 20

@@ -257,19 +257,20 @@ def _mixed_set(seed=11, d1=700, d2=6000):
 
 VARIANTS = [
     {},                                                          # default launch configuration
-    {"PCR_USTEP_MODE": "2"},                                     # throughput variants: 256 threads / 512 threads at 4 rows in flight
-    {"PCR_USTEP_MODE": "1"},                                     # latency variants everywhere
-    {"PCR_CLUSTER_K": "1"},                                      # no workgroup clusters
-    {"PCR_UBINS": "64:64:0,512:256:0"},                          # no LDS-resident rows, coarser classes
-    {"PCR_UBINS": "16:64:1,48:64:1,200:256:0,700:256:0"},        # other class bounds
-    {"PCR_SPMM_TILES": "5"}, {"PCR_SPMM_TILES": "16"}, {"PCR_SPMM_TILES": "64"},   # user tiles of the SpMM (incl. more tiles than XCDs)
-    {"PCR_SPMM_CHUNK": "32"}, {"PCR_SPMM_CHUNK": "128"},         # ratings per SpMM lane group (the default adapts to the shard: 64 here)
-    {"PCR_LANES": "1"},                                          # every class on the solver's stream
-    {"PCR_SDDMM_CSC": "1"}, {"PCR_SDDMM_CSC": "1", "PCR_SPMM_TILES": "16"},   # the CG's SDDMM over the tile-major CSC (wide item tables)
+    {"ustep_mode": "2"},                                     # throughput variants: 256 threads / 512 threads at 4 rows in flight
+    {"ustep_mode": "1"},                                     # latency variants everywhere
+    {"cluster_k": "1"},                                      # no workgroup clusters
+    {"ubins": "64:64:0,512:256:0"},                          # no LDS-resident rows, coarser classes
+    {"ubins": "16:64:1,48:64:1,200:256:0,700:256:0"},        # other class bounds
+    {"spmm_tiles": "5"}, {"spmm_tiles": "16"}, {"spmm_tiles": "64"},   # user tiles of the SpMM (incl. more tiles than XCDs)
+    {"spmm_chunk": "32"}, {"spmm_chunk": "128"},         # ratings per SpMM lane group (the default adapts to the shard: 64 here)
+    {"lanes": "1"},                                          # every class on the solver's stream
+    {"window_cache": "0"}, {"prepare_merged": "0"}, {"ustep_seq": "1"}, {"pipeline": "0"},   # searching sweeps, per-class prepare, serial classes
+    {"sddmm_csc": "1"}, {"sddmm_csc": "1", "spmm_tiles": "16"},   # the CG's SDDMM over the tile-major CSC (wide item tables)
 ]
 
 
-def test_launch_variants_agree(oracle, monkeypatch):
+def test_launch_variants_agree(oracle):
     """The length classes, workgroup variants, cluster size, SpMM tiling and stream placement are scheduling choices:
     two outer iterations in fp64 must give the same factors and objectives under every one of them (to summation-order
     rounding), and the first U step must match the oracle."""
@@ -280,9 +281,7 @@ def test_launch_variants_agree(oracle, monkeypatch):
     ds = pcr.Dataset.from_triplets(d1, d2, user, item, val)
     results = []
     for env in VARIANTS:
-        with monkeypatch.context() as mp:
-            for k, v in env.items():
-                mp.setenv(k, v)
+        with pcr.tuned(**env):                                   # pcr_tune(): read when the solver is created
             s = pcr.Solver(ds, pcr.Parameter(k=r, precision=pcr.PCR_F64, **{"lambda": lam}))
         s.set_factors(U0, V0)
         objs = []
@@ -580,3 +579,98 @@ def test_users_beyond_65535_ratings(oracle):
     e, n = s.evaluate(0)
     eo, no = oracle.eval(Ug, Vg, X)
     assert abs(e - eo) < 1e-12 and abs(n - no) < 1e-12
+
+
+def _one_outer_iteration_vs_oracle(oracle, d1, d2, user, item, val, r, lam, solver, precision=pcr.PCR_F64, scale=0.2, **par):
+    X = oracle.build_csr(d1, d2, user, item, val)
+    U0 = oracle.initial(d1, r) * scale; V0 = oracle.initial(d2, r) * scale
+    U1, V1, ro = oracle.train(X, U0, V0, lam, 1, solver=solver, do_predict=0)
+    ds = pcr.Dataset.from_triplets(d1, d2, user, item, val)
+    s = pcr.Solver(ds, pcr.Parameter(k=r, precision=precision, solver_type=solver, maxiter=1, do_predict=0, **{"lambda": lam}, **par))
+    s.set_factors(U0, V0)
+    recs, _ = s.train()
+    Ug, Vg = s.get_factors()
+    t = TOL[precision]
+    assert len(recs) == len(ro) == 2
+    for a, b in zip(recs, ro):
+        assert abs(a["obj"] / b["obj"] - 1) < max(t["obj"], t["fac"] * 1e-2), (a["obj"], b["obj"])
+    assert rel(Vg, V1) < t["fac"] and rel(Ug, U1) < t["fac"]
+    if precision == pcr.PCR_F64:
+        a, b = recs[1], ro[1]
+        assert (a["cg_v"], a["ls_v"], a["cg_u"], a["ls_u"]) == (b["cg_v"], b["ls_v"], b["cg_u"], b["ls_u"])
+    return s
+
+
+def test_cluster_class_mixes_level_counts(oracle):
+    """The cluster class of the U step takes the longest users of SEVERAL length classes and runs them in the global-scratch
+    form as soon as one of them needs it; its scratch slice must then be sized for the member with the MOST rating levels,
+    not for the levels of the users beyond 4096 ratings (round-1 advice): one 5000-rating user with 5 levels next to
+    3000- and 2040-rating users whose real-valued ratings are all distinct (PrimalCR: one level per rating), caps close
+    to a power of two so that no padding hides an overrun.  One outer iteration against the oracle, counts included."""
+    rng = np.random.default_rng(31)
+    d2, r, lam = 8200, 6, 20.0
+    lens = np.array([5000, 4090, 3000, 2040, 1030, 500, 100, 40, 7])
+    d1 = len(lens)
+    user = np.repeat(np.arange(d1), lens)
+    item = np.concatenate([np.sort(rng.choice(d2, n, replace=False)) for n in lens])
+    val = rng.normal(size=user.shape[0]) * 2.0                                 # all distinct: len levels under solver 1
+    val[:5000] = rng.integers(1, 6, 5000)                                       # ... except the longest user: 5 levels
+    _one_outer_iteration_vs_oracle(oracle, d1, d2, user, item, val, r, lam, solver=1)
+    _one_outer_iteration_vs_oracle(oracle, d1, d2, user, item, val, r, lam, solver=2)
+
+
+@pytest.mark.parametrize("r", [200, 257])
+def test_fp64_wide_ranks_with_users_near_4096_ratings(oracle, r):
+    """fp64 at configs[4]'s rank and beyond with users of 2049..4096 ratings: the LDS-resident form of k_ustep would need
+    more than the CU's 160 KB (22 B per rating + 136 B per rank column), so those classes must fall back to the
+    global-scratch form instead of failing the launch (round-1 advice)."""
+    rng = np.random.default_rng(r)
+    d2, lam = 4300, 50.0
+    lens = np.array([4096, 3974, 3000, 2049, 1500, 600, 130, 20])
+    d1 = len(lens)
+    user = np.repeat(np.arange(d1), lens)
+    item = np.concatenate([np.sort(rng.choice(d2, n, replace=False)) for n in lens])
+    val = rng.integers(1, 6, user.shape[0]).astype(np.float64)
+    _one_outer_iteration_vs_oracle(oracle, d1, d2, user, item, val, r, lam, solver=2, scale=0.05)
+
+
+def test_cluster_time_out_is_an_error_not_a_hang():
+    """A workgroup cluster that loses a member must end in PCR_ERR_DEVICE through the bounded wait of its hand-off, not in
+    a hung GPU.  pcr_tune("fault_cluster_member") makes the last member of every cluster leave at once."""
+    R = synth.generate("small", seed=4, d1=40, d2=6000, nnz=60000, mu=7.0, sigma=0.6)       # users of ~1000-3000 ratings
+    assert (np.bincount(R.user) > 1024).sum() >= 4
+    ds = pcr.Dataset.from_ratings(R)
+    with pcr.tuned(fault_cluster_member=1):
+        s = pcr.Solver(ds, pcr.Parameter(k=8, precision=pcr.PCR_F32))
+    s.set_factors(pcr.initial(R.d1, 8), pcr.initial(R.d2, 8))
+    s.update_V()
+    with pytest.raises(pcr.PcrError, match="timed out"):
+        s.update_U()
+    s.close()
+    s = pcr.Solver(ds, pcr.Parameter(k=8, precision=pcr.PCR_F32))                # and the device is fine afterwards
+    s.set_factors(pcr.initial(R.d1, 8), pcr.initial(R.d2, 8))
+    s.update_V(); s.update_U()
+
+
+def test_tight_cg_tolerance_uses_the_summed_residual(oracle):
+    """cg_tol far below 1e-5: the V side's one-pass CG update derives |rr|^2 from a recurrence that cancels once the
+    residual has dropped by ten orders of magnitude; below 1e-5 the stop test is taken on the directly summed residual
+    (k_cg_stop).  Same iteration count as the oracle, whose residual is always summed (pcrpp.cpp:349-350)."""
+    R = synth.generate("small", seed=9, d1=150, d2=90, nnz=5000, mu=3.2, sigma=0.9)
+    r, lam = 6, 3.0
+    X = oracle.build_csr(R.d1, R.d2, R.user, R.item, R.val)
+    U = oracle.initial(R.d1, r) * 0.4; V = oracle.initial(R.d2, r) * 0.4
+    ds = pcr.Dataset.from_triplets(R.d1, R.d2, R.user, R.item, R.val)
+    try:
+        oracle.set_cg(400, 1e-9)
+        s = pcr.Solver(ds, pcr.Parameter(k=r, precision=pcr.PCR_F64, cg_max_iter=400, cg_tol=1e-9, **{"lambda": lam}))
+        s.set_factors(U, V)
+        mo = oracle.comp_m(U, V, X)
+        s.comp_m()
+        g = s.obtain_g()
+        delta, its = s.solve_delta(g)
+        do, its_o = oracle.solve_delta_new(oracle.obtain_g_new(U, V, X, mo, lam), mo, U, X, lam)
+        assert abs(its - its_o) <= 1 and its < 400 and rel(delta, do) < 1e-7
+        assert rel(s.compute_Ha(delta), g) < 1e-8                                  # H delta = g to the tolerance asked for
+    finally:
+        oracle.set_cg()

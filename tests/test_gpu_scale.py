@@ -1,0 +1,131 @@
+"""BASELINE configs[3] and configs[4] as -m gpu tests on ONE MI355X (the 8-GPU execution itself is the driver's):
+
+* the 8-rank user sharding of a Netflix-shaped slice, every shard a solver of its own on the one GPU in shard-local mode:
+  partials add up to the 1-rank result and every shard's U rows equal the 1-rank rows (SURVEY 8e determinism row:
+  1e-12 in fp64);
+* the full Netflix-shaped set (480 189 x 17 770, 100 M ratings, k = 100) on one GPU through size-independent properties:
+  obj(U = V = 0) == #Omega exactly, strictly decreasing objective, fp32-storage vs fp64 NDCG@10 / pairwise error within
+  1e-3 (the north star's tolerance), identical V-side CG / line-search counts;
+* one GPU's share of the Yahoo!Music-shaped set (rank 0 of 8: 225 000 of 1.8 M users x 136 000 items, ~87.5 M ratings,
+  k = 200) with the same checks.
+
+The data come from the C++ generator (primalcr_amd/csrc/pcr_synth.cpp): seconds, not minutes.
+"""
+import time
+
+import numpy as np
+import pytest
+
+import primalcr_amd as pcr
+from primalcr_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)) if a.size else 0.0
+
+
+def test_eight_rank_sharding_of_a_netflix_shaped_slice():
+    """48 000 users / 10 M ratings of the Netflix shape cut into the 8 nnz-balanced shards pcr_partition_users gives 8
+    GPUs.  Every shard must hold every launch class (one-wave, 256- and 512-thread, cluster, global scratch) -- asserted
+    -- and, in shard-local mode, the 8 partials of m, objective, g, Ha must add up to the 1-rank result while each
+    shard's U step reproduces its rows of the 1-rank U step."""
+    R = synth.generate_fast("netflix", d1=48000, nnz=10_000_000)
+    r, lam, nranks = 16, 5000.0, 8
+    ds = pcr.Dataset.from_ratings(R)
+    lens = np.diff(R.index)
+    bounds = pcr.partition_users(R.index, nranks)
+    for q in range(nranks):
+        ql = lens[bounds[q]:bounds[q + 1]]
+        nnz_q = int(ql.sum())
+        assert abs(nnz_q / (R.nnz / nranks) - 1) < 0.02                       # nnz-balanced
+        for lo, hi in ((0, 32), (33, 128), (129, 512), (513, 1024), (1025, 4096), (4097, 1 << 30)):
+            assert ((ql >= lo) & (ql <= hi)).any(), (q, lo, hi)
+    U0, V0 = pcr.initial(R.d1, r), pcr.initial(R.d2, r)
+    par = dict(k=r, precision=pcr.PCR_F64, **{"lambda": lam})
+    full = pcr.Solver(ds, pcr.Parameter(**par))
+    full.set_factors(U0, V0)
+    m_full = full.comp_m(); obj_full = full.objective(); g_full = full.obtain_g()
+    a = np.random.default_rng(1).normal(size=V0.shape)
+    Ha_full = full.compute_Ha(a)
+    objU_full, info_full = full.update_U()
+    U_full, _ = full.get_factors()
+    full.close()
+    m_parts, g_sum, Ha_sum, obj_sum, cg_sum, ls_sum = [], 0.0, 0.0, 0.0, 0, 0
+    U_sh = np.zeros_like(U0)
+    for q in range(nranks):
+        s = pcr.Solver(ds, pcr.Parameter(**par), rank=q, nranks=nranks)
+        assert (s.first_user, s.n_users) == (bounds[q], bounds[q + 1] - bounds[q])
+        s.set_local_only(True)
+        s.set_factors(U0, V0)
+        m_parts.append(s.comp_m())
+        obj_sum += s.objective()
+        g_sum = g_sum + s.obtain_g()
+        Ha_sum = Ha_sum + s.compute_Ha(a)
+        _, info = s.update_U()
+        cg_sum += info["cg"]; ls_sum += info["ls"]
+        Uq, _ = s.get_factors()
+        U_sh[s.first_user:s.first_user + s.n_users] = Uq[s.first_user:s.first_user + s.n_users]
+        s.close()
+    assert np.array_equal(np.concatenate(m_parts), m_full)
+    obj_sum -= (nranks - 1) * lam / 2.0 * float((V0 ** 2).sum())              # every shard adds lambda/2 |V|^2 locally
+    assert abs(obj_sum / obj_full - 1) < 1e-12
+    assert rel(g_sum, g_full) < 1e-12 and rel(Ha_sum, Ha_full) < 1e-12
+    assert rel(U_sh, U_full) < 1e-12
+    assert (cg_sum, ls_sum) == (info_full["cg"], info_full["ls"])
+
+
+def _property_run(R, r, lam, iters=2):
+    """obj(0) == #Omega; `iters` outer iterations in fp32 storage and in fp64: decreasing objectives, equal V-side counts,
+    quality within the north star's 1e-3."""
+    ds = pcr.Dataset.from_ratings(R)
+    n_pairs = ds.count_pairs()
+    out = {}
+    for prec in (pcr.PCR_F32, pcr.PCR_F64):
+        t0 = time.time()
+        s = pcr.Solver(ds, pcr.Parameter(k=r, precision=prec, do_predict=0, **{"lambda": lam}))
+        t_create = time.time() - t0
+        if prec == pcr.PCR_F32:
+            s.set_factors(np.zeros((R.d1, r)), np.zeros((R.d2, r)))
+            s.comp_m(want=False)
+            assert s.objective() == float(n_pairs)                              # exact, fp64 sums of integers
+        s.set_factors(pcr.initial(R.d1, r), pcr.initial(R.d2, r))
+        s.comp_m(want=False)
+        objs, counts = [s.objective()], []
+        for _ in range(iters):
+            oV, iv = s.update_V()
+            oU, iu = s.update_U()
+            objs += [oV, oU]
+            counts.append((iv["cg"], iv["ls"], iv["accepted"]))
+            assert iu["ls"] >= R.d1 - 64 and iu["cg"] >= iu["ls"]               # (almost) every user took a Newton step
+        te = s.evaluate(1, 10); tr = s.evaluate(0, 10)
+        U, V = s.get_factors()
+        assert np.isfinite(U).all() and np.isfinite(V).all()
+        out[prec] = dict(objs=objs, counts=counts, te=te, tr=tr, create=t_create)
+        s.close()
+    for prec, o in out.items():
+        assert all(b < a for a, b in zip(o["objs"], o["objs"][1:])), (prec, o["objs"])   # strictly decreasing, every half step
+    a, b = out[pcr.PCR_F32], out[pcr.PCR_F64]
+    assert a["counts"] == b["counts"], (a["counts"], b["counts"])
+    assert np.allclose(a["objs"], b["objs"], rtol=1e-3)
+    for key in ("te", "tr"):
+        assert abs(a[key][0] - b[key][0]) < 1e-3 and abs(a[key][1] - b[key][1]) < 1e-3, (key, a[key], b[key])
+    return out
+
+
+def test_config3_full_netflix_shape_on_one_gpu():
+    """configs[3] at full size on one GPU (the 8-GPU run shards exactly this set by user)."""
+    R = synth.generate_fast("netflix")
+    assert (R.d1, R.d2, R.nnz) == (480189, 17770, 100_000_000)
+    out = _property_run(R, 100, 5000.0)
+    assert out[pcr.PCR_F32]["te"][1] > 0.9                                      # NDCG@10 after two iterations (0.95 at four)
+
+
+def test_config4_yahoo_shaped_share_of_one_gpu_k200():
+    """configs[4]: rank 0's share (1/8 of the users) of the Yahoo!Music-shaped set, k = 200 -- item table (109 MB in fp32)
+    beyond all L2s, users with tens of thousands of ratings."""
+    R = synth.generate_fast("yahoo", users=(0, 225000))
+    assert R.d2 == 136000 and 80_000_000 < R.nnz < 95_000_000 and int(np.diff(R.index).max()) > 30000
+    _property_run(R, 200, 5000.0)

@@ -170,3 +170,59 @@ def test_rating_parser_is_correctly_rounded(tmp_path):
         have = got[(z % 50, z // 50)]
         assert have == want or (np.isnan(have) and np.isnan(want)), (s, have, want)
         assert np.signbit(have) == np.signbit(want), s
+
+
+def test_tune_table_rejects_unknown_keys_and_reads_no_environment():
+    """pcr_tune() is the only way to override a launch choice: unknown keys are an error, and nothing on the product path
+    reads the environment any more (round-1 verdict: 23 undocumented getenv knobs)."""
+    pcr.tune("spmm_tiles", 16)
+    pcr.tune("spmm_tiles", None)
+    with pytest.raises(pcr.PcrError, match="unknown key"):
+        pcr.tune("no_such_knob", 1)
+    hdr = open(os.path.join(ROOT, "include", "primalcr.h")).read()
+    src_dir = os.path.join(ROOT, "primalcr_amd", "csrc")
+    keys = set(re.findall(r'pcr_tune_(?:int|get)\("([a-z_0-9]+)"', "".join(open(os.path.join(src_dir, f)).read() for f in ("pcr_solver.hip", "pcr_host.cpp"))))
+    assert keys, "the solver consults the tune table"
+    for k in keys:
+        pcr.tune(k, None)                                       # every key the solver reads is a registered key ...
+        assert re.search(r"\b" + k + r"\b", hdr), f"tune key {k} is not documented in include/primalcr.h"
+    for root, _, files in os.walk(src_dir):
+        for f in files:
+            assert "getenv" not in open(os.path.join(root, f), errors="replace").read(), f"{f} reads the environment"
+
+
+def test_dataset_from_csr_equals_from_triplets():
+    R = synth.generate("small", seed=5)
+    a = pcr.Dataset.from_ratings(R)
+    idx, item, val = a.csr(0)
+    tidx, titem, tval = a.csr(1)
+    b = pcr.Dataset.from_csr(R.d1, R.d2, idx, item.astype(np.int32), val, tidx, titem.astype(np.int32), tval)
+    assert a.dims() == b.dims() and a.count_pairs() == b.count_pairs()
+    for w in (0, 1):
+        for x, y in zip(a.csr(w), b.csr(w)):
+            assert np.array_equal(x, y)
+    bad = item.astype(np.int32).copy()
+    bad[[0, 1]] = bad[[1, 0]]                                   # items of a user must ascend (convert(), util.cpp:229-243)
+    with pytest.raises(pcr.PcrError, match="ascending"):
+        pcr.Dataset.from_csr(R.d1, R.d2, idx, bad, val)
+
+
+def test_cxx_generator_is_range_and_thread_independent():
+    """primalcr_amd/csrc/pcr_synth.cpp: one random stream per user, so any user range of a shape comes out the same whatever
+    the thread count -- what lets a test (or a rank) generate just its share of configs[3] / configs[4]."""
+    kw = dict(d1=3000, nnz=400_000)
+    R = synth.generate_fast("netflix", threads=1, **kw)
+    lens = np.diff(R.index)
+    assert R.nnz == 400_000 and lens.min() >= 10 and np.all(np.diff(R.tindex) == 10)
+    for u in (0, 17, 2999):
+        seg = R.item[R.index[u]:R.index[u + 1]]
+        assert np.all(np.diff(seg) > 0)
+        assert not set(seg) & set(R.titem[R.tindex[u]:R.tindex[u + 1]])        # held-out ratings are disjoint from training
+    shares = np.bincount(R.val.astype(int), minlength=6)[1:] / R.nnz
+    assert np.abs(shares - synth.LEVEL_SHARES).max() < 0.02                     # the 1-5 star shares of ml1m/test.ratings
+    part = synth.generate_fast("netflix", users=(1000, 1500), threads=5, **kw)
+    a, b = R.index[1000], R.index[1500]
+    assert np.array_equal(part.item, R.item[a:b]) and np.array_equal(part.val, R.val[a:b])
+    assert np.array_equal(part.titem, R.titem[R.tindex[1000]:R.tindex[1500]])
+    ds = pcr.Dataset.from_ratings(R)
+    assert ds.dims() == (3000, 17770, 400_000, 30_000)
