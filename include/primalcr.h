@@ -175,6 +175,15 @@ void pcr_solver_destroy(pcr_solver *s);
  * (128 bytes), the host application broadcasts it, every rank calls comm_init. */
 int pcr_comm_unique_id(void *id128);                                       /* [device] */
 int pcr_solver_comm_init(pcr_solver *s, const void *id128);                /* [device] */
+/* The direct peer-to-peer alternative for the ranks of ONE node (replaces the omp atomics of
+ * pcrpp.cpp:240-243, :323-327 across GPUs): every rank exposes an exchange buffer through HIP IPC; an all-reduce is a
+ * reduce-scatter + all-gather in which each rank reads its peers' buffers over xGMI, sums in rank order (every rank
+ * obtains the same bits) and meets the others in host barriers over a POSIX shared-memory control block, whose error flag
+ * also releases the peers of a rank that failed.  Every rank calls this with the same name ("/something", shm_open);
+ * no id exchange is needed.  Use either this or pcr_solver_comm_init. */
+int pcr_solver_comm_init_p2p(pcr_solver *s, const char *shm_name);         /* [device] */
+/* ranks the solver's communicator reports (ncclCommCount / the p2p control block); 1 without a communicator */
+int pcr_solver_comm_nranks(pcr_solver *s);
 /* Shard-local mode for a solver created with nranks > 1 and no communicator: every collective
  * becomes a no-op, so pcr_obtain_g / pcr_compute_Ha / pcr_objective return THIS SHARD'S PARTIAL
  * (rank 0 carries the lambda term).  Lets a host application combine shards itself, and lets one

@@ -86,6 +86,8 @@ def lib():
     L.pcr_solver_destroy.argtypes = [vp]
     L.pcr_comm_unique_id.argtypes = [vp]
     L.pcr_solver_comm_init.argtypes = [vp, vp]
+    L.pcr_solver_comm_init_p2p.argtypes = [vp, C.c_char_p]
+    L.pcr_solver_comm_nranks.argtypes = [vp]
     L.pcr_solver_set_local_only.argtypes = [vp, ci]
     L.pcr_solver_shard.argtypes = [vp] + [C.POINTER(i64)] * 3
     L.pcr_solver_set_factors.argtypes = [vp, vp, vp]
@@ -280,6 +282,13 @@ class Solver:
     def comm_init(self, uid: bytes):
         buf = C.create_string_buffer(uid, 128)
         _chk(lib().pcr_solver_comm_init(self._h, buf))
+
+    def comm_init_p2p(self, shm_name: str):
+        """Direct peer-to-peer exchange (every rank of the node calls it with the same '/name')."""
+        _chk(lib().pcr_solver_comm_init_p2p(self._h, shm_name.encode()))
+
+    def comm_nranks(self):
+        return lib().pcr_solver_comm_nranks(self._h)
 
     def set_local_only(self, on=True):
         _chk(lib().pcr_solver_set_local_only(self._h, int(on)))

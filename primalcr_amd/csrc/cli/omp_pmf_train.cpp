@@ -12,14 +12,29 @@
 //   --snapshot-every N  also write <model>.iter<k> after every N-th outer iteration
 //   --cg-iters N / --cg-tol X  truncated-Newton knobs (the reference hard-codes 10 / 0.01); --cg-iters k with a
 //                       small --cg-tol makes the U step an exact Newton step
+//   --gpus N       user-shard the training over N GPUs of this node: the data set is parsed once, then one
+//                  worker process per GPU is forked BEFORE anything touches a GPU; worker q owns the users
+//                  pcr_partition_users gives rank q, V and the CG vectors are replicated, the V-gradient and every
+//                  Hessian-vector product are all-reduced.  Worker 0 logs; at the end every worker deposits its rows of U
+//                  (the "all-gather of U shards") and the parent writes the model and U.txt / V.txt.
+//   --devices a,b,..  the HIP device of every rank (default 0..N-1)
+//   --comm rccl|p2p   exchange step: ncclAllReduce over RCCL (default) or the direct peer-to-peer reduce-scatter /
+//                     all-gather of pcr_solver_comm_init_p2p
+//   --tune key=value  a launch knob of pcr_tune() (repeatable)
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <csignal>
 #include <fstream>
 #include <iostream>
 #include <string>
 #include <vector>
+
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "primalcr.h"
 
@@ -41,7 +56,11 @@ static void exit_with_help() {
         "    --cache file : binary cache of the parsed data set (rebuilt when the text files change)\n"
         "    --snapshot-every n : also write <model>.iter<k> after every n-th iteration\n"
         "    --cg-iters n : CG iterations per Newton step at most (default 10, the reference's constant)\n"
-        "    --cg-tol x : CG residual tolerance relative to ||g|| (default 0.01, the reference's constant)\n");
+        "    --cg-tol x : CG residual tolerance relative to ||g|| (default 0.01, the reference's constant)\n"
+        "    --gpus n : shard the users over n GPUs of this node, one worker process per GPU (default 1)\n"
+        "    --devices a,b,.. : HIP device of every rank (default 0..n-1)\n"
+        "    --comm rccl|p2p : all-reduce through RCCL (default) or direct peer-to-peer buffers\n"
+        "    --tune key=value : launch knob (pcr_tune)\n");
     exit(1);
 }
 
@@ -69,11 +88,136 @@ static void die(const char* what) {
     exit(1);
 }
 
+// side files (pmf-train.cpp:208-227, 276-295) and the model (pmf-train.cpp:297-310)
+static void write_outputs(const pcr_params& param, const std::string& model, const std::vector<double>& U, const std::vector<double>& V,
+                          int64_t d1, int64_t d2) {
+    const int k = param.k;
+    std::string suffix = param.solver_type == PCR_SOLVER_PCR ? std::to_string(static_cast<int>(param.lambda)) : "";
+    auto dump = [&](const char* name, const std::vector<double>& M, int64_t rows) {
+        std::cout << name << " matrix of size " << rows << ", " << k << std::endl;
+        std::ofstream f(std::string(name) + suffix + ".txt");
+        for (int64_t a = 0; a < rows; ++a)
+            for (int b = 0; b < k; ++b) { f << M[a * k + b]; f << (b < k - 1 ? " " : "\n"); }
+    };
+    dump("U", U, d1);
+    dump("V", V, d2);
+    if (pcr_model_save(model.c_str(), U.data(), d1, V.data(), d2, k) != PCR_OK) die("model");
+}
+
+// ---- --gpus N: one worker process per GPU -------------------------------------------------------------------------------
+// Shared between the parent and its workers (anonymous MAP_SHARED, made before the fork): the RCCL id, the result factors.
+struct SharedHdr {
+    std::atomic<int> id_ready, failed, nranks_reported;
+    unsigned char nccl_id[128];
+    char shm_name[64];
+};
+
+// body of worker `rank`: everything that touches a GPU happens here, after the fork
+static int worker(const pcr_dataset* ds, pcr_params param, int rank, int nranks, const std::string& comm_kind, SharedHdr* hdr,
+                  double* Ush, double* Vsh, const std::vector<double>& U0, const std::vector<double>& V0, int64_t d1, int64_t d2,
+                  int snapshot_every, const std::string& model) {
+    auto fail = [&](const char* what) { fprintf(stderr, "[rank %d] %s: %s\n", rank, what, pcr_last_error()); hdr->failed.store(1); return 1; };
+    const auto t0 = std::chrono::steady_clock::now();
+    pcr_solver* s = nullptr;
+    if (pcr_solver_create(ds, &param, rank, nranks, &s) != PCR_OK) return fail("solver");
+    if (comm_kind == "p2p") {
+        if (pcr_solver_comm_init_p2p(s, hdr->shm_name) != PCR_OK) return fail("comm (p2p)");
+    } else {
+        if (rank == 0) {
+            if (pcr_comm_unique_id(hdr->nccl_id) != PCR_OK) return fail("comm id");
+            hdr->id_ready.store(1, std::memory_order_release);
+        }
+        for (int spins = 0; !hdr->id_ready.load(std::memory_order_acquire); ++spins) {
+            if (hdr->failed.load() || spins > 120 * 1000) { fprintf(stderr, "[rank %d] no communicator id from rank 0\n", rank); return 1; }
+            usleep(1000);
+        }
+        if (pcr_solver_comm_init(s, hdr->nccl_id) != PCR_OK) return fail("comm (rccl)");
+    }
+    if (rank == 0) hdr->nranks_reported.store(pcr_solver_comm_nranks(s));
+    {
+        int64_t f0 = 0, n0 = 0, z0 = 0;
+        pcr_solver_shard(s, &f0, &n0, &z0);
+        fprintf(stderr, "[rank %d] device %d: users [%ld, %ld), %ld ratings\n", rank, param.device, (long)f0, (long)(f0 + n0), (long)z0);
+    }
+    if (pcr_solver_set_factors(s, U0.data(), V0.data()) != PCR_OK) return fail("set_factors");
+    // snapshots: rank 0 alone sees the log lines, and a snapshot needs every rank's rows of U -- not offered with --gpus > 1
+    (void)snapshot_every; (void)model;
+    if (pcr_train(s, nullptr, nullptr, nullptr) != PCR_OK) return fail("train");
+    // "all-gather of U shards" (SURVEY 8e): every rank deposits its own rows; V is replicated, rank 0 deposits it
+    int64_t first = 0, nu = 0;
+    pcr_solver_shard(s, &first, &nu, nullptr);
+    std::vector<double> Uf((size_t)d1 * param.k), Vf((size_t)d2 * param.k);
+    if (pcr_solver_get_factors(s, Uf.data(), rank == 0 ? Vf.data() : nullptr) != PCR_OK) return fail("get_factors");
+    memcpy(Ush + first * param.k, Uf.data() + first * param.k, (size_t)nu * param.k * sizeof(double));
+    if (rank == 0) {
+        memcpy(Vsh, Vf.data(), Vf.size() * sizeof(double));
+        printf("Wall-time: %lg secs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        fflush(stdout);
+    }
+    pcr_solver_destroy(s);
+    return 0;
+}
+
+static int train_multi(const pcr_dataset* ds, const pcr_params& param, int gpus, const std::vector<int>& devices,
+                       const std::string& comm_kind, std::vector<double>& U, std::vector<double>& V, int64_t d1, int64_t d2,
+                       int snapshot_every, const std::string& model) {
+    if (snapshot_every > 0) { fprintf(stderr, "--snapshot-every is not available with --gpus > 1\n"); return 1; }
+    const size_t nU = (size_t)d1 * param.k, nV = (size_t)d2 * param.k;
+    const size_t bytes = sizeof(SharedHdr) + (nU + nV) * sizeof(double) + 64;
+    void* mem = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (mem == MAP_FAILED) { perror("mmap"); return 1; }
+    SharedHdr* hdr = new (mem) SharedHdr();
+    hdr->id_ready.store(0); hdr->failed.store(0); hdr->nranks_reported.store(0);
+    snprintf(hdr->shm_name, sizeof hdr->shm_name, "/pcr_p2p_%d", (int)getpid());
+    double* Ush = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(hdr + 1) + 63) & ~(uintptr_t)63);
+    double* Vsh = Ush + nU;
+    fflush(stdout); fflush(stderr);
+    std::vector<pid_t> kids;
+    for (int q = 0; q < gpus; ++q) {
+        const pid_t pid = fork();
+        if (pid < 0) { perror("fork"); for (pid_t k : kids) kill(k, SIGKILL); return 1; }
+        if (pid == 0) {
+            pcr_params p = param;
+            p.device = devices.empty() ? q : devices[q];
+            const int rc = worker(ds, p, q, gpus, comm_kind, hdr, Ush, Vsh, U, V, d1, d2, snapshot_every, model);
+            fflush(stdout); fflush(stderr);
+            _exit(rc);
+        }
+        kids.push_back(pid);
+    }
+    // the parent never touches a GPU: it waits; the first worker that fails takes the others with it (a rank blocked in an
+    // RCCL collective whose peer died would wait forever)
+    int bad = 0;
+    for (size_t left = kids.size(); left > 0;) {
+        int st = 0;
+        const pid_t pid = wait(&st);
+        if (pid < 0) break;
+        --left;
+        const bool ok = WIFEXITED(st) && WEXITSTATUS(st) == 0;
+        if (!ok && !bad) {
+            bad = 1;
+            hdr->failed.store(1);
+            for (pid_t k : kids) if (k != pid) kill(k, SIGTERM);
+        }
+    }
+    if (bad) { fprintf(stderr, "omp-pmf-train: a GPU worker failed\n"); munmap(mem, bytes); return 1; }
+    if (hdr->nranks_reported.load() != gpus) {
+        fprintf(stderr, "omp-pmf-train: the communicator reports %d ranks, expected %d\n", hdr->nranks_reported.load(), gpus);
+        munmap(mem, bytes);
+        return 1;
+    }
+    memcpy(U.data(), Ush, nU * sizeof(double));
+    memcpy(V.data(), Vsh, nV * sizeof(double));
+    munmap(mem, bytes);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     pcr_params param;
     pcr_params_default(&param);
-    std::string init_model, cache;
-    int snapshot_every = 0;
+    std::string init_model, cache, comm_kind = "rccl";
+    std::vector<int> devices;
+    int snapshot_every = 0, gpus = 1;
     int i;
     for (i = 1; i < argc; i++) {                       // pmf-train.cpp:36-108
         if (argv[i][0] != '-') break;
@@ -85,6 +229,21 @@ int main(int argc, char** argv) {
         if (!strcmp(argv[i - 1], "--snapshot-every")) { snapshot_every = atoi(argv[i]); continue; }
         if (!strcmp(argv[i - 1], "--cg-iters")) { param.cg_max_iter = atoi(argv[i]); continue; }
         if (!strcmp(argv[i - 1], "--cg-tol")) { param.cg_tol = atof(argv[i]); continue; }
+        if (!strcmp(argv[i - 1], "--gpus")) { gpus = atoi(argv[i]); continue; }
+        if (!strcmp(argv[i - 1], "--comm")) { comm_kind = argv[i]; continue; }
+        if (!strcmp(argv[i - 1], "--devices")) {
+            for (const char* q = argv[i]; *q;) { devices.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+            continue;
+        }
+        if (!strcmp(argv[i - 1], "--tune")) {
+            std::string kv = argv[i];
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos || pcr_tune(kv.substr(0, eq).c_str(), kv.substr(eq + 1).c_str()) != PCR_OK) {
+                fprintf(stderr, "--tune %s: %s\n", argv[i], eq == std::string::npos ? "expected key=value" : pcr_last_error());
+                return 1;
+            }
+            continue;
+        }
         switch (argv[i - 1][1]) {
             case 's': param.solver_type = atoi(argv[i]); break;
             case 'k': param.k = atoi(argv[i]); break;
@@ -143,8 +302,20 @@ int main(int argc, char** argv) {
     if (param.solver_type == PCR_SOLVER_PCRPP) { std::cout << nnz << std::endl; std::cout << "starts!" << std::endl; }
     else std::cout << "nnz: " << nnz << std::endl;
 
+    if (gpus < 1 || gpus > 16 || (comm_kind != "rccl" && comm_kind != "p2p") || (!devices.empty() && (int)devices.size() != gpus)) {
+        fprintf(stderr, "--gpus must be 1..16, --comm rccl or p2p, --devices one ordinal per rank\n");
+        return 1;
+    }
+    if (gpus > 1) {
+        const int rc = train_multi(ds, param, gpus, devices, comm_kind, U, V, d1, d2, snapshot_every, model);
+        if (rc != 0) return rc;
+        write_outputs(param, model, U, V, d1, d2);
+        pcr_dataset_free(ds);
+        return 0;
+    }
     auto t0 = std::chrono::steady_clock::now();
     pcr_solver* s = nullptr;
+    if (!devices.empty()) param.device = devices[0];
     if (pcr_solver_create(ds, &param, 0, 1, &s) != PCR_OK) die("solver");
     if (pcr_solver_set_factors(s, U.data(), V.data()) != PCR_OK) die("set_factors");
     SnapCtx snap{s, snapshot_every, model, d1, d2, k, &U, &V, false};
@@ -153,17 +324,7 @@ int main(int argc, char** argv) {
     if (pcr_solver_get_factors(s, U.data(), V.data()) != PCR_OK) die("get_factors");
     printf("Wall-time: %lg secs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 
-    // side files (pmf-train.cpp:208-227, 276-295)
-    std::string suffix = param.solver_type == PCR_SOLVER_PCR ? std::to_string(static_cast<int>(param.lambda)) : "";
-    auto dump = [&](const char* name, const std::vector<double>& M, int64_t rows) {
-        std::cout << name << " matrix of size " << rows << ", " << k << std::endl;
-        std::ofstream f(std::string(name) + suffix + ".txt");
-        for (int64_t a = 0; a < rows; ++a)
-            for (int b = 0; b < k; ++b) { f << M[a * k + b]; f << (b < k - 1 ? " " : "\n"); }
-    };
-    dump("U", U, d1);
-    dump("V", V, d2);
-    if (pcr_model_save(model.c_str(), U.data(), d1, V.data(), d2, k) != PCR_OK) die("model");
+    write_outputs(param, model, U, V, d1, d2);
     pcr_solver_destroy(s);
     pcr_dataset_free(ds);
     return 0;

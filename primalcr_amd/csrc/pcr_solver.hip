@@ -22,6 +22,7 @@
 
 #include "pcr_host.h"
 #include "pcr_kernels.h"
+#include "pcr_p2p.h"
 
 #define HIPCHK(expr)                                                                           \
     do {                                                                                       \
@@ -116,6 +117,9 @@ struct pcr_solver {
     virtual int train(pcr_log_fn log, void* ctx, pcr_iter_stats* hist) = 0;
     virtual int iterate_abi(int n, pcr_iter_stats* out) = 0;
     virtual int comm_init(const void* id) = 0;
+    virtual int comm_init_p2p(const char* shm_name) = 0;
+    virtual void comm_abort() = 0;
+    virtual int comm_nranks() = 0;
     virtual int sync() = 0;
     int64_t first_user = 0, n_users = 0, nnz_local = 0;
     bool prof_on = false;
@@ -165,6 +169,8 @@ struct Solver final : pcr_solver {
     hipEvent_t ev_lane[MAXLANE] = {};
     int nlane = 1;
     ncclComm_t comm = nullptr;
+    std::unique_ptr<P2PComm> p2p;                                 // the direct peer-to-peer alternative (pcr_p2p.h)
+    bool single() const { return (nranks == 1 && !comm && !p2p) || local_only; }     // no exchange step: one shard, or shard-local mode
     int ncu = 256;
 
     // ---- training shard
@@ -254,6 +260,7 @@ struct Solver final : pcr_solver {
         prof_resolve();
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         if (comm) ncclCommDestroy(comm);
+        p2p.reset();
         if (h_scal) (void)hipHostFree(h_scal);
         if (h_uobj) (void)hipHostFree(h_uobj);
         if (h_counters) (void)hipHostFree(h_counters);
@@ -273,7 +280,12 @@ struct Solver final : pcr_solver {
             if (!s->prof_on) return;
             ProfSlot* sl = &s->prof[name];
             sl->ratings = ratings; sl->users = users;
-            if ((sl->seen++ % s->prof_period) != 0) return;       // sampled: an event pair costs ~3 us of queue time
+            // sampled: an event pair costs ~3 us of queue time.  Slots launched once per outer iteration (the U-step classes,
+            // the prepares, the fork..join walls) are sampled at least every 4th launch, so that a 20-step run still
+            // averages five of them; the per-CG-iteration kernels every prof_period-th
+            const bool rare = name.compare(0, 5, "ustep") == 0 || name.compare(0, 5, "wall:") == 0 || name.compare(0, 7, "prepare") == 0;
+            const int period = rare ? std::min(s->prof_period, 4) : s->prof_period;
+            if ((sl->seen++ % period) != 0) return;
             slot = sl;
             a = s->ev_get(); b = s->ev_get();
             (void)hipEventRecord(a, q);
@@ -1034,16 +1046,24 @@ struct Solver final : pcr_solver {
     }
 
     int allreduce_T(T* buf, size_t count) {
-        if ((nranks == 1 && !comm) || local_only) return PCR_OK;
-        if (!comm) { pcr_set_error("nranks > 1 but pcr_solver_comm_init was not called"); return PCR_ERR_STATE; }
+        if (single()) return PCR_OK;
+        if (!comm && !p2p) { pcr_set_error("nranks > 1 but neither pcr_solver_comm_init nor pcr_solver_comm_init_p2p was called"); return PCR_ERR_STATE; }
         ProfScope ps(this, "allreduce");
+        if (p2p) {
+            if (!p2p->allreduce<T>(buf, count, st)) { pcr_set_error("p2p all-reduce: " + p2p->err); return PCR_ERR_COMM; }
+            return PCR_OK;
+        }
         NCCLCHK(ncclAllReduce(buf, buf, count, sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, comm, st));
         return PCR_OK;
     }
     int allreduce_f64(double* buf, size_t count) {
-        if ((nranks == 1 && !comm) || local_only) return PCR_OK;
-        if (!comm) { pcr_set_error("nranks > 1 but pcr_solver_comm_init was not called"); return PCR_ERR_STATE; }
+        if (single()) return PCR_OK;
+        if (!comm && !p2p) { pcr_set_error("nranks > 1 but neither pcr_solver_comm_init nor pcr_solver_comm_init_p2p was called"); return PCR_ERR_STATE; }
         ProfScope ps(this, "allreduce");
+        if (p2p) {
+            if (!p2p->allreduce<double>(buf, count, st, true)) { pcr_set_error("p2p all-reduce: " + p2p->err); return PCR_ERR_COMM; }
+            return PCR_OK;
+        }
         NCCLCHK(ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, st));
         return PCR_OK;
     }
@@ -1094,7 +1114,7 @@ struct Solver final : pcr_solver {
         hipLaunchKernelGGL((k_obj3<T>), dim3(nb), dim3(PCR_EW_BLOCK), 0, st, objx, objx2, n_users, Vm, nV, with_u ? d_U.p : (const T*)nullptr, nU, d_partA.p);
         // N ranks: ONE all-reduce of the four columns -- the per-user sums and |U|^2 are shard partials, |Vm|^2 (replicated) is
         // contributed by rank 0 alone
-        const bool reduce = !((nranks == 1 && !comm) || local_only);
+        const bool reduce = !single();
         const int keep1 = (!reduce || rank == 0) ? 1 : 0;
         if (after_ustep) hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + slot, d_counters.p, d_scal.p + slot + 4, counter_words(), keep1);
         else hipLaunchKernelGGL(k_fin4, dim3(1), dim3(PCR_EW_BLOCK), 0, st, d_partA.p, nb, d_scal.p + slot, (unsigned long long*)nullptr, (double*)nullptr, 0, keep1);
@@ -1204,7 +1224,7 @@ struct Solver final : pcr_solver {
         const int* skip = &d_cgp->done;
         // one GPU: Hp is final when k_spmm_fin stores it, so that kernel also produces the p.Hp / rr.p partials;
         // with an all-reduce in between they need their own pass (k_cg_a)
-        const bool fused_dots = (nranks == 1 && !comm) || local_only;
+        const bool fused_dots = single();
         const bool exact_rr = prm.cg_tol < 1e-5;                   // the residual recurrence of k_cg_bc cancels below that
         for (int k = 1; k <= prm.cg_max_iter; ++k) {
             RC(device_hv(d_p.p, d_Hp.p, skip, fused_dots ? d_rr.p : nullptr));
@@ -1543,6 +1563,29 @@ struct Solver final : pcr_solver {
         NCCLCHK(ncclCommInitRank(&comm, nranks, uid, rank));
         return PCR_OK;
     }
+    // direct peer-to-peer exchange (pcr_p2p.h): every rank of the job calls this with the same name
+    int comm_init_p2p(const char* shm_name) override {
+        if (comm || p2p) { pcr_set_error("this solver already has a communicator"); return PCR_ERR_STATE; }
+        HIPCHK(hipSetDevice(prm.device));
+        p2p.reset(new P2PComm());
+        if (!p2p->init(shm_name, rank, nranks, (size_t)d2 * geo.ld, sizeof(T))) {
+            pcr_set_error("p2p communicator: " + p2p->err);
+            p2p.reset();
+            return PCR_ERR_COMM;
+        }
+        return PCR_OK;
+    }
+    // a rank that fails leaves the job: its peers must not wait for it
+    void comm_abort() override {
+        if (p2p) p2p->abort_peers();
+        if (comm) { (void)ncclCommAbort(comm); comm = nullptr; }
+    }
+    int comm_nranks() override {
+        if (p2p) return p2p->nranks;
+        int n = 1;
+        if (comm && ncclCommCount(comm, &n) != ncclSuccess) n = -1;
+        return n;
+    }
     int sync() override { HIPCHK(hipStreamSynchronize(st)); return PCR_OK; }
 };
 
@@ -1586,6 +1629,14 @@ int pcr_comm_unique_id(void* id128) {
 }
 #define S_OR_ARG if (!s) { pcr_set_error("null solver"); return PCR_ERR_ARG; }
 int pcr_solver_comm_init(pcr_solver* s, const void* id128) { S_OR_ARG; return s->comm_init(id128); }
+int pcr_solver_comm_init_p2p(pcr_solver* s, const char* shm_name) {
+    S_OR_ARG;
+    if (!shm_name || shm_name[0] != '/') { pcr_set_error("pcr_solver_comm_init_p2p: the name must start with '/' (shm_open)"); return PCR_ERR_ARG; }
+    return s->comm_init_p2p(shm_name);
+}
+int pcr_solver_comm_nranks(pcr_solver* s) { if (!s) return -1; return s->comm_nranks(); }
+// a failing rank tells its peers (p2p: shared error flag; RCCL: local abort) before it reports the error
+static int leave_on_error(pcr_solver* s, int rc) { if (rc != PCR_OK) s->comm_abort(); return rc; }
 int pcr_solver_set_local_only(pcr_solver* s, int on) { S_OR_ARG; s->local_only = on != 0; return PCR_OK; }
 int pcr_solver_shard(const pcr_solver* s, int64_t* first_user, int64_t* n_users, int64_t* nnz_local) {
     S_OR_ARG;
@@ -1601,12 +1652,12 @@ int pcr_objective(pcr_solver* s, double* obj) { S_OR_ARG; return s->objective(ob
 int pcr_obtain_g(pcr_solver* s, double* g) { S_OR_ARG; return s->obtain_g(g); }
 int pcr_compute_Ha(pcr_solver* s, const double* a, double* Ha) { S_OR_ARG; return s->compute_Ha(a, Ha); }
 int pcr_solve_delta(pcr_solver* s, const double* g, double* delta, int* it) { S_OR_ARG; return s->solve_delta(g, delta, it); }
-int pcr_update_V(pcr_solver* s, double* now_obj, int* info) { S_OR_ARG; return s->update_V(now_obj, info); }
-int pcr_update_U(pcr_solver* s, double* now_obj, int64_t* info) { S_OR_ARG; return s->update_U(now_obj, info); }
+int pcr_update_V(pcr_solver* s, double* now_obj, int* info) { S_OR_ARG; return leave_on_error(s, s->update_V(now_obj, info)); }
+int pcr_update_U(pcr_solver* s, double* now_obj, int64_t* info) { S_OR_ARG; return leave_on_error(s, s->update_U(now_obj, info)); }
 int pcr_evaluate(pcr_solver* s, int which, int ndcg_k, double* e, double* n) { S_OR_ARG; return s->evaluate(which, ndcg_k, e, n); }
-int pcr_train(pcr_solver* s, pcr_log_fn log, void* ctx, pcr_iter_stats* hist) { S_OR_ARG; return s->train(log, ctx, hist); }
+int pcr_train(pcr_solver* s, pcr_log_fn log, void* ctx, pcr_iter_stats* hist) { S_OR_ARG; return leave_on_error(s, s->train(log, ctx, hist)); }
 int pcr_solver_sync(pcr_solver* s) { S_OR_ARG; return s->sync(); }
-int pcr_iterate(pcr_solver* s, int n, pcr_iter_stats* out) { S_OR_ARG; return s->iterate_abi(n, out); }
+int pcr_iterate(pcr_solver* s, int n, pcr_iter_stats* out) { S_OR_ARG; return leave_on_error(s, s->iterate_abi(n, out)); }
 
 int pcr_profile_enable(pcr_solver* s, int on) { S_OR_ARG; s->prof_on = on != 0; s->prof_period = on > 1 ? on : 1; if (on) s->prof_prewarm(4096); return PCR_OK; }
 int pcr_profile_reset(pcr_solver* s) {

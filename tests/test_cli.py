@@ -175,3 +175,75 @@ def test_train_cli_on_the_references_own_rating_files(name, tag, args, tmp_path)
         assert re.sub(NUM, "#", a) == re.sub(NUM, "#", b), (a, b)
         tol = 4e-2 if (noisy and a.startswith("(T")) else 6e-6
         assert np.allclose([float(x) for x in re.findall(NUM, a)], [float(x) for x in re.findall(NUM, b)], rtol=tol, atol=tol), (a, b)
+
+
+def test_gpus_option_bootstrap_without_a_gpu(tmp_path):
+    """--gpus N forks one worker per GPU before anything touches a GPU and the parent only waits.  On a machine without a
+    GPU every worker must fail loudly in pcr_solver_create, the parent must reap them all and exit 1 -- and bad option
+    values never reach the fork."""
+    import torch
+    R = synth.generate("tiny")
+    d = synth.write_dir(R, str(tmp_path / "data"))
+    r = run([TRAIN, "--gpus", "0", d, "m.model"], tmp_path)
+    assert r.returncode == 1 and "--gpus must be" in r.stderr
+    r = run([TRAIN, "--gpus", "2", "--devices", "0", d, "m.model"], tmp_path)
+    assert r.returncode == 1 and "one ordinal per rank" in r.stderr
+    r = run([TRAIN, "--gpus", "2", "--comm", "smoke-signals", d, "m.model"], tmp_path)
+    assert r.returncode == 1
+    r = run([TRAIN, "--tune", "nonsense=1", d, "m.model"], tmp_path)
+    assert r.returncode == 1 and "unknown key" in r.stderr
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the failure path of the workers needs a machine without one")
+    r = run([TRAIN, "--gpus", "3", "-p", "0", d, "m.model"], tmp_path)
+    assert r.returncode == 1 and "a GPU worker failed" in r.stderr
+    assert r.stderr.count("solver:") >= 1 and "HIP" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", [2, 1])
+def test_gpus_option_two_ranks_on_one_gpu_equal_one_rank(solver, tmp_path):
+    """omp-pmf-train --gpus 2 --devices 0,0 --comm p2p: two worker processes share the one GPU of the test box (RCCL refuses
+    two ranks on one device; the peer-to-peer communicator does not care), each owns the users pcr_partition_users gives
+    its rank, every V-side vector goes through the reduce-scatter / all-gather over IPC-mapped buffers.  fp64: objective
+    lines to the printed digits, model equal to the single-process run to summation-order rounding; --gpus 1 is the
+    plain run, byte for byte."""
+    import primalcr_amd as pcr
+    g, meta, d = golden_dir("mid5", tmp_path)
+    base = [TRAIN, "-s", str(solver), "-k", str(int(g["r"])), "-l", repr(float(g["lam"])), "-t", "3", "--f64"]
+    one = run(base + [d, "one.model"], tmp_path)
+    assert one.returncode == 0, one.stderr
+    same = run(base + ["--gpus", "1", d, "same.model"], tmp_path)
+    assert same.returncode == 0 and open(tmp_path / "same.model", "rb").read() == open(tmp_path / "one.model", "rb").read()
+    two = run(base + ["--gpus", "2", "--devices", "0,0", "--comm", "p2p", d, "two.model"], tmp_path)
+    assert two.returncode == 0, two.stderr
+    strip = lambda out: [l for l in out.split("\n") if l.startswith(("Iter", "(T"))]
+    la, lb = strip(one.stdout), strip(two.stdout)
+    assert len(la) == len(lb) == 4 + 8
+    for x, y in zip(la, lb):
+        fx = [float(v) for v in re.findall(NUM, x)]; fy = [float(v) for v in re.findall(NUM, y)]
+        if x.startswith("Iter"):
+            fx, fy = fx[:1] + fx[2:], fy[:1] + fy[2:]              # (the time differs)
+        assert re.sub(NUM, "#", x) == re.sub(NUM, "#", y) and np.allclose(fx, fy, rtol=2e-5, atol=2e-6), (x, y)
+    a = np.frombuffer(open(tmp_path / "one.model", "rb").read(), np.float64)
+    b = np.frombuffer(open(tmp_path / "two.model", "rb").read(), np.float64)
+    assert a.shape == b.shape and np.nanmax(np.abs(a[2:] - b[2:])) < 1e-9 * np.nanmax(np.abs(a[2:]))
+    # the workers' shards are the partitioner's
+    idx = np.concatenate([[0], np.cumsum(np.bincount(g["user"], minlength=int(g["d1"])))])
+    bounds = pcr.partition_users(idx, 2)
+    shards = re.findall(r"^\[rank (\d)\] device 0: users \[(\d+), (\d+)\), (\d+) ratings$", two.stderr, re.M)
+    assert sorted((int(q), int(a0), int(b0)) for q, a0, b0, _ in shards) == [(0, bounds[0], bounds[1]), (1, bounds[1], bounds[2])]
+
+
+@pytest.mark.gpu
+def test_gpus_option_three_ranks_default_precision(tmp_path):
+    """Three ranks on the one GPU in the default precision (fp32 storage): quality lines within 1e-3 of one rank."""
+    g, meta, d = golden_dir("mid5", tmp_path)
+    base = [TRAIN, "-k", str(int(g["r"])), "-l", repr(float(g["lam"])), "-t", "3"]
+    one = run(base + [d, "one.model"], tmp_path)
+    three = run(base + ["--gpus", "3", "--devices", "0,0,0", "--comm", "p2p", d, "three.model"], tmp_path)
+    assert one.returncode == 0 and three.returncode == 0, three.stderr
+    pat = r"^\((Training|Testing)\) pairwise error is (\S+) and ndcg is (\S+)$"
+    a = re.findall(pat, one.stdout, re.M); b = re.findall(pat, three.stdout, re.M)
+    assert len(a) == len(b) == 8
+    for (t1, e1, n1), (t2, e2, n2) in zip(a, b):
+        assert t1 == t2 and abs(float(e1) - float(e2)) < 1e-3 and abs(float(n1) - float(n2)) < 1e-3
