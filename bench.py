@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+TRAFFIC_FILE = "r02_traffic.json"   # PMC passes of this command at this round's kernels (tools/collect_profiles.sh)
 USERS_PER_GPU = 6040
 D2, NNZ_PER_GPU = 3952, 939809
 
@@ -122,33 +123,40 @@ def host_cores():
 
 def cpu_baseline(R, n_pairs, r, lam):
     """Reference OpenMP path on this host (kind "reference"), else the C restatement (kind "port").
+    BASELINE.md 3.3: timed at -n <all cores of this box's share> AND at -n 1.
     Bounded: data sets beyond 2 M ratings are timed on a prefix of their users (same shape, fewer users)."""
     from oracle import oracle_py
+    from primalcr_amd import synth
     cores = host_cores()
     sample_note = "the full data set"
+    user, tuser = R.user, R.tuser
     if R.nnz > 2_000_000:
-        from primalcr_amd import synth
-        nu = int(R.user[2_000_000])                 # whole users within the first 2 M ratings (triplets are user-sorted)
-        keep, tkeep = R.user < nu, R.tuser < nu
-        R = synth.Ratings(nu, R.d2, R.user[keep], R.item[keep], R.val[keep], R.tuser[tkeep], R.titem[tkeep], R.tval[tkeep])
+        nu = int(user[2_000_000])                 # whole users within the first 2 M ratings (triplets are user-sorted)
+        keep, tkeep = user < nu, tuser < nu
+        R = synth.Ratings(nu, R.d2, user[keep], R.item[keep], R.val[keep], tuser[tkeep], R.titem[tkeep], R.tval[tkeep])
         n_pairs = synth.count_pairs(R)
         sample_note = f"its first {nu} users ({R.nnz} ratings, {n_pairs} ordered pairs)"
+    elif not isinstance(R, synth.Ratings):
+        R = synth.Ratings(R.d1, R.d2, user, R.item, R.val, tuser, R.titem, R.tval)
     if os.path.exists(oracle_py.REF_TRAIN):
-        from primalcr_amd import synth
-        iters = 2
-        with tempfile.TemporaryDirectory() as td:
-            d = synth.write_dir(R, os.path.join(td, "data"))
+        def ref_run(threads, iters, d, td):
             t0 = time.time()
             out = subprocess.run([oracle_py.REF_TRAIN, "-s", "2", "-k", str(r), "-l", repr(lam), "-t", str(iters),
-                                  "-p", "0", "-n", str(cores), d, os.path.join(td, "m.model")],
+                                  "-p", "0", "-n", str(threads), d, os.path.join(td, "m.model")],
                                  cwd=td, capture_output=True, text=True, check=True).stdout
-            wall = time.time() - t0
-        times = [float(x) for x in re.findall(r"^Iter \d+ time (\S+) obj", out, re.M)]
-        secs = times[-1]
-        log(f"[cpu_baseline] reference omp-pmf-train -n {cores}: {secs:.2f}s for {iters} iterations (wall {wall:.1f}s)")
-        return {"value": n_pairs * iters / secs, "unit": "pairs/s", "cores": cores, "kind": "reference",
-                "sample": f"omp-pmf-train -s 2 -k {r} -l {lam:g} -t {iters} -p 0 -n {cores} on {sample_note}; "
-                          f"'Iter {iters} time' = {secs:.3f} s", "s_per_iter": secs / iters}
+            times = [float(x) for x in re.findall(r"^Iter \d+ time (\S+) obj", out, re.M)]
+            log(f"[cpu_baseline] reference omp-pmf-train -n {threads}: {times[-1]:.2f}s for {iters} iteration(s) (wall {time.time() - t0:.1f}s)")
+            return times[-1]
+        with tempfile.TemporaryDirectory() as td:
+            d = synth.write_dir(R, os.path.join(td, "data"))
+            it_all, it_one = 2, 1
+            secs = ref_run(cores, it_all, d, td)
+            secs1 = ref_run(1, it_one, d, td)
+        return {"value": n_pairs * it_all / secs, "unit": "pairs/s", "cores": cores, "kind": "reference",
+                "sample": f"omp-pmf-train -s 2 -k {r} -l {lam:g} -t {it_all} -p 0 -n {cores} on {sample_note}; "
+                          f"'Iter {it_all} time' = {secs:.3f} s", "s_per_iter": secs / it_all,
+                "single_thread": {"value": n_pairs * it_one / secs1, "unit": "pairs/s", "cores": 1, "s_per_iter": secs1 / it_one,
+                                  "sample": f"the same command with -n 1 -t {it_one}: 'Iter {it_one} time' = {secs1:.3f} s"}}
     orc = oracle_py.Oracle()
     nu = 400
     keep = R.user < nu
@@ -161,20 +169,76 @@ def cpu_baseline(R, n_pairs, r, lam):
             "sample": f"C restatement, first {nu} users ({int(keep.sum())} ratings, {pairs} pairs), 1 iteration = {secs:.2f} s"}
 
 
+def timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, local_rank, args, profile, shm_name):
+    """One solver, `warmup` untimed + exactly `steps` timed outer iterations (barrier + synchronize on both sides, MAX over
+    ranks), then the quality after warmup + steps iterations."""
+    p = pcr.Parameter(k=r, precision=prec, device=local_rank, do_predict=0, maxiter=1, **{"lambda": lam})
+    s = pcr.Solver(ds, p, rank, N)
+    if N > 1:
+        if args.comm == "p2p":
+            s.comm_init_p2p(shm_name + ("_64" if prec == pcr.PCR_F64 else "_32"))
+        else:
+            ids = [pcr.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            s.comm_init(ids[0])
+    s.set_factors(pcr.initial(R.d1, r), pcr.initial(R.d2, r))       # the reference's init stream (util.cpp:80)
+
+    def barrier():
+        s.sync()
+        torch.cuda.synchronize()
+        if N > 1:
+            dist.barrier()
+
+    objs = [rec["obj"] for rec in s.iterate(args.warmup)]
+    prof_period = 0
+    if profile:
+        # sampled: every n-th launch of each kernel carries an event pair (an event pair costs ~3 us of queue time: every 4th
+        # launch adds 6.6 % to the timed region, every 16th 1.9 %, with the same per-kernel averages)
+        prof_period = args.profile_period if args.profile_period > 0 else max(1, min(16, 11 * args.steps // 12))
+        s.profile(True, period=prof_period)
+        s.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    inner = {"cg_v": 0, "ls_v": 0, "cg_u": 0, "ls_u": 0}
+    # exactly K steps = K outer iterations (V step + U step) of the training loop, as pcr_train runs them (pcr_iterate)
+    for rec in s.iterate(args.steps):
+        objs.append(rec["obj"])
+        for key in inner:
+            inner[key] += rec[key]
+    barrier()
+    secs = time.perf_counter() - t0
+    if N > 1:
+        tt = torch.tensor([secs], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        secs = float(tt.item())
+    prof = s.profile_all() if profile else {}
+    launches = {name: s.profile_launches(name) for name in prof}
+    scope = {name: s.profile_scope(name) for name in prof}
+    s.profile(False)
+    te_err, te_ndcg = s.evaluate(1, 10)
+    tr_err, tr_ndcg = s.evaluate(0, 10)
+    out = dict(secs=secs, objs=objs, inner=inner, prof=prof, launches=launches, scope=scope, prof_period=prof_period,
+               te=(te_err, te_ndcg), tr=(tr_err, tr_ndcg), comm_nranks=s.comm_nranks(), shard=(s.first_user, s.n_users, s.nnz_local))
+    s.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--shape", choices=["ml1m", "netflix"], default="ml1m",
-                    help="ml1m: configs[1], 6040 users per GPU (weak scaling); netflix: configs[3], 480189 x 17770, 100 M "
-                         "ratings in total, user-sharded over the GPUs (strong scaling; generating it takes minutes per rank)")
-    ap.add_argument("--users", type=int, default=None, help="override the user count of the shape (total for netflix, per GPU for ml1m)")
+    ap.add_argument("--shape", choices=["ml1m", "netflix", "yahoo"], default="ml1m",
+                    help="ml1m: configs[1], 6040 users per GPU (weak scaling); netflix: configs[3], 480189 x 17770, 100 M ratings in "
+                         "total, user-sharded over the GPUs (strong scaling); yahoo: configs[4] shape -- give --users (a user prefix)")
+    ap.add_argument("--users", type=int, default=None, help="override the user count of the shape (total for netflix/yahoo, per GPU for ml1m)")
     ap.add_argument("--nnz", type=int, default=None, help="override the rating count likewise")
-    ap.add_argument("--rank-k", type=int, default=100, help="factor rank (BASELINE: 100)")
+    ap.add_argument("--rank-k", type=int, default=None, help="factor rank (BASELINE: 100; yahoo: 200)")
     ap.add_argument("--lam", type=float, default=5000.0)
     ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--comm", choices=["rccl", "p2p"], default="rccl", help="N > 1: ncclAllReduce, or the direct peer-to-peer exchange")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-f64", action="store_true", help="skip the second timed run in the reference's arithmetic type")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--profile-period", type=int, default=0,
                     help="event-time every n-th launch of each kernel (the first one included); 0 = as sparse as leaves a dozen "
@@ -207,101 +271,57 @@ def main():
     import primalcr_amd as pcr
     from primalcr_amd import synth
 
-    r, lam = args.rank_k, args.lam
+    r, lam = args.rank_k or (200 if args.shape == "yahoo" else 100), args.lam
     t0 = time.time()
     if args.shape == "ml1m":
         R = synth.generate("ml1m", d1=(args.users or USERS_PER_GPU) * N, nnz=(args.nnz or NNZ_PER_GPU) * N)
         scaling, shape_note = "weak", f"ml1m-shaped PrimalCR++ -k {r} -l {lam:g} (configs[1])"
-    else:
-        R = synth.generate("netflix", d1=args.users, nnz=args.nnz)
+    elif args.shape == "netflix":
+        R = synth.generate_fast("netflix", d1=args.users, nnz=args.nnz)
         scaling, shape_note = "strong", f"Netflix-shaped PrimalCR++ -k {r} -l {lam:g} (configs[3])"
+    else:
+        R = synth.generate_fast("yahoo", users=(0, args.users or 225000))
+        scaling, shape_note = "strong", f"Yahoo!Music-shaped PrimalCR++ -k {r} -l {lam:g} (configs[4]: first {R.d1} of 1.8 M users)"
     ds = pcr.Dataset.from_ratings(R)
     n_pairs = ds.count_pairs()
     if rank == 0:
         log(f"[data] {args.shape}-shaped x{N}: {R.d1} users x {R.d2} items, {R.nnz} ratings, {n_pairs} ordered pairs, "
-            f"{len(R.tuser)} test ratings ({time.time() - t0:.1f}s)")
+            f"{len(R.tval)} test ratings ({time.time() - t0:.1f}s)")
     prec = pcr.PCR_F32 if args.precision == "f32" else pcr.PCR_F64
-    p = pcr.Parameter(k=r, precision=prec, device=local_rank, do_predict=0, maxiter=1, **{"lambda": lam})
-    s = pcr.Solver(ds, p, rank, N)
+    shm = [f"/pcr_bench_{os.getpid()}" if rank == 0 else None]
     if N > 1:
-        ids = [pcr.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        s.comm_init(ids[0])
-    U0, V0 = pcr.initial(R.d1, r), pcr.initial(R.d2, r)      # the reference's init stream (util.cpp:80)
-    s.set_factors(U0, V0)
-
-    def barrier():
-        s.sync()
-        torch.cuda.synchronize()
-        if N > 1:
-            dist.barrier()
-
-    objs = [r["obj"] for r in s.iterate(args.warmup)]
-    if not args.no_profile:
-        # sampled: every n-th launch of each kernel carries an event pair (an event pair costs ~3 us of queue time: every 4th
-        # launch adds 6.6 % to the timed region, every 16th 1.9 %, with the same per-kernel averages)
-        prof_period = args.profile_period if args.profile_period > 0 else max(1, min(16, 11 * args.steps // 12))
-        s.profile(True, period=prof_period)
-        s.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    inner = {"cg_v": 0, "ls_v": 0, "cg_u": 0, "ls_u": 0}
-    # exactly K steps = K outer iterations (V step + U step) of the training loop, as pcr_train runs them (pcr_iterate)
-    for rec in s.iterate(args.steps):
-        objs.append(rec["obj"])
-        for key in inner:
-            inner[key] += rec[key]
-    barrier()
-    secs = time.perf_counter() - t0
-    if N > 1:
-        tt = torch.tensor([secs], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        secs = float(tt.item())
-    prof = {} if args.no_profile else s.profile_all()
-    s.profile(False)
-    # quality after warmup+steps outer iterations (NDCG@10 / pairwise error on the held-out ratings)
-    te_err, te_ndcg = s.evaluate(1, 10)
-    tr_err, tr_ndcg = s.evaluate(0, 10)
+        dist.broadcast_object_list(shm, src=0)
+    run = timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, local_rank, args, not args.no_profile, shm[0])
+    # the same workload in the reference's arithmetic type (fp64 storage as well as fp64 accumulation), timed the same way
+    run64 = None
+    if prec == pcr.PCR_F32 and not args.no_f64:
+        run64 = timed_run(pcr, torch, dist, ds, R, r, lam, pcr.PCR_F64, rank, N, local_rank, args, False, shm[0])
+    secs, objs, inner, prof = run["secs"], run["objs"], run["inner"], run["prof"]
+    te_err, te_ndcg = run["te"]; tr_err, tr_ndcg = run["tr"]
+    prof_period = run["prof_period"]
 
     if rank != 0:
         if N > 1:
             dist.barrier(); dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (rank 0's shard)
-    roof, kernels = None, {}
+    # ---- per-kernel rooflines (rank 0's shard)
+    roof, roof_phase, kernels = None, {}, {}
+    esz = 4 if prec == pcr.PCR_F32 else 8
     if prof:
-        esz = 4 if prec == pcr.PCR_F32 else 8
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")      # PMC passes of this command (tools/pmc_traffic.py)
-        if os.path.exists(tpath) and args.shape == "ml1m" and not args.users and not args.nnz and r == 100 and N == 1:
-            traffic = json.load(open(tpath))      # the PMC passes were taken on exactly this workload
-        # Share of the timed region.  The length bins of k_prepare / k_ustep run CONCURRENTLY on side streams, so the
-        # sum of their durations overstates their part of the wall clock: the fork..join wall time of each group
-        # ("wall:<class>" slots, timed on the solver's stream) is attributed to its bins in proportion to their
-        # durations.  Kernels launched back to back on the solver's stream count with their own duration.
-        # Launches are SAMPLED (every prof_period-th, the first included), so a slot's time in the region is its average
-        # times ALL its launches -- not the sum of its samples, which would favour the slots with few launches.
-        est = {name: ((ms / n) * max(s.profile_launches(name), n) if n else 0.0) for name, (ms, n) in prof.items()}
-        prof_est = {name: (est[name], n) for name, (ms, n) in prof.items()}
-        wall = {k[5:]: v for k, v in prof_est.items() if k.startswith("wall:")}
-        cls_sum = {}
-        for name, (ms, n) in prof_est.items():
-            cls = name.partition("/")[0]
-            if cls in wall:
-                cls_sum[cls] = cls_sum.get(cls, 0.0) + ms
-        eff = {}
-        for name, (ms, n) in prof_est.items():
-            cls = name.partition("/")[0]
-            if name.startswith("wall:"):
-                continue
-            eff[name] = wall[cls][0] * ms / cls_sum[cls] if cls in wall and cls_sum.get(cls) else ms
-        total_ms = sum(eff.values())
+        traffic, traffic_src = {}, None
+        tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)      # PMC passes of this command (tools/pmc_traffic.py)
+        if os.path.exists(tpath) and args.shape == "ml1m" and not args.users and not args.nnz and r == 100 and N == 1 and prec == pcr.PCR_F32:
+            tj = json.load(open(tpath))             # the PMC passes were taken on exactly this workload
+            traffic, traffic_src = tj.get("kernels", tj), tj.get("source")
+        # Launches are SAMPLED, so a slot's time in the region is its average times ALL its launches.
+        est = {name: ((ms / n) * max(run["launches"][name], n) if n else 0.0) for name, (ms, n) in prof.items()}
+        total_ms = sum(v for k, v in est.items() if not k.startswith("wall:"))
         for name, (ms, n) in prof.items():
             cls, _, tag = name.partition("/")
             if cls not in SLOT_KERNEL or n == 0:
                 continue
-            nnz_b, nu_b = s.profile_scope(name)          # ratings / users one launch of this slot covers
+            nnz_b, nu_b = run["scope"][name]              # ratings / users one launch of this slot covers
             ab = algorithmic_bytes(name, nnz_b, nu_b, R.d2, r, esz)
             avg_s = ms / n / 1e3
             tr = None
@@ -311,26 +331,50 @@ def main():
                          any(slot_kernel_match(other, kn, args.precision) and slot_kernel_match(name, kn, args.precision) for kn in traffic))
             for kname, t in traffic.items():
                 if not shared and slot_kernel_match(name, kname, args.precision):
-                    # FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md): quote the raw
-                    # counter sum; the x2-corrected read side is in profiles/r01_traffic.json
-                    tr = int(t["fetch_bytes_per_launch_raw"] + t["write_bytes_per_launch"])
-            kernels[name] = {"avg_us": round(avg_s * 1e6, 2), "timed_launches": int(n), "share": round(eff[name] / total_ms, 4),
-                             "concurrent_group": cls in wall, "algorithmic_bytes": int(ab),
-                             "achieved_GBs": round(ab / avg_s / 1e9, 2),
+                    # MI355X_MICROARCH.md (HBM): FETCH_SIZE counts wide coalesced reads at half their bytes on gfx950 ->
+                    # doubled; WRITE_SIZE is exact
+                    tr = int(2 * t["fetch_bytes_per_launch_raw"] + t["write_bytes_per_launch"])
+            kernels[name] = {"avg_us": round(avg_s * 1e6, 2), "timed_launches": int(n), "launches": int(run["launches"][name]),
+                             "gpu_time_share": round(est[name] / total_ms, 4), "concurrent_group": cls in ("ustep", "prepare", "eval"),
+                             "algorithmic_bytes": int(ab), "achieved_GBs": round(ab / avg_s / 1e9, 2),
                              "frac_hbm_peak": round(ab / avg_s / 1e9 / HBM_PEAK_GBS, 5), "traffic_bytes": tr}
         if args.verbose:
-            for k, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
-                extra = f"  alg {kernels[k]['achieved_GBs']:8.1f} GB/s  wall share {100 * kernels[k]['share']:5.1f} %" if k in kernels else ""
-                log(f"  {k:14s} {ms:9.3f} ms  {n:6d} timed  {1e3 * ms / max(n, 1):9.1f} us/launch{extra}")
-        dom = max(kernels, key=lambda k: kernels[k]["share"])
+            for k, (ms, n) in sorted(prof.items(), key=lambda kv: -est[kv[0]]):
+                extra = f"  alg {kernels[k]['achieved_GBs']:8.1f} GB/s  gpu-time share {100 * kernels[k]['gpu_time_share']:5.1f} %" if k in kernels else ""
+                log(f"  {k:14s} {est[k]:9.3f} ms  {n:6d} timed  {1e3 * ms / max(n, 1):9.1f} us/launch{extra}")
+        # dominant kernel = the slot with the most GPU time (average duration x launches), the way `rocprofv3 --stats` ranks
+        # kernels -- concurrent length classes are NOT discounted for running side by side
+        dom = max(kernels, key=lambda k: kernels[k]["gpu_time_share"])
         kd = kernels[dom]
         roof = {"bound": "hbm", "kernel": dom, "achieved": kd["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kd["frac_hbm_peak"], "traffic": kd["traffic_bytes"], "avg_launch_us": kd["avg_us"],
                 "launches_timed": kd["timed_launches"], "algorithmic_bytes_per_launch": kd["algorithmic_bytes"],
-                "share_of_timed_region": kd["share"],
-                "note": "dominant = largest share of the wall clock of the timed region (concurrent length bins share their "
-                        f"group's fork..join wall time); every {prof_period}th launch of a kernel is event-timed; per-kernel table in 'kernels' "
-                        "(DESIGN.md 3.5, 4)"}
+                "share_of_gpu_time": kd["gpu_time_share"],
+                "traffic_source": (traffic_src or f"profiles/{TRAFFIC_FILE}") + ": stored rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                  "command (separate runs), per launch, 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md); not "
+                                  "measured by this run" if kd["traffic_bytes"] is not None else None,
+                "note": "dominant = largest GPU time (average launch duration x launches, HIP events on the launch stream), as "
+                        f"rocprofv3 --stats ranks kernels; every {prof_period}th launch of a kernel is event-timed (once-per-step "
+                        "kernels every 4th); all slots in 'kernels', phases in 'roofline_phase' (DESIGN.md 3.5, 4)"}
+        # phases: algorithmic bytes of everything a phase launches per step / its wall time per step
+        def phase(names, wall_ms_per_step):
+            ab = sum(kernels[k]["algorithmic_bytes"] * run["launches"][k] / args.steps for k in names)
+            return {"bound": "hbm", "algorithmic_bytes_per_step": int(ab), "wall_us_per_step": round(1e3 * wall_ms_per_step, 1),
+                    "achieved": round(ab / (wall_ms_per_step / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ab / (wall_ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "share_of_step": round(wall_ms_per_step / (1e3 * secs / args.steps), 4)}
+        un = [k for k in kernels if k.startswith("ustep/")]
+        if un and prof.get("wall:ustep", (0, 0))[1]:
+            wm, wn = prof["wall:ustep"]
+            roof_phase["u_step"] = dict(phase(un, wm / wn), kernels=un,
+                                        note="all length classes of k_ustep, launched side by side: sum of their algorithmic bytes / fork..join wall "
+                                             "time on the solver's stream")
+        vn = [k for k in kernels if k.partition("/")[0] in ("sddmm", "spmm", "spmm_fin", "vhv", "vgrad", "cg", "prepare")]
+        if vn:
+            v_ms = sum(est[k] for k in vn) / args.steps          # back to back on one stream: durations add up
+            roof_phase["v_step"] = dict(phase(vn, v_ms), kernels=vn,
+                                        note="gradient + CG (SDDMM, sweep, SpMM, finish, vector update) + line search, back to back on the "
+                                             "solver's stream: sum of kernel time")
     cpu = None
     if N == 1 and not args.no_cpu:
         cpu = cpu_baseline(R, n_pairs, r, lam)
@@ -340,7 +384,7 @@ def main():
     # SURVEY 8d, the whole-iteration figure: compulsory bytes W of one outer iteration with ideal caching (esz-byte factors,
     # int32 item, uint8 level, esz-byte m, uint32 permutation) at the EXECUTED inner counts, over the measured time per
     # iteration -- all ranks' bytes over the job's time, against N x 8 TB/s.
-    esz_w = 4 if prec == pcr.PCR_F32 else 8
+    esz_w = esz
     n_cg, n_ls = inner["cg_v"] / args.steps, inner["ls_v"] / args.steps
     B_csr, F_U, F_V = 5 * R.nnz + 8 * (R.d1 + 1), esz_w * r * R.d1, esz_w * r * R.d2 * N      # V is replicated on every rank
     P_m, P_sort = B_csr + F_U + F_V + esz_w * R.nnz, 8 * R.nnz
@@ -360,8 +404,8 @@ def main():
     gather = {"bytes_per_half_pass": int(G), "half_passes_per_iteration": round(gather_passes, 2),
               "achieved_GBs": round(gather_passes * G / (secs / args.steps) / 1e9, 1),
               "note": "row gathers (one esz*r-byte factor row per rating and half-pass) sustained over the WHOLE iteration, all "
-                      "ranks; on this shape they are served by the L2s (user-average CG / line-search counts on the U side; the U step "
-                      "of users with <= 64 ratings loads its rows once and re-reads them from LDS)"}
+                      "ranks; on this shape they are served by the L2s (user-average CG / line-search counts on the U side, summed "
+                      "over all ranks)"}
     out = {
         "metric": "pairwise-comparisons/sec", "value": value, "unit": "pairs/s", "n_gpus": N, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps, "higher_is_better": True, "scaling": scaling,
@@ -369,15 +413,28 @@ def main():
         "config": {"workload": f"{shape_note}; {R.d1} users x {R.d2} items, "
                                f"{R.nnz} ratings, {n_pairs} ordered pairs; 1 step = 1 outer iteration (V step + U step)",
                    "solver": "PrimalCR++", "rank": r, "lambda": lam, "parallelism": f"user-sharded x{N}",
-                   "accumulation": "f64"},
+                   "accumulation": "f64", "storage": "f32" if prec == pcr.PCR_F32 else "f64",
+                   "exchange": None if N == 1 else args.comm},
         "ndcg10_test": te_ndcg, "pairwise_error_test": te_err, "ndcg10_train": tr_ndcg, "pairwise_error_train": tr_err,
         "outer_iterations_run": args.warmup + args.steps, "objective": objs[-1],
         "inner_per_step": {k: v / args.steps for k, v in inner.items()},
         # SURVEY 8d, kernel-level figure: ordered pairs swept per second over the EXECUTED sweep passes of a step
         # (V side: gradient + Hessian-vector products + line-search objectives; U side the same per user, averaged)
         "passes_per_step": passes, "sweep_pairs_per_s": value * passes, "s_per_iter": secs / args.steps,
-        "roofline": roof, "roofline_iteration": it_roof, "gather": gather, "cpu_baseline": cpu, "kernels": kernels,
+        "comm_nranks": run["comm_nranks"],
+        "roofline": roof, "roofline_phase": roof_phase, "roofline_iteration": it_roof, "gather": gather, "cpu_baseline": cpu,
+        "kernels": kernels,
     }
+    if run64:
+        # the reference computes in fp64 throughout: the same K steps with fp64 storage, same clock, same barriers
+        out["f64"] = {"dtype": "f64", "ms_per_step": 1e3 * run64["secs"] / args.steps, "value": n_pairs * args.steps / run64["secs"],
+                      "unit": "pairs/s", "ndcg10_test": run64["te"][1], "pairwise_error_test": run64["te"][0],
+                      "objective": run64["objs"][-1], "inner_per_step": {k: v / args.steps for k, v in run64["inner"].items()},
+                      "note": "second timed run of the same workload with U, V, m and the CG vectors stored in fp64 (the reference's "
+                              "arithmetic type); 'value' above is the fp32-storage / fp64-accumulation run the north star allows "
+                              "('within fp32 tolerance')"}
+        out["f64_minus_f32"] = {"ndcg10_test": run64["te"][1] - te_ndcg, "pairwise_error_test": run64["te"][0] - te_err,
+                                "objective_rel": run64["objs"][-1] / objs[-1] - 1}
     if cpu:
         out["speedup_vs_cpu_baseline"] = value / cpu["value"]
     print(json.dumps(out), flush=True)

@@ -3,7 +3,7 @@
 bench command.  Units/corrections per MI355X_MICROARCH.md (HBM section): the counters are in KiB
 (hbm_bytes = counter * 1024); on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced
 streaming reads, so the read side is reported both raw and doubled (upper bound for coalesced reads).
-Usage: pmc_traffic.py <dir_fetch> <dir_write> <out.json>"""
+Usage: pmc_traffic.py <dir_fetch> <dir_write> <out.json> [source note]"""
 import csv, glob, json, sys, collections
 def load(d, name):
     f = glob.glob(d + "/*/*counter_collection.csv")[0]
@@ -19,6 +19,6 @@ for k in sorted(set(fe) | set(wr)):
     f, nf = fe.get(k, [0, 1]); w, nw = wr.get(k, [0, 1])
     out[k] = {"launches": max(nf, nw), "fetch_bytes_per_launch_raw": 1024 * f / max(nf, 1),
               "fetch_bytes_per_launch_x2": 2048 * f / max(nf, 1), "write_bytes_per_launch": 1024 * w / max(nw, 1)}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
+json.dump({"source": sys.argv[4] if len(sys.argv) > 4 else None, "kernels": out}, open(sys.argv[3], "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["fetch_bytes_per_launch_raw"] * kv[1]["launches"])[:16]:
     print(f"{k[:70]:70s} n={v['launches']:5d} fetch={v['fetch_bytes_per_launch_raw']/1e6:9.3f} MB (x2 {v['fetch_bytes_per_launch_x2']/1e6:9.3f}) write={v['write_bytes_per_launch']/1e6:9.3f} MB")
