@@ -198,6 +198,7 @@ def timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, local_rank, args, 
         s.profile(True, period=prof_period)
         s.profile_reset()
     barrier()
+    rows0 = s.counter("ustep_row_gathers")
     t0 = time.perf_counter()
     inner = {"cg_v": 0, "ls_v": 0, "cg_u": 0, "ls_u": 0}
     # exactly K steps = K outer iterations (V step + U step) of the training loop, as pcr_train runs them (pcr_iterate)
@@ -218,6 +219,7 @@ def timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, local_rank, args, 
     te_err, te_ndcg = s.evaluate(1, 10)
     tr_err, tr_ndcg = s.evaluate(0, 10)
     out = dict(secs=secs, objs=objs, inner=inner, prof=prof, launches=launches, scope=scope, prof_period=prof_period,
+               u_rows=s.counter("ustep_row_gathers") - rows0,
                te=(te_err, te_ndcg), tr=(tr_err, tr_ndcg), comm_nranks=s.comm_nranks(), shard=(s.first_user, s.n_users, s.nnz_local))
     s.close()
     return out
@@ -366,15 +368,23 @@ def main():
         un = [k for k in kernels if k.startswith("ustep/")]
         if un and prof.get("wall:ustep", (0, 0))[1]:
             wm, wn = prof["wall:ustep"]
-            roof_phase["u_step"] = dict(phase(un, wm / wn), kernels=un,
+            u_gather = run["u_rows"] / args.steps / N * r * esz           # this rank's share (the counter is the all-rank total)
+            roof_phase["u_step"] = dict(phase(un, wm / wn), kernels=un, gathered_row_bytes_per_step=int(u_gather),
+                                        gather_GBs=round(u_gather / (wm / wn / 1e3) / 1e9, 1),
                                         note="all length classes of k_ustep, launched side by side: sum of their algorithmic bytes / fork..join wall "
-                                             "time on the solver's stream")
+                                             "time on the solver's stream; gather_GBs = rows of V actually gathered (counted in the kernel: per user "
+                                             "1 + 2 per CG iteration + 1 per line-search try, x its ratings) x row bytes / that wall time -- the "
+                                             "L2 -> CU row-gather rate this phase runs at (measured ceiling 16.8-18.8 TB/s, MI355X_MICROARCH.md)")
         vn = [k for k in kernels if k.partition("/")[0] in ("sddmm", "spmm", "spmm_fin", "vhv", "vgrad", "cg", "prepare")]
         if vn:
-            v_ms = sum(est[k] for k in vn) / args.steps          # back to back on one stream: durations add up
-            roof_phase["v_step"] = dict(phase(vn, v_ms), kernels=vn,
+            u_wall = roof_phase.get("u_step", {}).get("wall_us_per_step", 0.0) / 1e3
+            v_ms = 1e3 * secs / args.steps - u_wall               # the two half steps alternate on one stream: the rest of a step is the V step
+            v_gather = ((n_ls_v := inner["ls_v"] / args.steps) + 2 * (inner["cg_v"] / args.steps) + 1) * esz * r * run["shard"][2]
+            roof_phase["v_step"] = dict(phase(vn, v_ms), kernels=vn, gathered_row_bytes_per_step=int(v_gather),
+                                        gather_GBs=round(v_gather / (v_ms / 1e3) / 1e9, 1),
                                         note="gradient + CG (SDDMM, sweep, SpMM, finish, vector update) + line search, back to back on the "
-                                             "solver's stream: sum of kernel time")
+                                             "solver's stream: step time minus the U step's wall time; gather_GBs = (1 SpMM + n_cg x (SDDMM + "
+                                             "SpMM) + n_ls SDDMM) x ratings x row bytes / that time")
     cpu = None
     if N == 1 and not args.no_cpu:
         cpu = cpu_baseline(R, n_pairs, r, lam)
@@ -400,12 +410,14 @@ def main():
     # U side per rating 1 (gradient) + 2 per CG iteration + 1 per line-search try.
     G = esz_w * r * R.nnz
     n_cg_u, n_ls_u = inner["cg_u"] / args.steps / max(R.d1, 1), inner["ls_u"] / args.steps / max(R.d1, 1)
-    gather_passes = (n_ls + n_cg) + (1 + n_cg) + (1 + 2 * n_cg_u + n_ls_u)
+    u_half_passes = run["u_rows"] / args.steps / max(R.nnz, 1)       # counted in k_ustep: rating-weighted, not user-averaged
+    gather_passes = (n_ls + n_cg) + (1 + n_cg) + u_half_passes
     gather = {"bytes_per_half_pass": int(G), "half_passes_per_iteration": round(gather_passes, 2),
+              "u_side_half_passes": round(u_half_passes, 2), "u_side_user_average": round(1 + 2 * n_cg_u + n_ls_u, 2),
               "achieved_GBs": round(gather_passes * G / (secs / args.steps) / 1e9, 1),
               "note": "row gathers (one esz*r-byte factor row per rating and half-pass) sustained over the WHOLE iteration, all "
-                      "ranks; on this shape they are served by the L2s (user-average CG / line-search counts on the U side, summed "
-                      "over all ranks)"}
+                      "ranks; on this shape they are served by the L2s (U side: rows counted by the kernel -- long users run more CG "
+                      "iterations than the user average, so the rating-weighted pass count is the higher one)"}
     out = {
         "metric": "pairwise-comparisons/sec", "value": value, "unit": "pairs/s", "n_gpus": N, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps, "higher_is_better": True, "scaling": scaling,

@@ -146,7 +146,7 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *   ustep_mode      1 = latency form of k_ustep for every long class, 2 = throughput form (default: by user count)
  *   ustep_many      user count above which a long class counts as throughput-bound (default CUs/4)
  *   ustep_seq       1 = the U step's length classes back to back on one stream
- *   ustep_lockstep  U step as rating-parallel lock-step passes over all users: 1 on, 0 off (default: by shard size)
+ *   ustep_lockstep  1 = U step as rating-parallel lock-step passes over all users (default 0: per-user kernels)
  *   ustep_gram      dual (Gram-matrix, MFMA) U step for users with at most that many ratings; 0 off (default by rank)
  *   cluster_k       4 (default) or 1: workgroups per clustered long user;  cluster_users: how many users get clusters
  *   ubins           "cap:block:resident,..." length classes of the U step below 1024 ratings
@@ -184,6 +184,11 @@ int pcr_solver_comm_init(pcr_solver *s, const void *id128);                /* [d
 int pcr_solver_comm_init_p2p(pcr_solver *s, const char *shm_name);         /* [device] */
 /* ranks the solver's communicator reports (ncclCommCount / the p2p control block); 1 without a communicator */
 int pcr_solver_comm_nranks(pcr_solver *s);
+/* diagnostic counters, cumulative since the solver was created:
+ *   "ustep_row_gathers"  rows of V the U steps gathered (per user: 1 for the gradient + 2 per CG iteration + 1 per
+ *                        line-search try, times its rating count; all ranks) -- the U step's gather rate = this x k x
+ *                        sizeof(storage type) / its wall time */
+int pcr_solver_counter(pcr_solver *s, const char *name, double *value);
 /* Shard-local mode for a solver created with nranks > 1 and no communicator: every collective
  * becomes a no-op, so pcr_obtain_g / pcr_compute_Ha / pcr_objective return THIS SHARD'S PARTIAL
  * (rank 0 carries the lambda term).  Lets a host application combine shards itself, and lets one

@@ -88,6 +88,7 @@ def lib():
     L.pcr_solver_comm_init.argtypes = [vp, vp]
     L.pcr_solver_comm_init_p2p.argtypes = [vp, C.c_char_p]
     L.pcr_solver_comm_nranks.argtypes = [vp]
+    L.pcr_solver_counter.argtypes = [vp, C.c_char_p, C.POINTER(cd)]
     L.pcr_solver_set_local_only.argtypes = [vp, ci]
     L.pcr_solver_shard.argtypes = [vp] + [C.POINTER(i64)] * 3
     L.pcr_solver_set_factors.argtypes = [vp, vp, vp]
@@ -286,6 +287,11 @@ class Solver:
     def comm_init_p2p(self, shm_name: str):
         """Direct peer-to-peer exchange (every rank of the node calls it with the same '/name')."""
         _chk(lib().pcr_solver_comm_init_p2p(self._h, shm_name.encode()))
+
+    def counter(self, name):
+        v = C.c_double()
+        _chk(lib().pcr_solver_counter(self._h, name.encode(), v))
+        return v.value
 
     def comm_nranks(self):
         return lib().pcr_solver_comm_nranks(self._h)

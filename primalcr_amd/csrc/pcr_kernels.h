@@ -51,16 +51,19 @@ struct Shard {
     const int64_t* uptr;       // nu+1   user -> CSR offset
     const int32_t* item;       // nnz    CSR order
     const uint16_t* lvl;       // nnz    CSR order, dense level inside the user
-    const int32_t* cpos;       // nnz    CSR position -> CSC position
     const int64_t* runofs;     // nu+1
     const int32_t* runstart;   // per user T_u+1 cumulative level counts
     // (level, m)-sorted state written by k_prepare
     T* ms;                     // nnz
     int32_t* sitem;            // nnz    item id at sorted position
     uint16_t* slvl;            // nnz
-    int32_t* cinv;             // nnz    CSC entry -> sorted position (k_spmm reads c through it)
-    int32_t* scpos;            // nnz    CSC entry of the rating at each sorted position (inverse of cinv): lets k_ustep
-                               //        re-sort a user in place without going back to CSR order
+    int32_t* sidx;             // nnz    index INSIDE THE USER'S CSR SEGMENT of the rating at each sorted position: the only map
+                               //        between the two orders.  Per-rating values that cross kernels (the SDDMM's b, the
+                               //        sweeps' c) live in CSR order; a sweep reads b and writes c through sidx -- a
+                               //        permutation inside its own user's segment, whole cache lines -- and the item-major
+                               //        k_spmm reads c through a STATIC CSC -> CSR map.  (Round 1 kept a dynamic CSC <-> sorted
+                               //        map instead, rewritten by every sort: a 4-byte scatter per rating into 64-byte lines
+                               //        spread over the whole shard -- 3.6x the algorithmic write traffic in k_prepare.)
     double* objp;              // nu     per-user loss partial (no regulariser)
     double* objr;              // nu     k_ustep: obj_u of the returned u (loss + lambda/2 |u|^2, pcrpp.cpp:835)
     // window cache: for sorted position p and every OTHER level l' (slot = l' < l ? l' : l'-1) the
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(const T* __restrict__ U, const 
                                                  const int32_t* __restrict__ ruser, const int32_t* __restrict__ rows,
                                                  int64_t nnz, T* __restrict__ out, Geo geo, int tile, const int* skip,
                                                  const int32_t* __restrict__ perm, const int2* __restrict__ blk_map,
-                                                 const int32_t* __restrict__ chunk_ptr) {
+                                                 const int32_t* __restrict__ chunk_ptr, const uint8_t* __restrict__ only = nullptr) {
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -636,7 +639,13 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(const T* __restrict__ U, const 
     for (int t = threadIdx.x; t < nb; t += BLOCK) { s_row[t] = rows[b0 + t]; s_usr[t] = ruser[b0 + t]; }
     __syncthreads();
     const int l0 = grp * tile;
-    const int l1 = (l0 + tile < nb) ? l0 + tile : nb;
+    int l1 = (l0 + tile < nb) ? l0 + tile : nb;
+    if (only) {     // lock-step U step: `only[user]` = the user still takes part; a lane group none of whose ratings do skips its tile
+        int any = 0;
+        for (int q = l0 + g; q < l1; q += G) any |= (int)only[s_usr[q]];
+        for (int off = G >> 1; off > 0; off >>= 1) any |= __shfl_xor(any, off);
+        if (!any) l1 = l0;
+    }
     const int rho = 4 * (g & 1) + (g & 2) + ((g >> 2) & 1);
     for (int k = 0; k * G < geo.nchunk; ++k) {
         const int ch = g + k * G;
@@ -738,7 +747,7 @@ __device__ unsigned long long g_prep_prof[4 * 8];
 template <typename T, int BLOCK, bool BIG>
 __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, const int32_t* __restrict__ users, int nusers,
                                              const T* __restrict__ m_in, int cap, int cap_pad, int rs_cap, char* scratch,
-                                             size_t stride, int strict, int first, int step) {
+                                             size_t stride, int strict, int first, int step, const uint8_t* __restrict__ only = nullptr) {
     typedef typename LiSel<T, BIG>::type LI;
     Carver small(smem);
     double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
@@ -754,6 +763,7 @@ __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, cons
 
     for (int ui = first; ui < nusers; ui += step) {
         const int u = users[ui];
+        if (only && !only[u]) continue;                       // lock-step U step: users whose line search is over keep their state
         const int64_t s0 = S.uptr[u];
         const int n = (int)(S.uptr[u + 1] - s0);
         const int nlev = (int)(S.runofs[u + 1] - S.runofs[u]) - 1;
@@ -777,9 +787,7 @@ __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, cons
             S.ms[s0 + p] = key[p];
             S.slvl[s0 + p] = (uint16_t)LiOps<LI>::lev(x);
             S.sitem[s0 + p] = S.item[s0 + idx];
-            const int32_t e = S.cpos[s0 + idx];
-            S.scpos[s0 + p] = e;
-            S.cinv[e] = (int32_t)(s0 + p);
+            S.sidx[s0 + p] = (int32_t)idx;
         }
         PPROF(2);
         double loss;
@@ -807,9 +815,10 @@ __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, cons
 template <typename T, int BLOCK, bool BIG>
 __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                    const T* __restrict__ m_in,
-                                                   int cap, int cap_pad, int rs_cap, char* scratch, size_t stride, int strict) {
+                                                   int cap, int cap_pad, int rs_cap, char* scratch, size_t stride, int strict,
+                                                   const uint8_t* __restrict__ only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    prepare_body<T, BLOCK, BIG>(smem, S, users, nusers, m_in, cap, cap_pad, rs_cap, scratch, stride, strict, (int)blockIdx.x, (int)gridDim.x);
+    prepare_body<T, BLOCK, BIG>(smem, S, users, nusers, m_in, cap, cap_pad, rs_cap, scratch, stride, strict, (int)blockIdx.x, (int)gridDim.x, only);
 }
 
 // Both LDS-resident classes in ONE launch of 512-thread workgroups: workgroups [0, nblk_b) take the long users of list B
@@ -819,15 +828,16 @@ template <typename T>
 __global__ __launch_bounds__(512) void k_prepare_all(Shard<T> S, const int32_t* __restrict__ users_a, int nusers_a, int cap_a,
                                                      int cap_pad_a, int rs_cap_a, size_t wave_bytes,
                                                      const int32_t* __restrict__ users_b, int nusers_b, int cap_b, int cap_pad_b,
-                                                     int rs_cap_b, int nblk_b, const T* __restrict__ m_in, int strict) {
+                                                     int rs_cap_b, int nblk_b, const T* __restrict__ m_in, int strict,
+                                                     const uint8_t* __restrict__ only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < nblk_b)
         prepare_body<T, 512, false>(smem, S, users_b, nusers_b, m_in, cap_b, cap_pad_b, rs_cap_b, nullptr, 0, strict,
-                                    (int)blockIdx.x, nblk_b);
+                                    (int)blockIdx.x, nblk_b, only);
     else
         prepare_body<T, 64, false>(smem + (size_t)(threadIdx.x >> 6) * wave_bytes, S, users_a, nusers_a, m_in, cap_a, cap_pad_a,
                                    rs_cap_a, nullptr, 0, strict, ((int)blockIdx.x - nblk_b) * 8 + (int)(threadIdx.x >> 6),
-                                   ((int)gridDim.x - nblk_b) * 8);
+                                   ((int)gridDim.x - nblk_b) * 8, only);
 
 }
 
@@ -838,25 +848,29 @@ __global__ __launch_bounds__(512) void k_prepare_all(Shard<T> S, const int32_t* 
 // ---------------------------------------------------------------------------------------
 template <typename T>
 static inline size_t vsweep_bytes(int cap, int rs_cap, bool two) {      // two: scores AND sweep values (HV without window cache)
-    return carve_bytes(cap, sizeof(T)) * (two ? 2 : 1) + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
+    return carve_bytes(cap, sizeof(T)) * (two ? 3 : 2) + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);      // + the CSR-order staging array
 }
 
 // body of k_vsweep: workgroup `blk` of `nblk` walks users blk, blk + nblk, ...
 template <typename T, int BLOCK, bool BIG, bool HV>
 __device__ __forceinline__ void vsweep_block_body(char* smem, const Shard<T>& S, const int32_t* __restrict__ users, int nusers,
                                                   const T* __restrict__ bsrc, T* __restrict__ c_out, int cap, int rs_cap,
-                                                  char* scratch, size_t stride, int strict, int blk, int nblk) {
+                                                  char* scratch, size_t stride, int strict, int blk, int nblk,
+                                                  const uint8_t* __restrict__ only = nullptr) {
     Carver small(smem);
     double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
     Carver big(BIG ? scratch + (size_t)blk * stride : small.p);
     T* ms = big.take<T>(cap);                           // scores (thresholds) -- not loaded when the window cache replaces them
     T* x = (HV && !S.ws) ? big.take<T>(cap) : ms;       // sweep values b; they share the array unless both are needed
+    T* stg = big.take<T>(cap);                          // CSR-order staging: b comes in and c goes out as whole lines, the
+                                                        // permutation to / from the sorted order happens here (LDS or scratch)
     double* Sx = big.take<double>(cap + 1);
     int* rs = big.take<int>(rs_cap);
     const int tid = threadIdx.x;
 
     for (int ui = blk; ui < nusers; ui += nblk) {
         const int u = users[ui];
+        if (only && !only[u]) continue;
         const int64_t s0 = S.uptr[u];
         const int n = (int)(S.uptr[u + 1] - s0);
         const int nlev = (int)(S.runofs[u + 1] - S.runofs[u]) - 1;
@@ -865,7 +879,9 @@ __device__ __forceinline__ void vsweep_block_body(char* smem, const Shard<T>& S,
         for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
         const T* xs = ms;
         if (HV) {
-            for (int p = tid; p < n; p += BLOCK) x[p] = bsrc[s0 + p];      // b = u_i . a_item, from k_sddmm
+            for (int q = tid; q < n; q += BLOCK) stg[q] = bsrc[s0 + q];                 // b = u_i . a_item (k_sddmm, CSR order)
+            __syncthreads();
+            for (int p = tid; p < n; p += BLOCK) x[p] = stg[S.sidx[s0 + p]];
             xs = x;
         }
         __syncthreads();
@@ -875,19 +891,22 @@ __device__ __forceinline__ void vsweep_block_body(char* smem, const Shard<T>& S,
             const double c = S.ws
                 ? sweep_coeff_win(S.win + (size_t)(s0 + p) * S.ws, Sx, rs, nlev, lev, (double)xs[p], HV ? 0.0 : 1.0)
                 : sweep_coeff<T>(ms, Sx, rs, nlev, lev, ms[p], (double)xs[p], HV ? 0.0 : 1.0, strict);
-            c_out[s0 + p] = (T)c;                 // sorted order: coalesced (k_spmm gathers it through cinv)
+            stg[S.sidx[s0 + p]] = (T)c;           // back to CSR order (every b was picked up before the scan's barriers)
         }
+        __syncthreads();
+        for (int q = tid; q < n; q += BLOCK) c_out[s0 + q] = stg[q];
         __syncthreads();
     }
 }
 template <typename T, int BLOCK, bool BIG, bool HV>
 __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                   const T* __restrict__ bsrc, T* __restrict__ c_out,
-                                                  int cap, int rs_cap, char* scratch, size_t stride, int strict, const int* skip) {
+                                                  int cap, int rs_cap, char* scratch, size_t stride, int strict, const int* skip,
+                                                  const uint8_t* __restrict__ only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (skip && *skip) return;
     vsweep_block_body<T, BLOCK, BIG, HV>(smem, S, users, nusers, bsrc, c_out, cap, rs_cap, scratch, stride, strict,
-                                         (int)blockIdx.x, (int)gridDim.x);
+                                         (int)blockIdx.x, (int)gridDim.x, only);
 }
 
 // k_vsweep for short users (<= 256 ratings), ONE WAVE PER USER, four users per 256-thread
@@ -895,18 +914,21 @@ __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int
 // in program order), so the many short users of a rating set do not pay a block's fixed cost each.
 template <typename T>
 static inline size_t vsweep_wave_bytes(int cap, int rs_cap, bool two) {      // per wave
-    return carve_bytes(cap, sizeof(T)) * (two ? 2 : 1) + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
+    return carve_bytes(cap, sizeof(T)) * (two ? 3 : 2) + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
 }
 // body: this wave sweeps user number ui of the list
 template <typename T, bool HV>
 __device__ __forceinline__ void vsweep_wave_body(char* smem, const Shard<T>& S, const int32_t* __restrict__ users, int nusers,
                                                  const T* __restrict__ bsrc, T* __restrict__ c_out,
-                                                 int cap, int rs_cap, size_t wave_bytes, int strict, int ui) {
+                                                 int cap, int rs_cap, size_t wave_bytes, int strict, int ui,
+                                                 const uint8_t* __restrict__ only = nullptr) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (ui >= nusers) return;
+    if (only && !only[users[ui]]) return;
     Carver big(smem + (size_t)wid * wave_bytes);
     T* ms = big.take<T>(cap);                           // scores (thresholds) -- not loaded when the window cache replaces them
     T* x = (HV && !S.ws) ? big.take<T>(cap) : ms;       // sweep values b; they share the array unless both are needed
+    T* stg = big.take<T>(cap);                          // CSR-order staging (see vsweep_block_body)
     double* Sx = big.take<double>(cap + 1);
     int* rs = big.take<int>(rs_cap);
     const int u = users[ui];
@@ -918,7 +940,9 @@ __device__ __forceinline__ void vsweep_wave_body(char* smem, const Shard<T>& S, 
     for (int l = lane; l <= nlev; l += 64) rs[l] = S.runstart[S.runofs[u] + l];
     const T* xs = ms;
     if (HV) {
-        for (int p = lane; p < n; p += 64) x[p] = bsrc[s0 + p];
+        for (int q = lane; q < n; q += 64) stg[q] = bsrc[s0 + q];
+        wave_sync();
+        for (int p = lane; p < n; p += 64) x[p] = stg[S.sidx[s0 + p]];
         xs = x;
     }
     wave_sync();
@@ -937,17 +961,20 @@ __device__ __forceinline__ void vsweep_wave_body(char* smem, const Shard<T>& S, 
         const double c = S.ws
             ? sweep_coeff_win(S.win + (size_t)(s0 + p) * S.ws, Sx, rs, nlev, lev, (double)xs[p], HV ? 0.0 : 1.0)
             : sweep_coeff<T>(ms, Sx, rs, nlev, lev, ms[p], (double)xs[p], HV ? 0.0 : 1.0, strict);
-        c_out[s0 + p] = (T)c;
+        stg[S.sidx[s0 + p]] = (T)c;
     }
+    wave_sync();
+    for (int q = lane; q < n; q += 64) c_out[s0 + q] = stg[q];
 }
 template <typename T, bool HV>
 __global__ __launch_bounds__(256) void k_vsweep_wave(Shard<T> S, const int32_t* __restrict__ users, int nusers,
                                                      const T* __restrict__ bsrc, T* __restrict__ c_out,
-                                                     int cap, int rs_cap, size_t wave_bytes, int strict, const int* skip) {
+                                                     int cap, int rs_cap, size_t wave_bytes, int strict, const int* skip,
+                                                     const uint8_t* __restrict__ only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (skip && *skip) return;
     vsweep_wave_body<T, HV>(smem, S, users, nusers, bsrc, c_out, cap, rs_cap, wave_bytes, strict,
-                            (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+                            (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), only);
 }
 
 // Both LDS-resident classes in ONE launch of 512-thread workgroups (the two sweeps are each shorter than a launch
@@ -957,15 +984,16 @@ template <typename T, bool HV>
 __global__ __launch_bounds__(512) void k_vsweep_all(Shard<T> S, const int32_t* __restrict__ users_a, int nusers_a, int cap_a,
                                                     int rs_cap_a, size_t wave_bytes, const int32_t* __restrict__ users_b,
                                                     int nusers_b, int cap_b, int rs_cap_b, int nblk_b,
-                                                    const T* __restrict__ bsrc, T* __restrict__ c_out, int strict, const int* skip) {
+                                                    const T* __restrict__ bsrc, T* __restrict__ c_out, int strict, const int* skip,
+                                                    const uint8_t* __restrict__ only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (skip && *skip) return;
     if ((int)blockIdx.x < nblk_b)
         vsweep_block_body<T, 512, false, HV>(smem, S, users_b, nusers_b, bsrc, c_out, cap_b, rs_cap_b, nullptr, 0, strict,
-                                             (int)blockIdx.x, nblk_b);
+                                             (int)blockIdx.x, nblk_b, only);
     else
         vsweep_wave_body<T, HV>(smem, S, users_a, nusers_a, bsrc, c_out, cap_a, rs_cap_a, wave_bytes, strict,
-                                ((int)blockIdx.x - nblk_b) * 8 + (int)(threadIdx.x >> 6));
+                                ((int)blockIdx.x - nblk_b) * 8 + (int)(threadIdx.x >> 6), only);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -976,7 +1004,7 @@ __global__ __launch_bounds__(512) void k_vsweep_all(Shard<T> S, const int32_t* _
 // fp64 registers and stores ONE partial row per (chunk, item) incidence with plain coalesced
 // stores into a slab whose slot numbering is static (slots of one item are consecutive).
 // k_spmm_fin then sums each item's slots in a fixed order -> bitwise reproducible.
-// c is read through cinv (CSC entry -> sorted position), so the sweeps write it coalesced.
+// c (CSR order) is read through c2r, the STATIC CSC entry -> CSR position map of the shard.
 // XCD-aware tiling: the CSC is built per USER TILE (a contiguous user range whose rows of U, and whose slice of c, fit
 // one XCD's 4 MB L2), tile-major, and workgroup b works on a tile t with t % 8 == b % 8 (workgroups go to the XCDs
 // round-robin), so the random row gather of a tile is served by ONE L2 instead of every L2 holding a copy of all of U
@@ -984,11 +1012,12 @@ __global__ __launch_bounds__(512) void k_vsweep_all(Shard<T> S, const int32_t* _
 // (slot_id maps the (chunk, item) incidences, enumerated in chunk order, to item-major slab rows).
 // ---------------------------------------------------------------------------------------
 template <typename T, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const int32_t* __restrict__ cinv,
+__global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const int32_t* __restrict__ c2r,
                                                 const int32_t* __restrict__ cuf,
                                                 const int32_t* __restrict__ chunk_ptr, const int32_t* __restrict__ inc_base,
                                                 const int32_t* __restrict__ slot_id, const int2* __restrict__ blk_chunks,
-                                                const T* __restrict__ U, T* __restrict__ slab, Geo geo, const int* skip) {
+                                                const T* __restrict__ U, T* __restrict__ slab, Geo geo, const int* skip,
+                                                const uint8_t* __restrict__ only = nullptr, const int32_t* __restrict__ inc_row = nullptr) {
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     if (skip && *skip) return;
@@ -997,6 +1026,12 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const i
     if ((int)threadIdx.x / G >= bc.y) return;
     const int gid = bc.x + (int)threadIdx.x / G;
     const int64_t z0 = chunk_ptr[gid], z1 = chunk_ptr[gid + 1];
+    if (only) {     // lock-step U step (output rows = users): a chunk none of whose users still takes part is skipped
+        int any = 0;
+        for (int i = inc_base[gid] + g; i < inc_base[gid + 1]; i += G) any |= (int)only[inc_row[i]];
+        for (int off = G >> 1; off > 0; off >>= 1) any |= __shfl_xor(any, off);
+        if (!any) return;
+    }
     for (int k = 0; k * G < geo.nchunk; ++k) {
         const int ch = g + k * G;
         const bool act = ch < geo.nchunk;
@@ -1021,7 +1056,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const i
             const int64_t zi = zb + g;
             T cr = (T)0;
             int ur = 0;
-            if (zi < z1) { cr = c[cinv[zi]]; ur = cuf[zi]; }            // user id; sign bit: a new item starts here (not at the chunk start)
+            if (zi < z1) { cr = c2r ? c[c2r[zi]] : c[zi]; ur = cuf[zi]; }            // user id; sign bit: a new item starts here (not at the chunk start)
             const int cnt = (int)((z1 - zb < G) ? (z1 - zb) : G);
             for (int q = 0; q < cnt; q += PCR_UNR) {
                 V rv[PCR_UNR];
@@ -1599,11 +1634,11 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         __syncthreads();
         // ---- The scores of the last line-search try ARE m = V_I u_new, sorted: leave them as the shard's sorted state
         // (what k_prepare would rebuild from (U_new, V) at the start of the next V step: scores, items, levels, the
-        // CSC <-> sorted maps, the window cache and the loss), so that update_V needs no SDDMM + sort of its own.
+        // sorted -> CSR map, the window cache and the loss), so that update_V needs no SDDMM + sort of its own.
         // A skipped user (:787-790) keeps u, so its state stays valid as it is.
         if (!skip && mem == 0) {
             int32_t* stage = reinterpret_cast<int32_t*>(Sx);                  // Sx is free again: (cap + 1) doubles >= n ints
-            for (int p = tid; p < n; p += BLOCK) stage[p] = S.scpos[s0 + LiOps<LI>::idx(li[p])];
+            for (int p = tid; p < n; p += BLOCK) stage[p] = S.sidx[s0 + LiOps<LI>::idx(li[p])];
             __syncthreads();                                                  // all of the old map is read before any of it is rewritten
             uint32_t* wout = S.ws ? S.win + (size_t)s0 * S.ws : nullptr;
             for (int p = tid; p < n; p += BLOCK) {
@@ -1612,9 +1647,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                 S.ms[s0 + p] = key[p];
                 S.slvl[s0 + p] = (uint16_t)lev;
                 S.sitem[s0 + p] = itm[LiOps<LI>::idx(x)];
-                const int32_t e = stage[p];
-                S.scpos[s0 + p] = e;
-                S.cinv[e] = (int32_t)(s0 + p);
+                S.sidx[s0 + p] = stage[p];
                 if (wout) find_windows<T>(key, rs, nlev, lev, key[p], strict, wout + (size_t)p * S.ws);
             }
         }
@@ -1624,6 +1657,9 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
             if (!skip) S.objp[u] = loss_new;
             if (n_cg) atomicAdd(counters + 0, (unsigned long long)n_cg);
             if (n_ls) atomicAdd(counters + 1, (unsigned long long)n_ls);
+            // rows of V this user's step gathered: gradient + 2 per CG iteration + 1 per line-search try (diagnostic: the
+            // U step's achieved gather rate in bench.py)
+            atomicAdd(counters + 2, (unsigned long long)n * (unsigned long long)(1 + 2 * n_cg + n_ls));
         }
         __syncthreads();
         UPROF(10);
@@ -1636,6 +1672,245 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         atomicAdd(counters + 4 + cls * 16 + 12, 1ull);
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------
+// Lock-step U step (large shards): update_U_new (pcrpp.cpp:818-838) as RATING-PARALLEL passes over all users at once
+// instead of one workgroup per user.  Users are independent given V, so their Newton steps can advance together:
+//     gradient    k_vsweep<GRAD> -> k_spmm over the CSR (rows of V gathered, one partial row per (chunk, user)) -> k_ufin_grad
+//     CG, k = 1.. k_sddmm(P, V) -> k_vsweep<HV> -> k_spmm -> k_ufin_cg     (users whose residual has met the tolerance drop
+//                 out: lane groups / chunks / workgroups holding only finished users return at once)
+//     line search k_uls_apply -> k_sddmm(U_new, V) -> k_prepare (sort, windows, loss) -> k_uls_decide, repeated for the users
+//                 that found no decrease (pcrpp.cpp:794-813)
+// The gathers then run at the rate of k_sddmm / k_spmm (perfectly balanced, 13-15 TB/s out of the L2s) instead of the
+// 2.3x lower rate of the per-user teams of k_ustep, which stay the choice for small shards (one launch, no 10 x 4 kernel
+// latencies).  Arithmetic per user is that of k_ustep: r-vectors in fp64, the same alpha / beta / stop formulas
+// (pcrpp.cpp:628-647), the same skip rules (:787-790, pcr.cpp:552), the last tried u returned (:794-814).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct ULock {
+    double *D, *RR, *P, *HP;        // nu x ld: delta, residual, direction, H p (fp64, as the LDS r-vectors of k_ustep)
+    T *PT, *Unew;                   // nu x ld: the direction rounded to T (what the SDDMM multiplies), the tried u
+    double *prev_obj, *err, *nn, *step;     // per user
+    uint8_t *active, *ls;           // CG still running / line search still running
+    int* tries;
+    int* nact;                      // [0] users with a running CG, [1] users in the line search, [2] "CG all done" flag
+};
+
+template <typename X>
+__device__ __forceinline__ X group_sum(X v, int G) {
+    for (int off = G >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// sum of the slab rows [s0, s1) of one chunk column, added to acc[] (fp64), eight loads in flight
+template <typename T>
+__device__ __forceinline__ void slab_sum(const T* __restrict__ slab, int s0, int s1, int ch, const Geo& geo, double* acc) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VEC = VecOf<T>::N;
+    for (int sl = s0; sl < s1; sl += 8) {
+        V pv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (sl + q < s1) pv[q] = *reinterpret_cast<const V*>(slab + row_off(sl + q, geo) + ch * VEC);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (sl + q < s1) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] += (double)velem(pv[q], e);
+            }
+    }
+}
+
+// g_u = lambda u + sum_j c_j v_j (obtain_g_u_new, pcrpp.cpp:493-539; zeros for a user without ratings, :496-498), the skip
+// rules, prev_obj (pcrpp.cpp:786), and the CG start (:629-631): delta = 0, rr = -g, p = g.  G lanes per user.
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_ufin_grad(const T* __restrict__ slab, const int32_t* __restrict__ uslot,
+                                                     const T* __restrict__ U, const int64_t* __restrict__ uptr,
+                                                     const int64_t* __restrict__ runofs, const double* __restrict__ objp,
+                                                     double* __restrict__ objr, double lambda, double stepsize0, double cg_tol,
+                                                     int solver1, int nu, Geo geo, ULock<T> L) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VEC = VecOf<T>::N;
+    __shared__ int cnt_s;
+    if (threadIdx.x == 0) cnt_s = 0;
+    __syncthreads();
+    const int G = geo.G, g = threadIdx.x & (G - 1), ipb = BLOCK / G;
+    int mine = 0;
+    for (int u = (int)blockIdx.x * ipb + (int)threadIdx.x / G; u < nu; u += (int)gridDim.x * ipb) {
+        const int s0 = uslot[u], s1 = uslot[u + 1];
+        const bool empty = uptr[u + 1] == uptr[u];
+        double un2 = 0.0, gn2 = 0.0;
+        for (int ch = g; ch < geo.nchunk; ch += G) {
+            const size_t o = row_off(u, geo) + (size_t)ch * VEC;
+            const V uv = *reinterpret_cast<const V*>(U + o);
+            double acc[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = empty ? 0.0 : (double)velem(uv, e) * lambda;
+            slab_sum<T>(slab, s0, s1, ch, geo, acc);
+            V pt;
+            T* ptp = reinterpret_cast<T*>(&pt);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const double ue = (double)velem(uv, e);
+                un2 += ue * ue; gn2 += acc[e] * acc[e];
+                L.D[o + e] = 0.0; L.RR[o + e] = acc[e] * -1.0; L.P[o + e] = acc[e];
+                ptp[e] = (T)acc[e];
+            }
+            *reinterpret_cast<V*>(L.PT + o) = pt;
+        }
+        un2 = group_sum(un2, G); gn2 = group_sum(gn2, G);
+        if (g == 0) {
+            const double prev = lambda / 2.0 * un2 + objp[u];
+            const int nlev = (int)(runofs[u + 1] - runofs[u]) - 1;
+            const bool skip = (gn2 < 0.0001) || (solver1 && nlev <= 1);          // pcrpp.cpp:787-790; pcr.cpp:552
+            L.prev_obj[u] = prev; L.err[u] = sqrt(gn2) * cg_tol; L.step[u] = stepsize0; L.tries[u] = 0;
+            L.active[u] = skip ? 0 : 1; L.ls[u] = skip ? 0 : 1;
+            objr[u] = prev;                                                      // a skipped user keeps u_i and its objective
+            mine += skip ? 0 : 1;
+        }
+    }
+    if (mine) atomicAdd(&cnt_s, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && cnt_s) { atomicAdd(L.nact, cnt_s); atomicAdd(L.nact + 1, cnt_s); }
+}
+
+// one CG iteration of every user still running (solve_delta_u_new, pcrpp.cpp:636-645): H p = lambda p + sum_j c_j v_j from the
+// slab, alpha = -(rr.p)/(p.Hp), delta += alpha p, rr += alpha Hp, stop if |rr| < err, else beta = (rr.Hp)/(p.Hp), p = -rr + beta p
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_ufin_cg(const T* __restrict__ slab, const int32_t* __restrict__ uslot, double lambda,
+                                                   int nu, Geo geo, ULock<T> L, unsigned long long* __restrict__ counters) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VEC = VecOf<T>::N;
+    __shared__ int cnt_s[2];
+    if (L.nact[2]) return;
+    if (threadIdx.x < 2) cnt_s[threadIdx.x] = 0;
+    __syncthreads();
+    const int G = geo.G, g = threadIdx.x & (G - 1), ipb = BLOCK / G;
+    int ran = 0, done = 0;
+    for (int u = (int)blockIdx.x * ipb + (int)threadIdx.x / G; u < nu; u += (int)gridDim.x * ipb) {
+        if (!L.active[u]) continue;                                   // (uniform inside a lane group)
+        const int s0 = uslot[u], s1 = uslot[u + 1];
+        double a = 0.0, b = 0.0;
+        for (int ch = g; ch < geo.nchunk; ch += G) {
+            const size_t o = row_off(u, geo) + (size_t)ch * VEC;
+            double hp[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) hp[e] = L.P[o + e] * lambda;
+            slab_sum<T>(slab, s0, s1, ch, geo, hp);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { L.HP[o + e] = hp[e]; a += L.P[o + e] * hp[e]; b += L.RR[o + e] * L.P[o + e]; }
+        }
+        const double pHp = group_sum(a, G), rp = group_sum(b, G);
+        const double alpha = -1.0 * rp / pHp;
+        a = 0.0; b = 0.0;
+        for (int ch = g; ch < geo.nchunk; ch += G) {
+            const size_t o = row_off(u, geo) + (size_t)ch * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const double hv = L.HP[o + e];                         // (this lane's own stores: program order)
+                L.D[o + e] = L.D[o + e] + L.P[o + e] * alpha;
+                const double rn = L.RR[o + e] + hv * alpha;
+                L.RR[o + e] = rn;
+                a += rn * rn; b += rn * hv;
+            }
+        }
+        const double rr2 = group_sum(a, G), rHp = group_sum(b, G);
+        ran += (g == 0);
+        if (sqrt(rr2) < L.err[u]) {
+            if (g == 0) { L.active[u] = 0; done += 1; }
+            continue;
+        }
+        const double beta = rHp / pHp;
+        for (int ch = g; ch < geo.nchunk; ch += G) {
+            const size_t o = row_off(u, geo) + (size_t)ch * VEC;
+            V pt;
+            T* ptp = reinterpret_cast<T*>(&pt);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const double pn = L.RR[o + e] * -1.0 + L.P[o + e] * beta;
+                L.P[o + e] = pn;
+                ptp[e] = (T)pn;
+            }
+            *reinterpret_cast<V*>(L.PT + o) = pt;
+        }
+    }
+    if (ran) atomicAdd(&cnt_s[0], ran);
+    if (done) atomicAdd(&cnt_s[1], done);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (cnt_s[0]) atomicAdd(counters + 0, (unsigned long long)cnt_s[0]);
+        if (cnt_s[1]) atomicSub(L.nact, cnt_s[1]);
+    }
+}
+// after an iteration: nobody left -> the remaining (already queued) kernels of the solve return at once
+__global__ void k_ucg_check(int* nact) { if (threadIdx.x == 0 && nact[0] <= 0) nact[2] = 1; }
+
+// line search, one try of every user still searching: u_new = u - step * delta (pcrpp.cpp:795-797), rounded to T as it will be
+// stored; nn = |u_new|^2
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_uls_apply(const T* __restrict__ U, int nu, Geo geo, ULock<T> L) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VEC = VecOf<T>::N;
+    const int G = geo.G, g = threadIdx.x & (G - 1), ipb = BLOCK / G;
+    for (int u = (int)blockIdx.x * ipb + (int)threadIdx.x / G; u < nu; u += (int)gridDim.x * ipb) {
+        if (!L.ls[u]) continue;
+        const double step = L.step[u];
+        double nn = 0.0;
+        for (int ch = g; ch < geo.nchunk; ch += G) {
+            const size_t o = row_off(u, geo) + (size_t)ch * VEC;
+            const V uv = *reinterpret_cast<const V*>(U + o);
+            V nv;
+            T* np = reinterpret_cast<T*>(&nv);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const double v = (double)velem(uv, e) + L.D[o + e] * -step;
+                np[e] = (T)v;
+                nn += (double)np[e] * (double)np[e];
+            }
+            *reinterpret_cast<V*>(L.Unew + o) = nv;
+        }
+        nn = group_sum(nn, G);
+        if (g == 0) L.nn[u] = nn;
+    }
+}
+// ... and its verdict (pcrpp.cpp:806-812): accept on a strict decrease, else halve the step, at most 20 tries; the LAST tried
+// u_new is what the user gets either way (:813), with its objective
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_uls_decide(T* __restrict__ U, const double* __restrict__ objp, double* __restrict__ objr,
+                                                      double lambda, int nu, Geo geo, ULock<T> L,
+                                                      unsigned long long* __restrict__ counters) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VEC = VecOf<T>::N;
+    __shared__ int cnt_s[2];
+    if (threadIdx.x < 2) cnt_s[threadIdx.x] = 0;
+    __syncthreads();
+    const int G = geo.G, g = threadIdx.x & (G - 1), ipb = BLOCK / G;
+    int tried = 0, fin = 0;
+    for (int u = (int)blockIdx.x * ipb + (int)threadIdx.x / G; u < nu; u += (int)gridDim.x * ipb) {
+        if (!L.ls[u]) continue;
+        const double obj_new = lambda / 2.0 * L.nn[u] + objp[u];
+        const int tries = L.tries[u] + 1;
+        const bool stop = (obj_new < L.prev_obj[u]) || tries >= 20;
+        if (stop) {
+            for (int ch = g; ch < geo.nchunk; ch += G) {
+                const size_t o = row_off(u, geo) + (size_t)ch * VEC;
+                *reinterpret_cast<V*>(U + o) = *reinterpret_cast<const V*>(L.Unew + o);
+            }
+        }
+        if (g == 0) {
+            tried += 1;
+            L.tries[u] = tries;
+            if (stop) { objr[u] = obj_new; L.ls[u] = 0; fin += 1; } else L.step[u] = L.step[u] / 2.0;
+        }
+    }
+    if (tried) atomicAdd(&cnt_s[0], tried);
+    if (fin) atomicAdd(&cnt_s[1], fin);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (cnt_s[0]) atomicAdd(counters + 1, (unsigned long long)cnt_s[0]);
+        if (cnt_s[1]) atomicSub(L.nact + 1, cnt_s[1]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1884,7 +2159,7 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_fin4(const double* __restrict_
         if (threadIdx.x == 0) out[c] = (c == 1 && !keep1) ? 0.0 : x;
     }
     if (cnt) {
-        if (threadIdx.x == 0) { cnt_out[0] = (double)cnt[0]; cnt_out[1] = (double)cnt[1]; cnt_out[2] = (double)cnt[3]; cnt_out[3] = 0.0; }
+        if (threadIdx.x == 0) { cnt_out[0] = (double)cnt[0]; cnt_out[1] = (double)cnt[1]; cnt_out[2] = (double)cnt[3]; cnt_out[3] = (double)cnt[2]; }
         __syncthreads();
         for (int i = threadIdx.x; i < nzero; i += PCR_EW_BLOCK) cnt[i] = 0ull;
     }

@@ -122,6 +122,7 @@ struct pcr_solver {
     virtual int comm_nranks() = 0;
     virtual int sync() = 0;
     int64_t first_user = 0, n_users = 0, nnz_local = 0;
+    double ustep_rows = 0.0;      // rows of V gathered by all U steps so far (all ranks); pcr_solver_counter("ustep_row_gathers")
     bool prof_on = false;
     bool local_only = false;      // nranks > 1 without a communicator: entry points return this shard's partials
     int prof_period = 1;          // time every prof_period-th launch of each slot
@@ -134,7 +135,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = 1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
-        fault_cluster_member = 0;
+        fault_cluster_member = 0, ustep_lockstep = -1;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -143,6 +144,7 @@ struct Tune {
         cluster_users = pcr_tune_int("cluster_users", 0); window_cache = pcr_tune_int("window_cache", 1);
         prepare_merged = pcr_tune_int("prepare_merged", 1); ustep_seq = pcr_tune_int("ustep_seq", 0); eval_brute = pcr_tune_int("eval_brute", 0);
         pipeline = pcr_tune_int("pipeline", 1); debug = pcr_tune_int("debug", 0); fault_cluster_member = pcr_tune_int("fault_cluster_member", 0);
+        ustep_lockstep = pcr_tune_int("ustep_lockstep", -1);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -176,9 +178,9 @@ struct Solver final : pcr_solver {
     // ---- training shard
     Shard<T> sh;
     DBuf<int64_t> d_uptr, d_runofs;
-    DBuf<int32_t> d_scpos;
+    DBuf<int32_t> d_sidx;
     DBuf<double> d_objr;
-    DBuf<int32_t> d_item, d_cpos, d_runstart, d_sitem, d_cinv, d_cuser, d_crow, d_ruser, d_slot_base, d_item_slot, d_chunk_ptr, d_slot_id;
+    DBuf<int32_t> d_item, d_c2r, d_runstart, d_sitem, d_cuser, d_crow, d_ruser, d_slot_base, d_item_slot, d_chunk_ptr, d_slot_id;
     DBuf<int2> d_blk_chunks;                      // k_spmm: first chunk and chunk count of every workgroup
     DBuf<int32_t> d_cuf;                          // k_spmm: user id | new-item flag per CSC entry
     int spmm_blocks = 0, spmm_tiles = 1;
@@ -199,6 +201,17 @@ struct Solver final : pcr_solver {
     DBuf<char> d_xch;
     size_t xch_stride = 0;
     int max_clusters = 1;
+    // ---- lock-step U step (pcr_kernels.h, "Lock-step U step"): user-major slab SpMM over the CSR + per-user CG state
+    bool lockstep = false;
+    DBuf<int32_t> du_cuf, du_chunk_ptr, du_inc_base, du_slot_id, du_inc_row, du_uslot;
+    DBuf<int2> du_blk_chunks;
+    int u_spmm_blocks = 0;
+    DBuf<T> du_slab, du_PT, du_Unew;
+    DBuf<double> du_D, du_RR, du_P, du_HP, du_prev, du_err, du_nn, du_step;
+    DBuf<uint8_t> du_active, du_ls;
+    DBuf<int> du_tries, du_nact;
+    int* h_nact = nullptr;                                        // pinned
+    ULock<T> ul;
     // ---- eval data (0 = train, 1 = test)
     struct EvalSet {
         int64_t nnz = 0;
@@ -264,6 +277,7 @@ struct Solver final : pcr_solver {
         if (h_scal) (void)hipHostFree(h_scal);
         if (h_uobj) (void)hipHostFree(h_uobj);
         if (h_counters) (void)hipHostFree(h_counters);
+        if (h_nact) (void)hipHostFree(h_nact);
         for (int i = 0; i < NSIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (int i = 0; i < MAXLANE; ++i) if (ev_lane[i]) (void)hipEventDestroy(ev_lane[i]);
@@ -554,8 +568,8 @@ struct Solver final : pcr_solver {
             for (int c : {256, 320, 384, 448, 512}) {
                 const int64_t n_wave = std::upper_bound(lens.begin(), lens.end(), (int64_t)c) - lens.begin();
                 const int64_t n_blk = std::max<int64_t>(0, max_lds - n_wave);
-                const size_t wave_lds = 8 * ((size_t)c * sizeof(T) + (size_t)(c + 1) * 8 + 64);
-                const size_t blk_lds = n_blk > 0 ? (size_t)cap_b * sizeof(T) + (size_t)(cap_b + 1) * 8 + 1024 : 0;
+                const size_t wave_lds = 8 * ((size_t)c * 2 * sizeof(T) + (size_t)(c + 1) * 8 + 64);
+                const size_t blk_lds = n_blk > 0 ? (size_t)cap_b * 2 * sizeof(T) + (size_t)(cap_b + 1) * 8 + 1024 : 0;
                 const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, ((size_t)160 << 10) / std::max<size_t>(1, std::max(wave_lds, blk_lds))));
                 const double rounds = (double)(cdiv(n_wave, 8) + n_blk) / ((double)ncu * per_cu);
                 const double cost = std::max(rounds, 1.0) * (1.0 + c / 1024.0);
@@ -687,16 +701,21 @@ struct Solver final : pcr_solver {
         }
 
         RC(d_uptr.upload(uptr, st)); RC(d_item.upload(item, st)); RC(d_lvl.upload(lv.level, st));
-        RC(d_cpos.upload(cpos, st)); RC(d_cuser.upload(cuser, st)); RC(d_crow.upload(crow, st)); RC(d_ruser.upload(ruser, st));
+        {   // static CSC entry -> CSR position map (the inverse of cpos)
+            std::vector<int32_t> c2r(nnz_local);
+            for (int64_t z = 0; z < nnz_local; ++z) c2r[cpos[z]] = (int32_t)z;
+            RC(d_c2r.upload(c2r, st));
+        }
+        RC(d_cuser.upload(cuser, st)); RC(d_crow.upload(crow, st)); RC(d_ruser.upload(ruser, st));
         RC(d_runofs.upload(lv.run_ofs, st)); RC(d_runstart.upload(lv.run_start, st));
-        RC(d_ms.alloc(nnz_local)); RC(d_sitem.alloc(nnz_local)); RC(d_slvl.alloc(nnz_local)); RC(d_cinv.alloc(nnz_local));
+        RC(d_ms.alloc(nnz_local)); RC(d_sitem.alloc(nnz_local)); RC(d_slvl.alloc(nnz_local));
         RC(d_c.alloc(nnz_local)); RC(d_objp.alloc(nu)); RC(d_mcsr.alloc(nnz_local)); RC(d_b.alloc(nnz_local));
         sh.nu = nu; sh.nnz = nnz_local; sh.d2 = (int)d2;
-        sh.uptr = d_uptr.p; sh.item = d_item.p; sh.lvl = d_lvl.p; sh.cpos = d_cpos.p;
+        sh.uptr = d_uptr.p; sh.item = d_item.p; sh.lvl = d_lvl.p;
         sh.runofs = d_runofs.p; sh.runstart = d_runstart.p;
-        sh.ms = d_ms.p; sh.sitem = d_sitem.p; sh.slvl = d_slvl.p; sh.cinv = d_cinv.p; sh.objp = d_objp.p;
-        RC(d_scpos.alloc(nnz_local)); RC(d_objr.alloc(nu));
-        sh.scpos = d_scpos.p; sh.objr = d_objr.p;
+        sh.ms = d_ms.p; sh.sitem = d_sitem.p; sh.slvl = d_slvl.p; sh.objp = d_objp.p;
+        RC(d_sidx.alloc(nnz_local)); RC(d_objr.alloc(nu));
+        sh.sidx = d_sidx.p; sh.objr = d_objr.p;
         // window cache (pcr_kernels.h, Shard::win): one slot per other level, up to 9 levels
         sh.ws = (lv.max_levels >= 2 && lv.max_levels <= 9) ? lv.max_levels - 1 : 0;
         if (!tune.window_cache) sh.ws = 0;
@@ -773,6 +792,45 @@ struct Solver final : pcr_solver {
             scratch_blocks = std::max((int)std::min<size_t>(std::max<size_t>(nbig, 1), (size_t)ncu * 2), u_big_blocks);
             RC(d_scratch.alloc(scratch_stride * (size_t)scratch_blocks));
         }
+        // Lock-step U step: built and measured -- on every shape tried the per-user k_ustep stays ahead (full
+        // Netflix shape: U step 52 ms per-user, 63 ms lock-step; the long users, which hold most ratings, are also the ones
+        // whose CG runs longest, so few ratings ever drop out, and b / c / the r-vectors now cross global memory).  It stays
+        // available behind pcr_tune("ustep_lockstep", "1") and is held to the same parity tests.
+        lockstep = tune.ustep_lockstep > 0;
+        if (lockstep && nnz_local > 0) {
+            const int chunk = 128, gpb = 256 / geo.G;
+            std::vector<int32_t> chunk_ptr, cuf(item), inc_base, inc_row, uslot(nu + 1, 0);
+            for (int64_t a = 0; a < nnz_local; a += chunk) chunk_ptr.push_back((int32_t)a);
+            const int64_t nchunks = (int64_t)chunk_ptr.size();
+            chunk_ptr.push_back((int32_t)nnz_local);
+            for (int64_t c = 0; c < nchunks; ++c) {
+                inc_base.push_back((int32_t)inc_row.size());
+                for (int64_t z = chunk_ptr[c]; z < chunk_ptr[c + 1]; ++z) {
+                    if (z == chunk_ptr[c] || ruser[z] != ruser[z - 1]) inc_row.push_back(ruser[z]);
+                    if (z != chunk_ptr[c] && ruser[z] != ruser[z - 1]) cuf[z] |= (int32_t)0x80000000;      // "a new user starts here"
+                }
+            }
+            inc_base.push_back((int32_t)inc_row.size());
+            for (int32_t u : inc_row) uslot[u + 1]++;                  // incidences enumerated in CSR order are user-major already
+            for (int64_t u = 0; u < nu; ++u) uslot[u + 1] += uslot[u];
+            std::vector<int32_t> slot_id(inc_row.size());
+            for (size_t i = 0; i < slot_id.size(); ++i) slot_id[i] = (int32_t)i;
+            std::vector<int2> blk;
+            for (int64_t c = 0; c < nchunks; c += gpb) blk.push_back(make_int2((int)c, (int)std::min<int64_t>(gpb, nchunks - c)));
+            u_spmm_blocks = (int)blk.size();
+            RC(du_cuf.upload(cuf, st)); RC(du_chunk_ptr.upload(chunk_ptr, st)); RC(du_inc_base.upload(inc_base, st));
+            RC(du_slot_id.upload(slot_id, st)); RC(du_inc_row.upload(inc_row, st)); RC(du_uslot.upload(uslot, st));
+            RC(du_blk_chunks.upload(blk, st));
+            RC(du_slab.alloc(std::max<size_t>(inc_row.size(), 1) * geo.ld));
+            const size_t nUl = (size_t)nu * geo.ld;
+            RC(du_PT.alloc(nUl)); RC(du_Unew.alloc(nUl)); RC(du_D.alloc(nUl)); RC(du_RR.alloc(nUl)); RC(du_P.alloc(nUl)); RC(du_HP.alloc(nUl));
+            RC(du_prev.alloc(nu)); RC(du_err.alloc(nu)); RC(du_nn.alloc(nu)); RC(du_step.alloc(nu));
+            RC(du_active.alloc(nu)); RC(du_ls.alloc(nu)); RC(du_tries.alloc(nu)); RC(du_nact.alloc(4));
+            HIPCHK(hipHostMalloc((void**)&h_nact, 4 * sizeof(int)));
+            ul.D = du_D.p; ul.RR = du_RR.p; ul.P = du_P.p; ul.HP = du_HP.p; ul.PT = du_PT.p; ul.Unew = du_Unew.p;
+            ul.prev_obj = du_prev.p; ul.err = du_err.p; ul.nn = du_nn.p; ul.step = du_step.p;
+            ul.active = du_active.p; ul.ls = du_ls.p; ul.tries = du_tries.p; ul.nact = du_nact.p;
+        } else lockstep = false;
         RC(set_lds_limits());
         HIPCHK(hipStreamSynchronize(st));
         RC(pick_lanes());
@@ -908,9 +966,11 @@ struct Solver final : pcr_solver {
     // ------------------------------------------------------------------------------ launches
     // m = V_I u, sort, per-user loss -> objp.  Vm = matrix the scores are taken against.
     // out[z] = U[user(z)] . M[rows[z]] for all local ratings (rating-parallel, balanced)
-    int launch_sddmm(const T* M, const int32_t* rows, T* out, const int* skip = nullptr) {
+    int launch_sddmm(const T* M, const int32_t* rows, T* out, const int* skip = nullptr, const T* Umat = nullptr,
+                     const uint8_t* only = nullptr, const char* slot = "sddmm") {
         if (nnz_local == 0) return PCR_OK;
-        ProfScope ps(this, "sddmm");
+        ProfScope ps(this, slot);
+        if (!Umat) Umat = d_U.p;
         // tile = consecutive ratings one lane group walks.  64 by default; a shard that needs between one and two rounds of
         // workgroups at 64 gets the smallest tile (a multiple of the 8-row batch) with which ONE round holds it all
         // (ml1m: 96 -- 1224 workgroups on 1280 slots instead of 1836; 1.66 -> 1.64 ms per iteration; 80: 1.68, 128: 1.67)
@@ -927,8 +987,8 @@ struct Solver final : pcr_solver {
         const int tile = sddmm_tile;
         const int ngrp = 256 / geo.G, span = ngrp * tile;
         const int grid = cdiv(nnz_local, span);
-        hipLaunchKernelGGL((k_sddmm<T, 256>), dim3(grid), dim3(256), (size_t)span * 8, st, d_U.p, M, d_ruser.p, rows, nnz_local, out, geo, tile, skip,
-                           (const int32_t*)nullptr, (const int2*)nullptr, (const int32_t*)nullptr);
+        hipLaunchKernelGGL((k_sddmm<T, 256>), dim3(grid), dim3(256), (size_t)span * 8, st, Umat, M, d_ruser.p, rows, nnz_local, out, geo, tile, skip,
+                           (const int32_t*)nullptr, (const int2*)nullptr, (const int32_t*)nullptr, only);
         HIPCHK(hipGetLastError());
         return PCR_OK;
     }
@@ -940,7 +1000,7 @@ struct Solver final : pcr_solver {
         ProfScope ps(this, "sddmm");
         const int span = (256 / geo.G) * spmm_chunk;
         hipLaunchKernelGGL((k_sddmm<T, 256>), dim3(spmm_blocks), dim3(256), (size_t)span * 8, st, A, d_U.p, d_crow.p, d_cuser.p, nnz_local, out, geo,
-                           spmm_chunk, skip, d_cinv.p, d_blk_chunks.p, d_chunk_ptr.p);
+                           spmm_chunk, skip, d_c2r.p, d_blk_chunks.p, d_chunk_ptr.p, (const uint8_t*)nullptr);
         HIPCHK(hipGetLastError());
         return PCR_OK;
     }
@@ -948,15 +1008,15 @@ struct Solver final : pcr_solver {
     bool prepare_is_single_launch() const {
         return tune.prepare_merged && !pbins[0].users.empty() && !pbins[1].users.empty();
     }
-    int launch_prepare(const T* Vm) {
-        RC(launch_sddmm(Vm, d_item.p, d_mcsr.p));
+    int launch_prepare(const T* Vm, const T* Umat = nullptr, const uint8_t* only = nullptr) {
+        RC(launch_sddmm(Vm, d_item.p, d_mcsr.p, nullptr, Umat, only, only ? "u:sddmm" : "sddmm"));
         auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
             const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
             const size_t bigb = prepare_bytes<T>(b.cap, cap_pad, rsc, b.big ? 8 : 4);
             const size_t lds = small_common(b.block) + (b.big ? 0 : bigb);
             const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
-#define LP(BL, BG) hipLaunchKernelGGL((k_prepare<T, BL, BG>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_mcsr.p, b.cap, cap_pad, rsc, d_scratch.p, scratch_stride, strict())
+#define LP(BL, BG) hipLaunchKernelGGL((k_prepare<T, BL, BG>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_mcsr.p, b.cap, cap_pad, rsc, d_scratch.p, scratch_stride, strict(), only)
             if (b.big) LP(512, true);
             else if (b.block == 64) LP(64, false);
             else if (b.block == 256) LP(256, false);
@@ -972,9 +1032,9 @@ struct Solver final : pcr_solver {
             const size_t wb = (small_common(64) + prepare_bytes<T>(ba.cap, cpa, rsa, 4) + 15) & ~(size_t)15;
             const size_t lds = std::max(wb * 8, small_common(512) + prepare_bytes<T>(bb.cap, cpb, rsb, 4));
             {
-                ProfScope ps(this, "prepare/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
+                ProfScope ps(this, only ? "u:prepare" : "prepare/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
                 hipLaunchKernelGGL((k_prepare_all<T>), dim3(nb + cdiv(na, 8)), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, cpa, rsa, wb,
-                                   bb.d_users.p, nb, bb.cap, cpb, rsb, nb, d_mcsr.p, strict());
+                                   bb.d_users.p, nb, bb.cap, cpb, rsb, nb, d_mcsr.p, strict(), only);
             }
             if (!pbins[2].users.empty()) { ProfScope ps(this, pname("prepare", pbins[2]), st, pbins[2].nnz, (int64_t)pbins[2].users.size()); fn(pbins[2], st); }
             HIPCHK(hipGetLastError());
@@ -987,21 +1047,25 @@ struct Solver final : pcr_solver {
     }
 
     int launch_vsweep(bool hv, const T* A, const int* skip = nullptr) {
-        if (hv) { if (sddmm_by_tiles()) RC(launch_sddmm_csc(A, d_b.p, skip)); else RC(launch_sddmm(A, d_sitem.p, d_b.p, skip)); }
+        if (hv) { if (sddmm_by_tiles()) RC(launch_sddmm_csc(A, d_b.p, skip)); else RC(launch_sddmm(A, d_item.p, d_b.p, skip)); }      // b in CSR order
+        return launch_sweeps(hv, skip, nullptr);
+    }
+    // the per-user sweeps alone: b (CSR order, d_b) -> c (CSR order, d_c); only: lock-step U step, users still taking part
+    int launch_sweeps(bool hv, const int* skip, const uint8_t* only) {
         const bool two = hv && !sh.ws;                      // scores and sweep values both live in LDS (no window cache)
         auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
             const int rsc = b.max_lev + 2;
             if (b.block == 64) {                         // short users: one wave each, four per workgroup
                 const size_t wb = (vsweep_wave_bytes<T>(b.cap, rsc, two) + 15) & ~(size_t)15;
-                if (hv) hipLaunchKernelGGL((k_vsweep_wave<T, true>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip);
-                else hipLaunchKernelGGL((k_vsweep_wave<T, false>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip);
+                if (hv) hipLaunchKernelGGL((k_vsweep_wave<T, true>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip, only);
+                else hipLaunchKernelGGL((k_vsweep_wave<T, false>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip, only);
                 return;
             }
             const size_t bigb = vsweep_bytes<T>(b.cap, rsc, two);
             const size_t lds = small_common(b.block) + (b.big ? 0 : bigb);
             const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
-#define LV(BL, BG, HV) hipLaunchKernelGGL((k_vsweep<T, BL, BG, HV>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, d_scratch.p, scratch_stride, strict(), skip)
+#define LV(BL, BG, HV) hipLaunchKernelGGL((k_vsweep<T, BL, BG, HV>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, d_scratch.p, scratch_stride, strict(), skip, only)
             if (hv) { if (b.big) LV(512, true, true); else LV(512, false, true); }
             else { if (b.big) LV(512, true, false); else LV(512, false, false); }
 #undef LV
@@ -1015,11 +1079,11 @@ struct Solver final : pcr_solver {
             const size_t lds = std::max(wb * 8, small_common(512) + vsweep_bytes<T>(bb.cap, rsb, two));
             const int grid = nb + cdiv(na, 8);
             {
-                ProfScope ps(this, std::string(hv ? "vhv" : "vgrad") + "/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
+                ProfScope ps(this, only ? std::string("u:sweep") : std::string(hv ? "vhv" : "vgrad") + "/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
                 if (hv) hipLaunchKernelGGL((k_vsweep_all<T, true>), dim3(grid), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, rsa, wb,
-                                           bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip);
+                                           bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip, only);
                 else hipLaunchKernelGGL((k_vsweep_all<T, false>), dim3(grid), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, rsa, wb,
-                                        bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip);
+                                        bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip, only);
             }
             if (!sbins[2].users.empty()) { ProfScope ps(this, pname(hv ? "vhv" : "vgrad", sbins[2]), st, sbins[2].nnz, (int64_t)sbins[2].users.size()); fn(sbins[2], st); }
             HIPCHK(hipGetLastError());
@@ -1035,7 +1099,7 @@ struct Solver final : pcr_solver {
     int launch_spmm(T* out, const T* base, double beta, const int* skip = nullptr, const T* dots_rr = nullptr) {
         if (nnz_local > 0) {
             ProfScope ps(this, "spmm");
-            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(spmm_blocks), dim3(256), 0, st, d_c.p, d_cinv.p, d_cuf.p,
+            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(spmm_blocks), dim3(256), 0, st, d_c.p, d_c2r.p, d_cuf.p,
                                d_chunk_ptr.p, d_slot_base.p, d_slot_id.p, d_blk_chunks.p, d_U.p, d_slab.p, geo, skip);
         }
         ProfScope ps2(this, "spmm_fin");
@@ -1312,7 +1376,60 @@ struct Solver final : pcr_solver {
         counters_zeroed = true;
         return PCR_OK;
     }
+    // update_U_new as rating-parallel passes over all users (pcr_kernels.h, "Lock-step U step")
+    int launch_ustep_lockstep() {
+        RC(zero_counters());
+        counters_zeroed = false;
+        ProfScope wall(this, "wall:ustep", st);
+        const int nu = (int)n_users;
+        const int fin_grid = (int)std::min<int64_t>(4096, cdiv(std::max(nu, 1), 256 / geo.G));
+        auto spmm_u = [&](const int* skip, const uint8_t* only) {
+            ProfScope ps(this, "u:spmm");
+            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(u_spmm_blocks), dim3(256), 0, st, d_c.p, (const int32_t*)nullptr, du_cuf.p, du_chunk_ptr.p,
+                               du_inc_base.p, du_slot_id.p, du_blk_chunks.p, d_V.p, du_slab.p, geo, skip, only, du_inc_row.p);
+        };
+        HIPCHK(hipMemsetAsync(du_nact.p, 0, 4 * sizeof(int), st));
+        // ---- gradient (obtain_g_u_new) at the sorted state of (U, V), skip rules, CG start
+        RC(launch_sweeps(false, nullptr, nullptr));
+        spmm_u(nullptr, nullptr);
+        {
+            ProfScope ps(this, "u:fin");
+            hipLaunchKernelGGL((k_ufin_grad<T, 256>), dim3(fin_grid), dim3(256), 0, st, du_slab.p, du_uslot.p, d_U.p, d_uptr.p, d_runofs.p, d_objp.p,
+                               d_objr.p, prm.lambda, prm.stepsize, prm.cg_tol, strict(), nu, geo, ul);
+            hipLaunchKernelGGL(k_ucg_check, dim3(1), dim3(64), 0, st, du_nact.p);
+        }
+        // ---- CG (solve_delta_u_new): all iterations queued; once every user has stopped the rest return at once
+        const int* done = du_nact.p + 2;
+        for (int k = 1; k <= prm.cg_max_iter; ++k) {
+            RC(launch_sddmm(d_V.p, d_item.p, d_b.p, done, du_PT.p, du_active.p, "u:sddmm"));      // b = p_user . v_item
+            RC(launch_sweeps(true, done, du_active.p));
+            spmm_u(done, du_active.p);
+            ProfScope ps(this, "u:fin");
+            hipLaunchKernelGGL((k_ufin_cg<T, 256>), dim3(fin_grid), dim3(256), 0, st, du_slab.p, du_uslot.p, prm.lambda, nu, geo, ul, d_counters.p);
+            hipLaunchKernelGGL(k_ucg_check, dim3(1), dim3(64), 0, st, du_nact.p);
+        }
+        HIPCHK(hipGetLastError());
+        // ---- line search (pcrpp.cpp:794-813): every user that moved tries step 1; the few that found no decrease halve
+        for (int round = 0; round < 20; ++round) {
+            {
+                ProfScope ps(this, "u:ls");
+                hipLaunchKernelGGL((k_uls_apply<T, 256>), dim3(fin_grid), dim3(256), 0, st, d_U.p, nu, geo, ul);
+            }
+            RC(launch_prepare(d_V.p, du_Unew.p, du_ls.p));              // scores, sort, windows and loss of the tried u, those users only
+            {
+                ProfScope ps(this, "u:ls");
+                hipLaunchKernelGGL((k_uls_decide<T, 256>), dim3(fin_grid), dim3(256), 0, st, d_U.p, d_objp.p, d_objr.p, prm.lambda, nu, geo, ul, d_counters.p);
+            }
+            HIPCHK(hipMemcpyAsync(h_nact, du_nact.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (h_nact[1] <= 0) break;
+        }
+        HIPCHK(hipGetLastError());
+        return PCR_OK;
+    }
+
     int launch_ustep() {
+        if (lockstep) return launch_ustep_lockstep();
         RC(zero_counters());
         counters_zeroed = false;
         auto fn = [&](Bin& b, hipStream_t q) {
@@ -1389,6 +1506,7 @@ struct Solver final : pcr_solver {
         const int cb = uobj_merged ? 8 : 4;                         // counters follow the four sums (objective_sums)
         if (h_uobj[cb + 2] != 0.0) { pcr_set_error("k_ustep: a workgroup cluster timed out at a hand-off (members not co-resident?)"); return PCR_ERR_DEVICE; }
         if (info) { info[0] = (int64_t)h_uobj[cb]; info[1] = (int64_t)h_uobj[cb + 1]; }
+        ustep_rows += h_uobj[cb + 3];
         return PCR_OK;
     }
 
@@ -1635,6 +1753,13 @@ int pcr_solver_comm_init_p2p(pcr_solver* s, const char* shm_name) {
     return s->comm_init_p2p(shm_name);
 }
 int pcr_solver_comm_nranks(pcr_solver* s) { if (!s) return -1; return s->comm_nranks(); }
+int pcr_solver_counter(pcr_solver* s, const char* name, double* value) {
+    S_OR_ARG;
+    if (!name || !value) { pcr_set_error("pcr_solver_counter: bad argument"); return PCR_ERR_ARG; }
+    if (!strcmp(name, "ustep_row_gathers")) { *value = s->ustep_rows; return PCR_OK; }
+    pcr_set_error(std::string("pcr_solver_counter: unknown counter '") + name + "'");
+    return PCR_ERR_ARG;
+}
 // a failing rank tells its peers (p2p: shared error flag; RCCL: local abort) before it reports the error
 static int leave_on_error(pcr_solver* s, int rc) { if (rc != PCR_OK) s->comm_abort(); return rc; }
 int pcr_solver_set_local_only(pcr_solver* s, int on) { S_OR_ARG; s->local_only = on != 0; return PCR_OK; }

@@ -15,9 +15,16 @@ ap.add_argument("-k", type=int, default=100); ap.add_argument("-t", type=int, de
 ap.add_argument("--f64", action="store_true"); ap.add_argument("--ref", action="store_true"); ap.add_argument("--predict", type=int, default=0)
 ap.add_argument("--threads", type=int, default=16); ap.add_argument("-s", type=int, default=2, help="1 PrimalCR, 2 PrimalCR++")
 ap.add_argument("--cg-iters", type=int, default=10); ap.add_argument("--cg-tol", type=float, default=0.01)
+ap.add_argument("--tune", action="append", default=[], help="key=value launch knob (pcr_tune), repeatable")
 a = ap.parse_args()
+for kv in a.tune:
+    pcr.tune(*kv.split("=", 1))
 t0 = time.time()
-R = synth.generate(a.shape, d1=a.d1, d2=a.d2, nnz=a.nnz, mu=a.mu, sigma=a.sigma)
+ap_users = None
+if a.shape in ("netflix", "yahoo"):      # the C++ generator (seconds); --d1 N on yahoo = its first N users
+    R = synth.generate_fast(a.shape, users=(0, a.d1) if (a.shape == "yahoo" and a.d1) else None, d1=None if a.shape == "yahoo" else a.d1, d2=a.d2, nnz=a.nnz, mu=a.mu, sigma=a.sigma)
+else:
+    R = synth.generate(a.shape, d1=a.d1, d2=a.d2, nnz=a.nnz, mu=a.mu, sigma=a.sigma)
 ds = pcr.Dataset.from_ratings(R)
 idx, _, _ = ds.csr(0); lens = np.diff(idx)
 print(f"[data] {R.d1}x{R.d2} nnz={R.nnz} pairs={ds.count_pairs()} len max={lens.max()} mean={lens.mean():.1f} >4096: {(lens>4096).sum()} ({time.time()-t0:.1f}s)", flush=True)
