@@ -169,14 +169,15 @@ def cpu_baseline(R, n_pairs, r, lam):
             "sample": f"C restatement, first {nu} users ({int(keep.sum())} ratings, {pairs} pairs), 1 iteration = {secs:.2f} s"}
 
 
-def timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, local_rank, args, profile, shm_name):
+def timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, local_rank, args, profile, shm_name, count_rows=False):
     """One solver, `warmup` untimed + exactly `steps` timed outer iterations (barrier + synchronize on both sides, MAX over
     ranks), then the quality after warmup + steps iterations."""
     p = pcr.Parameter(k=r, precision=prec, device=local_rank, do_predict=0, maxiter=1, **{"lambda": lam})
-    s = pcr.Solver(ds, p, rank, N)
+    with pcr.tuned(**({"count_rows": 1} if count_rows else {})):
+        s = pcr.Solver(ds, p, rank, N)
     if N > 1:
         if args.comm == "p2p":
-            s.comm_init_p2p(shm_name + ("_64" if prec == pcr.PCR_F64 else "_32"))
+            s.comm_init_p2p(shm_name + ("_64" if prec == pcr.PCR_F64 else "_32") + ("c" if count_rows else ""))
         else:
             ids = [pcr.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
@@ -298,6 +299,9 @@ def main():
     run64 = None
     if prec == pcr.PCR_F32 and not args.no_f64:
         run64 = timed_run(pcr, torch, dist, ds, R, r, lam, pcr.PCR_F64, rank, N, local_rank, args, False, shm[0])
+    # diagnostic replay of the same iterations with the U-step kernels counting the rows of V they gather (an extra atomic per
+    # user, so it is kept out of the timed run): the rating-weighted pass count of the U step
+    run["u_rows"] = timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, local_rank, args, False, shm[0], count_rows=True)["u_rows"]
     secs, objs, inner, prof = run["secs"], run["objs"], run["inner"], run["prof"]
     te_err, te_ndcg = run["te"]; tr_err, tr_ndcg = run["tr"]
     prof_period = run["prof_period"]

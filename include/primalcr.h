@@ -147,17 +147,17 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *   ustep_many      user count above which a long class counts as throughput-bound (default CUs/4)
  *   ustep_seq       1 = the U step's length classes back to back on one stream
  *   ustep_lockstep  1 = U step as rating-parallel lock-step passes over all users (default 0: per-user kernels)
- *   ustep_gram      dual (Gram-matrix, MFMA) U step for users with at most that many ratings; 0 off (default by rank)
+ *   ustep_gram      dual (Gram-matrix on MFMA) U step for users with at most that many ratings (<= 128; default 0 = off)
  *   cluster_k       4 (default) or 1: workgroups per clustered long user;  cluster_users: how many users get clusters
  *   ubins           "cap:block:resident,..." length classes of the U step below 1024 ratings
  *   spmm_tiles, spmm_chunk, sddmm_tile, sddmm_csc   tiling of the rating-parallel kernels
  *   sweep_wave_cap  ratings up to which a sweep gives a user one wave
  *   window_cache    0 = sweeps search their hinge windows instead of caching them
  *   prepare_merged  0 = one prepare launch per length class
- *   cg_fused        persistent one-launch CG iteration: 1 on, 0 off (default: by shard size)
  *   lanes           concurrent streams for length classes (1 = none);  pipeline: 0 = host round trip after every U step
  *   eval_brute      1 = O(len^2) evaluator
- *   comm            "rccl" (default) | "p2p": all-reduce of the V-side vectors through peer-mapped buffers
+ *   count_rows      1 = the U-step kernels count the rows of V they gather (pcr_solver_counter; a diagnostic that
+ *                   costs the short-user classes 10-20 %, so off by default)
  *   debug           1 = print launch decisions to stderr
  *   fault_cluster_member   test hook: one member of every workgroup cluster leaves early (the launch must report
  *                   PCR_ERR_DEVICE through the bounded hand-off wait instead of hanging) */
@@ -186,8 +186,8 @@ int pcr_solver_comm_init_p2p(pcr_solver *s, const char *shm_name);         /* [d
 int pcr_solver_comm_nranks(pcr_solver *s);
 /* diagnostic counters, cumulative since the solver was created:
  *   "ustep_row_gathers"  rows of V the U steps gathered (per user: 1 for the gradient + 2 per CG iteration + 1 per
- *                        line-search try, times its rating count; all ranks) -- the U step's gather rate = this x k x
- *                        sizeof(storage type) / its wall time */
+ *                        line-search try, times its rating count; all ranks; counted only under pcr_tune("count_rows")) --
+ *                        the U step's gather rate = this x k x sizeof(storage type) / its wall time */
 int pcr_solver_counter(pcr_solver *s, const char *name, double *value);
 /* Shard-local mode for a solver created with nranks > 1 and no communicator: every collective
  * becomes a no-op, so pcr_obtain_g / pcr_compute_Ha / pcr_objective return THIS SHARD'S PARTIAL

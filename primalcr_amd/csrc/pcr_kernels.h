@@ -299,6 +299,20 @@ __device__ __forceinline__ void find_windows(const T* ms, const int* rs, int nle
     }
 }
 
+// level of sorted position p = the run it lies in (rs: run boundaries in LDS).  With the few levels of star ratings this is
+// cheaper than a 2-byte global load per rating, and the sweeps then read ONE per-rating index stream (sidx) where they
+// used to read one (slvl) before c went out in CSR order.
+__device__ __forceinline__ int level_of(const int* rs, int nlev, int p) {
+    if (nlev <= 8) {
+        int lev = 0;
+        for (int l = 1; l < nlev; ++l) lev += (p >= rs[l]) ? 1 : 0;
+        return lev;
+    }
+    int lo = 0, hi = nlev - 1;                       // last l with rs[l] <= p
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (rs[mid] <= p) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
 // sweep_coeff with cached boundaries (w: ws slots of this item)
 __device__ __forceinline__ double sweep_coeff_win(const uint32_t* __restrict__ w, const double* S, const int* rs, int nlev,
                                                   int lev, double xp, double shift) {
@@ -848,7 +862,7 @@ __global__ __launch_bounds__(512) void k_prepare_all(Shard<T> S, const int32_t* 
 // ---------------------------------------------------------------------------------------
 template <typename T>
 static inline size_t vsweep_bytes(int cap, int rs_cap, bool two) {      // two: scores AND sweep values (HV without window cache)
-    return carve_bytes(cap, sizeof(T)) * (two ? 3 : 2) + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);      // + the CSR-order staging array
+    return carve_bytes(cap, sizeof(T)) * (two ? 2 : 1) + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
 }
 
 // body of k_vsweep: workgroup `blk` of `nblk` walks users blk, blk + nblk, ...
@@ -856,14 +870,12 @@ template <typename T, int BLOCK, bool BIG, bool HV>
 __device__ __forceinline__ void vsweep_block_body(char* smem, const Shard<T>& S, const int32_t* __restrict__ users, int nusers,
                                                   const T* __restrict__ bsrc, T* __restrict__ c_out, int cap, int rs_cap,
                                                   char* scratch, size_t stride, int strict, int blk, int nblk,
-                                                  const uint8_t* __restrict__ only = nullptr) {
+                                                  const uint8_t* __restrict__ only = nullptr, int b_csr = 0) {
     Carver small(smem);
     double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
     Carver big(BIG ? scratch + (size_t)blk * stride : small.p);
     T* ms = big.take<T>(cap);                           // scores (thresholds) -- not loaded when the window cache replaces them
     T* x = (HV && !S.ws) ? big.take<T>(cap) : ms;       // sweep values b; they share the array unless both are needed
-    T* stg = big.take<T>(cap);                          // CSR-order staging: b comes in and c goes out as whole lines, the
-                                                        // permutation to / from the sorted order happens here (LDS or scratch)
     double* Sx = big.take<double>(cap + 1);
     int* rs = big.take<int>(rs_cap);
     const int tid = threadIdx.x;
@@ -878,23 +890,22 @@ __device__ __forceinline__ void vsweep_block_body(char* smem, const Shard<T>& S,
         if (!HV || !S.ws) for (int p = tid; p < n; p += BLOCK) ms[p] = S.ms[s0 + p];
         for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
         const T* xs = ms;
-        if (HV) {
-            for (int q = tid; q < n; q += BLOCK) stg[q] = bsrc[s0 + q];                 // b = u_i . a_item (k_sddmm, CSR order)
-            __syncthreads();
-            for (int p = tid; p < n; p += BLOCK) x[p] = stg[S.sidx[s0 + p]];
+        if (HV) {     // b = u_i . a_item from k_sddmm: in sorted order when it walked sitem, in CSR order when it walked the CSC
+            for (int p = tid; p < n; p += BLOCK) x[p] = bsrc[s0 + (b_csr ? S.sidx[s0 + p] : p)];
             xs = x;
         }
         __syncthreads();
         block_excl_scan<BLOCK>([&](int i) { return (double)xs[i]; }, Sx, n, red);
         for (int p = tid; p < n; p += BLOCK) {
-            const int lev = S.slvl[s0 + p];
+            const int lev = level_of(rs, nlev, p);
             const double c = S.ws
                 ? sweep_coeff_win(S.win + (size_t)(s0 + p) * S.ws, Sx, rs, nlev, lev, (double)xs[p], HV ? 0.0 : 1.0)
                 : sweep_coeff<T>(ms, Sx, rs, nlev, lev, ms[p], (double)xs[p], HV ? 0.0 : 1.0, strict);
-            stg[S.sidx[s0 + p]] = (T)c;           // back to CSR order (every b was picked up before the scan's barriers)
+            // c goes out in CSR order -- a permutation inside this user's own segment, so the lines it touches are written in
+            // full by this workgroup (staging the permutation through LDS was measured slower: 2.11 against 1.65 ms per
+            // launch on the Netflix shape, the extra array costs occupancy)
+            c_out[s0 + S.sidx[s0 + p]] = (T)c;
         }
-        __syncthreads();
-        for (int q = tid; q < n; q += BLOCK) c_out[s0 + q] = stg[q];
         __syncthreads();
     }
 }
@@ -902,11 +913,11 @@ template <typename T, int BLOCK, bool BIG, bool HV>
 __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                   const T* __restrict__ bsrc, T* __restrict__ c_out,
                                                   int cap, int rs_cap, char* scratch, size_t stride, int strict, const int* skip,
-                                                  const uint8_t* __restrict__ only) {
+                                                  const uint8_t* __restrict__ only, int b_csr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (skip && *skip) return;
     vsweep_block_body<T, BLOCK, BIG, HV>(smem, S, users, nusers, bsrc, c_out, cap, rs_cap, scratch, stride, strict,
-                                         (int)blockIdx.x, (int)gridDim.x, only);
+                                         (int)blockIdx.x, (int)gridDim.x, only, b_csr);
 }
 
 // k_vsweep for short users (<= 256 ratings), ONE WAVE PER USER, four users per 256-thread
@@ -914,21 +925,20 @@ __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int
 // in program order), so the many short users of a rating set do not pay a block's fixed cost each.
 template <typename T>
 static inline size_t vsweep_wave_bytes(int cap, int rs_cap, bool two) {      // per wave
-    return carve_bytes(cap, sizeof(T)) * (two ? 3 : 2) + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
+    return carve_bytes(cap, sizeof(T)) * (two ? 2 : 1) + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
 }
 // body: this wave sweeps user number ui of the list
 template <typename T, bool HV>
 __device__ __forceinline__ void vsweep_wave_body(char* smem, const Shard<T>& S, const int32_t* __restrict__ users, int nusers,
                                                  const T* __restrict__ bsrc, T* __restrict__ c_out,
                                                  int cap, int rs_cap, size_t wave_bytes, int strict, int ui,
-                                                 const uint8_t* __restrict__ only = nullptr) {
+                                                 const uint8_t* __restrict__ only = nullptr, int b_csr = 0) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (ui >= nusers) return;
     if (only && !only[users[ui]]) return;
     Carver big(smem + (size_t)wid * wave_bytes);
     T* ms = big.take<T>(cap);                           // scores (thresholds) -- not loaded when the window cache replaces them
     T* x = (HV && !S.ws) ? big.take<T>(cap) : ms;       // sweep values b; they share the array unless both are needed
-    T* stg = big.take<T>(cap);                          // CSR-order staging (see vsweep_block_body)
     double* Sx = big.take<double>(cap + 1);
     int* rs = big.take<int>(rs_cap);
     const int u = users[ui];
@@ -940,9 +950,7 @@ __device__ __forceinline__ void vsweep_wave_body(char* smem, const Shard<T>& S, 
     for (int l = lane; l <= nlev; l += 64) rs[l] = S.runstart[S.runofs[u] + l];
     const T* xs = ms;
     if (HV) {
-        for (int q = lane; q < n; q += 64) stg[q] = bsrc[s0 + q];
-        wave_sync();
-        for (int p = lane; p < n; p += 64) x[p] = stg[S.sidx[s0 + p]];
+        for (int p = lane; p < n; p += 64) x[p] = bsrc[s0 + (b_csr ? S.sidx[s0 + p] : p)];
         xs = x;
     }
     wave_sync();
@@ -957,24 +965,22 @@ __device__ __forceinline__ void vsweep_wave_body(char* smem, const Shard<T>& S, 
     if (lane == 0) Sx[n] = carry;
     wave_sync();
     for (int p = lane; p < n; p += 64) {
-        const int lev = S.slvl[s0 + p];
+        const int lev = level_of(rs, nlev, p);
         const double c = S.ws
             ? sweep_coeff_win(S.win + (size_t)(s0 + p) * S.ws, Sx, rs, nlev, lev, (double)xs[p], HV ? 0.0 : 1.0)
             : sweep_coeff<T>(ms, Sx, rs, nlev, lev, ms[p], (double)xs[p], HV ? 0.0 : 1.0, strict);
-        stg[S.sidx[s0 + p]] = (T)c;
+        c_out[s0 + S.sidx[s0 + p]] = (T)c;
     }
-    wave_sync();
-    for (int q = lane; q < n; q += 64) c_out[s0 + q] = stg[q];
 }
 template <typename T, bool HV>
 __global__ __launch_bounds__(256) void k_vsweep_wave(Shard<T> S, const int32_t* __restrict__ users, int nusers,
                                                      const T* __restrict__ bsrc, T* __restrict__ c_out,
                                                      int cap, int rs_cap, size_t wave_bytes, int strict, const int* skip,
-                                                     const uint8_t* __restrict__ only) {
+                                                     const uint8_t* __restrict__ only, int b_csr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (skip && *skip) return;
     vsweep_wave_body<T, HV>(smem, S, users, nusers, bsrc, c_out, cap, rs_cap, wave_bytes, strict,
-                            (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), only);
+                            (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), only, b_csr);
 }
 
 // Both LDS-resident classes in ONE launch of 512-thread workgroups (the two sweeps are each shorter than a launch
@@ -985,15 +991,15 @@ __global__ __launch_bounds__(512) void k_vsweep_all(Shard<T> S, const int32_t* _
                                                     int rs_cap_a, size_t wave_bytes, const int32_t* __restrict__ users_b,
                                                     int nusers_b, int cap_b, int rs_cap_b, int nblk_b,
                                                     const T* __restrict__ bsrc, T* __restrict__ c_out, int strict, const int* skip,
-                                                    const uint8_t* __restrict__ only) {
+                                                    const uint8_t* __restrict__ only, int b_csr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (skip && *skip) return;
     if ((int)blockIdx.x < nblk_b)
         vsweep_block_body<T, 512, false, HV>(smem, S, users_b, nusers_b, bsrc, c_out, cap_b, rs_cap_b, nullptr, 0, strict,
-                                             (int)blockIdx.x, nblk_b, only);
+                                             (int)blockIdx.x, nblk_b, only, b_csr);
     else
         vsweep_wave_body<T, HV>(smem, S, users_a, nusers_a, bsrc, c_out, cap_a, rs_cap_a, wave_bytes, strict,
-                                ((int)blockIdx.x - nblk_b) * 8 + (int)(threadIdx.x >> 6), only);
+                                ((int)blockIdx.x - nblk_b) * 8 + (int)(threadIdx.x >> 6), only, b_csr);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1429,7 +1435,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // test hook (pcr_tune "fault_cluster_member"): the last member of every cluster leaves at once, so that the others run
     // into the bounded wait of cluster_barrier and the launch reports a time-out instead of hanging
-    if (K > 1 && fault && (int)(blockIdx.x % K) == K - 1) return;
+    if (K > 1 && (fault & 1) && (int)(blockIdx.x % K) == K - 1) return;
     Carver small(smem);
     T* vecT = small.take<T>(geo.ld);
     double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
@@ -1657,9 +1663,9 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
             if (!skip) S.objp[u] = loss_new;
             if (n_cg) atomicAdd(counters + 0, (unsigned long long)n_cg);
             if (n_ls) atomicAdd(counters + 1, (unsigned long long)n_ls);
-            // rows of V this user's step gathered: gradient + 2 per CG iteration + 1 per line-search try (diagnostic: the
-            // U step's achieved gather rate in bench.py)
-            atomicAdd(counters + 2, (unsigned long long)n * (unsigned long long)(1 + 2 * n_cg + n_ls));
+            // rows of V this user's step gathered: gradient + 2 per CG iteration + 1 per line-search try (diagnostic, only
+            // with pcr_tune("count_rows"): a third same-address atomic per user costs the short classes 10-20 %)
+            if (fault & 2) atomicAdd(counters + 2, (unsigned long long)n * (unsigned long long)(1 + 2 * n_cg + n_ls));
         }
         __syncthreads();
         UPROF(10);

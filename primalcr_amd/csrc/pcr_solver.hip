@@ -22,6 +22,7 @@
 
 #include "pcr_host.h"
 #include "pcr_kernels.h"
+#include "pcr_gram.h"
 #include "pcr_p2p.h"
 
 #define HIPCHK(expr)                                                                           \
@@ -83,6 +84,7 @@ struct Bin {
     int limit = 0;       // upper length bound of the class (0: none)
     int rcap = 0;        // k_ustep: rows of V a workgroup keeps resident in LDS
     int unr = 4;         // k_ustep: rows in flight per lane group (8: latency-bound class, one workgroup per CU)
+    bool gram = false;   // k_ustep_gram: the dual (Gram-matrix, MFMA) form for users with few ratings
     int max_lev = 0;
     int64_t nnz = 0;     // ratings of the users in the bin
     std::vector<int32_t> users;
@@ -93,6 +95,7 @@ struct Bin {
 // threads for the top classes: k_ustep needs more than the 128 VGPRs a 512-thread block may use.
 static const int BIN_LIMIT[3] = {128, 512, 4096};
 static const int BIN_BLOCK[4] = {64, 256, 512, 512};
+static const int GRAM_DEFAULT_CAP = 0;       // default length bound of the dual-form U-step class (0: off; pcr_tune "ustep_gram")
 
 struct ProfSlot {
     int64_t ratings = -1, users = -1;      // what one launch covers (-1: the whole shard)
@@ -135,7 +138,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = 1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
-        fault_cluster_member = 0, ustep_lockstep = -1;
+        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -145,6 +148,7 @@ struct Tune {
         prepare_merged = pcr_tune_int("prepare_merged", 1); ustep_seq = pcr_tune_int("ustep_seq", 0); eval_brute = pcr_tune_int("eval_brute", 0);
         pipeline = pcr_tune_int("pipeline", 1); debug = pcr_tune_int("debug", 0); fault_cluster_member = pcr_tune_int("fault_cluster_member", 0);
         ustep_lockstep = pcr_tune_int("ustep_lockstep", -1);
+        ustep_gram = pcr_tune_int("ustep_gram", -1); count_rows = pcr_tune_int("count_rows", 0);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -568,8 +572,8 @@ struct Solver final : pcr_solver {
             for (int c : {256, 320, 384, 448, 512}) {
                 const int64_t n_wave = std::upper_bound(lens.begin(), lens.end(), (int64_t)c) - lens.begin();
                 const int64_t n_blk = std::max<int64_t>(0, max_lds - n_wave);
-                const size_t wave_lds = 8 * ((size_t)c * 2 * sizeof(T) + (size_t)(c + 1) * 8 + 64);
-                const size_t blk_lds = n_blk > 0 ? (size_t)cap_b * 2 * sizeof(T) + (size_t)(cap_b + 1) * 8 + 1024 : 0;
+                const size_t wave_lds = 8 * ((size_t)c * sizeof(T) + (size_t)(c + 1) * 8 + 64);
+                const size_t blk_lds = n_blk > 0 ? (size_t)cap_b * sizeof(T) + (size_t)(cap_b + 1) * 8 + 1024 : 0;
                 const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, ((size_t)160 << 10) / std::max<size_t>(1, std::max(wave_lds, blk_lds))));
                 const double rounds = (double)(cdiv(n_wave, 8) + n_blk) / ((double)ncu * per_cu);
                 const double cost = std::max(rounds, 1.0) * (1.0 + c / 1024.0);
@@ -603,6 +607,21 @@ struct Solver final : pcr_solver {
                 q += used; if (*q == ',') ++q;
             }
         }
+        // Dual form (pcr_gram.h): users with at most gram_cap ratings run k_ustep_gram -- one class in place of the one-wave
+        // classes.  gram_cap = pcr_tune("ustep_gram") or the largest count whose LDS (row image / Gram matrix + n-vectors)
+        // still lets two workgroups share a CU, at most 128 (fp64: 64).
+        int gram_cap = 0;
+        if (tune.ustep_gram != 0 && tune.ubins.empty()) {
+            const int hard = sizeof(T) == 4 ? 128 : 64;
+            const int want = tune.ustep_gram > 0 ? std::min(tune.ustep_gram, hard) : GRAM_DEFAULT_CAP;
+            const int nchp0 = geo.nchunk | 1;
+            for (int c = want; c >= 16; c -= 8)
+                if (gram_bytes<T>(c, host_pow2(c), lv.max_levels + 2, geo.ld, nchp0, 256) <= (tune.ustep_gram > 0 ? (size_t)160 : (size_t)80) * 1024) { gram_cap = c; break; }
+            if (lv.max_levels > 64) gram_cap = 0;              // (real-valued ratings under PrimalCR: a level per rating -- keep the general kernel)
+        }
+        size_t ngram = 0;
+        if (gram_cap > 64) { ucap = {64, gram_cap, 512}; ublk = {64, 256, 256}; ures = {0, 0, 0}; ngram = 2; }       // one wave up to 64 ratings
+        else if (gram_cap > 0) { ucap = {gram_cap, 512}; ublk = {64, 256}; ures = {0, 0}; ngram = 1; }
         const size_t nsmall = ucap.size();
         // Latency or throughput?  A class with few users is one round of workgroups and is bound by the per-user dependency
         // chain: 512 threads, 8 rows in flight per lane group, 174-205 VGPRs = one workgroup per CU.  A class with many users
@@ -620,6 +639,7 @@ struct Solver final : pcr_solver {
         if (many(n_mid)) { ucap.push_back(2048); ublk.push_back(512); }
         ucap.push_back(4096); ublk.push_back(512); ublk.push_back(512);
         make_bins(uptr, nu, &lv.run_ofs, ubins, ucap, ublk);
+        for (size_t q = 0; q < ngram; ++q) ubins[q].gram = true;
         // Workgroup clusters trade throughput for latency: only the longest users of the shard (the critical path, more than
         // 1024 ratings) get them, ncu/(4K) users (all their workgroups fit the chip at once, see below) -- ONE extra class
         // whatever length class they came from (in global scratch if any of them needs it).  pcr_tune("cluster_k", "1") disables.
@@ -664,7 +684,7 @@ struct Solver final : pcr_solver {
         // A class whose per-rating arrays + r-vectors do not fit the 160 KB of LDS (fp64 at wide ranks with users near 4096
         // ratings, or thousands of rating levels under PrimalCR) runs the global-scratch form of the kernel instead.
         for (auto& b : ubins) {
-            if (b.big || b.users.empty()) continue;
+            if (b.big || b.users.empty() || b.gram) continue;
             const size_t fixed = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + ustep_big_bytes<T>(b.cap, host_pow2(b.cap), b.max_lev + 2, 4);
             if (fixed > (size_t)160 * 1024) { b.big = true; b.block = 512; }
         }
@@ -679,7 +699,7 @@ struct Solver final : pcr_solver {
             const size_t lim = 160 * 1024;
             for (size_t bi = 0; bi < ubins.size(); ++bi) {
                 Bin& b = ubins[bi];
-                if (b.users.empty()) continue;
+                if (b.users.empty() || b.gram) continue;
                 // the LDS image pays where LDS is spare: the one-wave classes of <= 64 ratings, and the latency-bound
                 // 512-thread classes (one workgroup per CU anyway), which keep as many rows as fit beside their arrays
                 const int res_on = bi < nsmall ? (b.block == 64 ? ures[bi] : 0) : (b.unr == 8);
@@ -851,6 +871,8 @@ struct Solver final : pcr_solver {
         UL(512, false, 1, true, 8); UL(512, false, 1, false, 4); UL(512, false, 4, true, 8);
         UL(512, true, 1, true, 8); UL(512, true, 1, false, 4); UL(512, true, 4, true, 8);
 #undef UL
+        HIPCHK(hipFuncSetAttribute((const void*)k_ustep_gram<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_ustep_gram<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_eval<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_eval2<T, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         return PCR_OK;
@@ -956,6 +978,7 @@ struct Solver final : pcr_solver {
     // profile slot of one kernel launch: "<class>/<workgroup size>[g]" (g = global-scratch variant)
     // ("ustep" has several classes per workgroup size: "<class>/<workgroup size>.<length bound>")
     static std::string pname(const char* cls, const Bin& b) {
+        if (b.gram) return std::string(cls) + "/gram" + std::to_string(b.block) + "." + std::to_string(b.limit);
         std::string s = std::string(cls) + "/" + std::to_string(b.block);
         if (!strcmp(cls, "ustep") && b.limit) s += "." + std::to_string(b.limit);
         return s + (b.big ? "g" : "") + (b.K > 1 ? "c" : "");
@@ -1047,25 +1070,28 @@ struct Solver final : pcr_solver {
     }
 
     int launch_vsweep(bool hv, const T* A, const int* skip = nullptr) {
-        if (hv) { if (sddmm_by_tiles()) RC(launch_sddmm_csc(A, d_b.p, skip)); else RC(launch_sddmm(A, d_item.p, d_b.p, skip)); }      // b in CSR order
-        return launch_sweeps(hv, skip, nullptr);
+        // b = u_user . A_item per rating: walking the sorted state's item ids leaves it in sorted order (what the sweep reads);
+        // the CSC walk (item tables beyond the L2s) leaves it in CSR order and the sweep picks it up through sidx
+        if (hv) { if (sddmm_by_tiles()) RC(launch_sddmm_csc(A, d_b.p, skip)); else RC(launch_sddmm(A, d_sitem.p, d_b.p, skip)); }
+        return launch_sweeps(hv, skip, nullptr, hv && sddmm_by_tiles());
     }
-    // the per-user sweeps alone: b (CSR order, d_b) -> c (CSR order, d_c); only: lock-step U step, users still taking part
-    int launch_sweeps(bool hv, const int* skip, const uint8_t* only) {
+    // the per-user sweeps alone: b (d_b) -> c (CSR order, d_c); only: lock-step U step, users still taking part
+    int launch_sweeps(bool hv, const int* skip, const uint8_t* only, bool b_csr = false) {
+        const int bc = b_csr ? 1 : 0;
         const bool two = hv && !sh.ws;                      // scores and sweep values both live in LDS (no window cache)
         auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
             const int rsc = b.max_lev + 2;
             if (b.block == 64) {                         // short users: one wave each, four per workgroup
                 const size_t wb = (vsweep_wave_bytes<T>(b.cap, rsc, two) + 15) & ~(size_t)15;
-                if (hv) hipLaunchKernelGGL((k_vsweep_wave<T, true>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip, only);
-                else hipLaunchKernelGGL((k_vsweep_wave<T, false>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip, only);
+                if (hv) hipLaunchKernelGGL((k_vsweep_wave<T, true>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip, only, bc);
+                else hipLaunchKernelGGL((k_vsweep_wave<T, false>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip, only, bc);
                 return;
             }
             const size_t bigb = vsweep_bytes<T>(b.cap, rsc, two);
             const size_t lds = small_common(b.block) + (b.big ? 0 : bigb);
             const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
-#define LV(BL, BG, HV) hipLaunchKernelGGL((k_vsweep<T, BL, BG, HV>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, d_scratch.p, scratch_stride, strict(), skip, only)
+#define LV(BL, BG, HV) hipLaunchKernelGGL((k_vsweep<T, BL, BG, HV>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, d_scratch.p, scratch_stride, strict(), skip, only, bc)
             if (hv) { if (b.big) LV(512, true, true); else LV(512, false, true); }
             else { if (b.big) LV(512, true, false); else LV(512, false, false); }
 #undef LV
@@ -1081,9 +1107,9 @@ struct Solver final : pcr_solver {
             {
                 ProfScope ps(this, only ? std::string("u:sweep") : std::string(hv ? "vhv" : "vgrad") + "/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
                 if (hv) hipLaunchKernelGGL((k_vsweep_all<T, true>), dim3(grid), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, rsa, wb,
-                                           bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip, only);
+                                           bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip, only, bc);
                 else hipLaunchKernelGGL((k_vsweep_all<T, false>), dim3(grid), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, rsa, wb,
-                                        bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip, only);
+                                        bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip, only, bc);
             }
             if (!sbins[2].users.empty()) { ProfScope ps(this, pname(hv ? "vhv" : "vgrad", sbins[2]), st, sbins[2].nnz, (int64_t)sbins[2].users.size()); fn(sbins[2], st); }
             HIPCHK(hipGetLastError());
@@ -1401,7 +1427,7 @@ struct Solver final : pcr_solver {
         // ---- CG (solve_delta_u_new): all iterations queued; once every user has stopped the rest return at once
         const int* done = du_nact.p + 2;
         for (int k = 1; k <= prm.cg_max_iter; ++k) {
-            RC(launch_sddmm(d_V.p, d_item.p, d_b.p, done, du_PT.p, du_active.p, "u:sddmm"));      // b = p_user . v_item
+            RC(launch_sddmm(d_V.p, d_sitem.p, d_b.p, done, du_PT.p, du_active.p, "u:sddmm"));     // b = p_user . v_item, sorted order
             RC(launch_sweeps(true, done, du_active.p));
             spmm_u(done, du_active.p);
             ProfScope ps(this, "u:fin");
@@ -1443,7 +1469,17 @@ struct Solver final : pcr_solver {
             // clusters: grid <= one workgroup per CU so that every member of every cluster is resident
             const int grid = b.ugrid;
             char* scr = d_scratch.p + (size_t)b.scratch_ofs * scratch_stride;
-#define LU(BL, BG, KK, RS, UN) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb, tune.fault_cluster_member)
+#define LU(BL, BG, KK, RS, UN) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb, (tune.fault_cluster_member ? 1 : 0) | (tune.count_rows ? 2 : 0))
+            if (b.gram) {
+                const size_t gl = gram_bytes<T>(b.cap, cap_pad, rsc, geo.ld, nchp, b.block);
+                if (b.block == 64)
+                    hipLaunchKernelGGL((k_ustep_gram<T, 64>), dim3(nus), dim3(64), gl, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize,
+                                       prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, nchp, d_counters.p, tune.count_rows);
+                else
+                    hipLaunchKernelGGL((k_ustep_gram<T, 256>), dim3(nus), dim3(256), gl, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize,
+                                       prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, nchp, d_counters.p, tune.count_rows);
+                return;
+            }
             if (b.big) { if (b.K == 4) LU(512, true, 4, true, 8); else if (b.unr == 8) LU(512, true, 1, true, 8); else LU(512, true, 1, false, 4); }
             else if (b.block == 64) { if (b.rcap > 0) LU(64, false, 1, true, 4); else LU(64, false, 1, false, 4); }
             else if (b.block == 256) LU(256, false, 1, false, 4);

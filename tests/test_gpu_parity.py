@@ -265,6 +265,7 @@ VARIANTS = [
     {"spmm_tiles": "5"}, {"spmm_tiles": "16"}, {"spmm_tiles": "64"},   # user tiles of the SpMM (incl. more tiles than XCDs)
     {"spmm_chunk": "32"}, {"spmm_chunk": "128"},         # ratings per SpMM lane group (the default adapts to the shard: 64 here)
     {"lanes": "1"},                                          # every class on the solver's stream
+    {"ustep_gram": "128"}, {"ustep_gram": "40"}, {"ustep_gram": "64", "window_cache": "0"},   # dual (Gram matrix on MFMA) form for short users
     {"ustep_lockstep": "1"}, {"ustep_lockstep": "1", "window_cache": "0"},   # the U step as rating-parallel lock-step passes (large-shard form)
     {"window_cache": "0"}, {"prepare_merged": "0"}, {"ustep_seq": "1"}, {"pipeline": "0"},   # searching sweeps, per-class prepare, serial classes
     {"sddmm_csc": "1"}, {"sddmm_csc": "1", "spmm_tiles": "16"},   # the CG's SDDMM over the tile-major CSC (wide item tables)
@@ -737,3 +738,63 @@ def test_lockstep_u_step_line_search_retries(oracle, step):
         oV, iv = s.update_V()
         V2, m2, objVo, ivo = oracle.update_V_new(X, lam, step, U1, V0)
         assert (iv["cg"], iv["ls"]) == (ivo["cg"], ivo["ls"]) and abs(oV / objVo - 1) < 1e-9, ls
+
+
+@pytest.mark.parametrize("precision", [pcr.PCR_F64, pcr.PCR_F32])
+@pytest.mark.parametrize("solver,r", [(2, 10), (1, 10), (2, 100), (2, 132)])
+def test_gram_u_step_against_oracle(oracle, precision, solver, r):
+    """k_ustep_gram (pcr_gram.h): users with few ratings take their Newton step in the span of u_i and their rows of V,
+    through the n x n Gram matrix built by MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64).  A set whose short
+    users hit every tile count (1..128 ratings: 1-4 MFMA tiles a side in fp32, 1-4 in fp64 up to 64), users with no / one /
+    all-equal ratings, rank below and above the rating counts (r = 10 < n, r = 100 ~ n, r = 132: k range of a lane not a
+    multiple of 4).  Two outer iterations against the oracle, counts included in fp64."""
+    rng = np.random.default_rng(5 + r)
+    d2, lam = 1500, 25.0
+    lens = np.concatenate([[0, 1, 2, 128, 127, 97, 96, 65, 64, 63, 33, 32, 31, 17, 16, 15, 5, 300, 1100], rng.integers(3, 129, 120)])
+    d1 = len(lens)
+    user = np.repeat(np.arange(d1), lens)
+    item = np.concatenate([np.sort(rng.choice(d2, n, replace=False)) for n in lens])
+    val = rng.integers(1, 6, user.shape[0]).astype(np.float64)
+    val[user == 12] = 2.0                                                      # a user with all-equal ratings
+    X = oracle.build_csr(d1, d2, user, item, val)
+    U0 = oracle.initial(d1, r) * 0.3; V0 = oracle.initial(d2, r) * 0.3
+    Uo, Vo, ro = oracle.train(X, U0, V0, lam, 2, solver=solver, do_predict=0)
+    ds = pcr.Dataset.from_triplets(d1, d2, user, item, val)
+    with pcr.tuned(ustep_gram=128):
+        s = pcr.Solver(ds, pcr.Parameter(k=r, precision=precision, solver_type=solver, maxiter=2, do_predict=0, **{"lambda": lam}))
+    s.profile(True)
+    s.set_factors(U0, V0)
+    recs, _ = s.train()
+    assert any(name.startswith("ustep/gram") for name in s.profile_all()), "the dual-form class did not run"
+    Ug, Vg = s.get_factors()
+    t = TOL[precision]
+    for a, b in zip(recs, ro):
+        assert abs(a["obj"] / b["obj"] - 1) < max(t["obj"], t["fac"] * 1e-2), (a["obj"], b["obj"])
+    assert rel(Vg, Vo) < t["fac"] and rel(Ug, Uo) < t["fac"]
+    if precision == pcr.PCR_F64:
+        for a, b in zip(recs[1:], ro[1:]):
+            assert (a["cg_v"], a["ls_v"], a["cg_u"], a["ls_u"]) == (b["cg_v"], b["ls_v"], b["cg_u"], b["ls_u"])
+
+
+def test_gram_u_step_line_search_retries(oracle):
+    """The dual form's line search never touches a row of V (m_new = (1 - s alpha_d) m - s K a_delta): with an initial step of
+    50 most users halve several times; counts, objective and factors as the oracle's, and the state it leaves starts the
+    next V step exactly like the per-user kernel's."""
+    R = synth.generate("small", seed=12, d1=300, d2=200, nnz=20000, mu=3.8, sigma=0.8)
+    r, lam, step = 6, 1e-3, 50.0
+    X = oracle.build_csr(R.d1, R.d2, R.user, R.item, R.val)
+    U0 = oracle.initial(R.d1, r); V0 = oracle.initial(R.d2, r)
+    m0 = oracle.comp_m(U0, V0, X)
+    U1, objUo, iu = oracle.update_U_new(X, m0, lam, step, V0, U0)
+    ds = pcr.Dataset.from_ratings(R)
+    with pcr.tuned(ustep_gram=128):
+        s = pcr.Solver(ds, pcr.Parameter(k=r, precision=pcr.PCR_F64, stepsize=step, **{"lambda": lam}))
+    s.set_factors(U0, V0)
+    s.comp_m(want=False)
+    objU, info = s.update_U()
+    Ug, _ = s.get_factors()
+    assert (info["cg"], info["ls"]) == (iu["cg"], iu["ls"]) and iu["ls"] > 2 * R.d1
+    assert abs(objU / objUo - 1) < 1e-9 and rel(Ug, U1) < 1e-7
+    oV, iv = s.update_V()
+    V2, m2, objVo, ivo = oracle.update_V_new(X, lam, step, U1, V0)
+    assert (iv["cg"], iv["ls"]) == (ivo["cg"], ivo["ls"]) and abs(oV / objVo - 1) < 1e-9
