@@ -247,3 +247,54 @@ def test_gpus_option_three_ranks_default_precision(tmp_path):
     assert len(a) == len(b) == 8
     for (t1, e1, n1), (t2, e2, n2) in zip(a, b):
         assert t1 == t2 and abs(float(e1) - float(e2)) < 1e-3 and abs(float(n1) - float(n2)) < 1e-3
+
+
+STUB = os.path.join(ROOT, "oracle", "_ref", "omp-pmf-train-mi355x")
+
+
+def test_integration_stub_links_against_the_reference_objects(tmp_path):
+    """INTEGRATION.md section 1 as a program (oracle/integration_stub.cpp): the reference's own load() / initial() /
+    save_mat_t() objects, its headers, and libprimalcr.so in one binary -- built by oracle/Makefile wherever the reference is
+    present (the GPU box gets the prebuilt file).  Without a GPU it must stop at pcr_solver_create with the library's error."""
+    import torch
+    if not os.path.exists(STUB):
+        pytest.skip("oracle/_ref/omp-pmf-train-mi355x not built (no /root/reference in this container)")
+    ldd = subprocess.run(["ldd", STUB], capture_output=True, text=True).stdout
+    assert "libprimalcr.so" in ldd and "not found" not in ldd
+    d = synth.write_dir(synth.generate("tiny"), str(tmp_path / "data"))
+    r = run([STUB, "-k", "4", d], tmp_path)
+    assert r.returncode == 1 and "usage:" in r.stderr
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the no-GPU failure path needs a machine without one")
+    r = run([STUB, "-k", "4", "-t", "1", d, "m.model"], tmp_path)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+    assert "the number of rows is 60 and the number of cols is 40" in r.stdout      # the reference's loader ran
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", [2, 1])
+def test_integration_stub_reproduces_the_reference_run(solver, tmp_path):
+    """The reference-side binding end to end: reference loader + reference initial() + pcr_train through the C ABI + reference
+    save_mat_t(), against the unmodified binary's golden stdout and model on the same directory (fp64 storage)."""
+    if not os.path.exists(STUB):
+        pytest.skip("oracle/_ref/omp-pmf-train-mi355x not built")
+    g, meta, d = golden_dir("mid5", tmp_path)
+    out = run([STUB, "-s", str(solver), "-k", str(int(g["r"])), "-l", repr(float(g["lam"])), "-t", str(meta["iters"]), "--f64", d, "stub.model"], tmp_path)
+    assert out.returncode == 0, out.stderr
+    strip = lambda text: [l for l in text.split("\n") if l.startswith(("Iter", "(T"))]
+    ours, theirs = strip(out.stdout), strip(meta["stdout_s%d" % solver])
+    assert len(ours) == len(theirs) > 0
+    for a, b in zip(ours, theirs):
+        fa = [float(x) for x in re.findall(NUM, a)]; fb = [float(x) for x in re.findall(NUM, b)]
+        if a.startswith("Iter"):
+            fa, fb = fa[:1] + fa[2:], fb[:1] + fb[2:]                # (the time differs)
+        assert re.sub(NUM, "#", a) == re.sub(NUM, "#", b) and np.allclose(fa, fb, rtol=2e-5, atol=2e-6), (a, b)
+    raw = open(tmp_path / "stub.model", "rb").read()                  # written by the reference's save_mat_t
+    assert len(raw) == meta[f"model_bytes_s{solver}"]
+    d1, k = struct.unpack("ll", raw[:16])
+    U = np.frombuffer(raw, np.float64, d1 * k, 16).reshape(d1, k)
+    off = 16 + 8 * d1 * k
+    d2, k2 = struct.unpack("ll", raw[off:off + 16])
+    V = np.frombuffer(raw, np.float64, d2 * k2, off + 16).reshape(d2, k2)
+    assert np.abs(U - g[f"cli_U_s{solver}"]).max() < 1e-6 * np.abs(U).max()
+    assert np.abs(V - g[f"cli_V_s{solver}"]).max() < 1e-6 * np.abs(V).max()
