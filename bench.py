@@ -210,7 +210,7 @@ def timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, local_rank, args, 
     barrier()
     secs = time.perf_counter() - t0
     if N > 1:
-        tt = torch.tensor([secs], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([secs], device="cuda" if args.rendezvous == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         secs = float(tt.item())
     prof = s.profile_all() if profile else {}
@@ -240,6 +240,10 @@ def main():
     ap.add_argument("--lam", type=float, default=5000.0)
     ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
     ap.add_argument("--comm", choices=["rccl", "p2p"], default="rccl", help="N > 1: ncclAllReduce, or the direct peer-to-peer exchange")
+    ap.add_argument("--devices", default=None, help="HIP device of every local rank, e.g. 0,0 (rehearsal of the N > 1 path on a box with "
+                                                    "fewer GPUs than ranks; needs --comm p2p and --rendezvous gloo: RCCL refuses two ranks on one device)")
+    ap.add_argument("--rendezvous", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend of the barriers and the id broadcast")
+    ap.add_argument("--tune", action="append", default=[], help="key=value launch knob (pcr_tune), repeatable -- for A/B runs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-f64", action="store_true", help="skip the second timed run in the reference's arithmetic type")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
@@ -260,11 +264,15 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the training path)")
-    torch.cuda.set_device(local_rank)
+    device = int(args.devices.split(",")[local_rank]) if args.devices else local_rank
+    torch.cuda.set_device(device)
     dist = None
     if N > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rendezvous == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
 
     if local_rank == 0 and not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "primalcr_amd", "lib", "libprimalcr.so")):
         import __graft_entry__                   # clean checkout: compile the product first (no fallback exists)
@@ -274,6 +282,8 @@ def main():
     import primalcr_amd as pcr
     from primalcr_amd import synth
 
+    for kv in args.tune:
+        pcr.tune(*kv.split("=", 1))
     r, lam = args.rank_k or (200 if args.shape == "yahoo" else 100), args.lam
     t0 = time.time()
     if args.shape == "ml1m":
@@ -294,14 +304,14 @@ def main():
     shm = [f"/pcr_bench_{os.getpid()}" if rank == 0 else None]
     if N > 1:
         dist.broadcast_object_list(shm, src=0)
-    run = timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, local_rank, args, not args.no_profile, shm[0])
+    run = timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, device, args, not args.no_profile, shm[0])
     # the same workload in the reference's arithmetic type (fp64 storage as well as fp64 accumulation), timed the same way
     run64 = None
     if prec == pcr.PCR_F32 and not args.no_f64:
-        run64 = timed_run(pcr, torch, dist, ds, R, r, lam, pcr.PCR_F64, rank, N, local_rank, args, False, shm[0])
+        run64 = timed_run(pcr, torch, dist, ds, R, r, lam, pcr.PCR_F64, rank, N, device, args, False, shm[0])
     # diagnostic replay of the same iterations with the U-step kernels counting the rows of V they gather (an extra atomic per
     # user, so it is kept out of the timed run): the rating-weighted pass count of the U step
-    run["u_rows"] = timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, local_rank, args, False, shm[0], count_rows=True)["u_rows"]
+    run["u_rows"] = timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, device, args, False, shm[0], count_rows=True)["u_rows"]
     secs, objs, inner, prof = run["secs"], run["objs"], run["inner"], run["prof"]
     te_err, te_ndcg = run["te"]; tr_err, tr_ndcg = run["tr"]
     prof_period = run["prof_period"]

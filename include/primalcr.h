@@ -152,6 +152,7 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *   ubins           "cap:block:resident,..." length classes of the U step below 1024 ratings
  *   spmm_tiles, spmm_chunk, sddmm_tile, sddmm_csc   tiling of the rating-parallel kernels
  *   sweep_wave_cap  ratings up to which a sweep gives a user one wave
+ *   wide_teams      1 = 1024-thread workgroups in the merged prepare and sweep launches (default 0: 512)
  *   window_cache    0 = sweeps search their hinge windows instead of caching them
  *   prepare_merged  0 = one prepare launch per length class
  *   lanes           concurrent streams for length classes (1 = none);  pipeline: 0 = host round trip after every U step

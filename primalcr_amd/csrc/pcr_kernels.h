@@ -838,20 +838,20 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const in
 // Both LDS-resident classes in ONE launch of 512-thread workgroups: workgroups [0, nblk_b) take the long users of list B
 // one per workgroup, the others eight short users of list A each, one per wave (a one-wave team needs no workgroup
 // barrier).  One launch instead of one per class on concurrent streams: no fork / join around the line search.
-template <typename T>
-__global__ __launch_bounds__(512) void k_prepare_all(Shard<T> S, const int32_t* __restrict__ users_a, int nusers_a, int cap_a,
+template <typename T, int WB>
+__global__ __launch_bounds__(WB) void k_prepare_all(Shard<T> S, const int32_t* __restrict__ users_a, int nusers_a, int cap_a,
                                                      int cap_pad_a, int rs_cap_a, size_t wave_bytes,
                                                      const int32_t* __restrict__ users_b, int nusers_b, int cap_b, int cap_pad_b,
                                                      int rs_cap_b, int nblk_b, const T* __restrict__ m_in, int strict,
                                                      const uint8_t* __restrict__ only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < nblk_b)
-        prepare_body<T, 512, false>(smem, S, users_b, nusers_b, m_in, cap_b, cap_pad_b, rs_cap_b, nullptr, 0, strict,
-                                    (int)blockIdx.x, nblk_b, only);
+        prepare_body<T, WB, false>(smem, S, users_b, nusers_b, m_in, cap_b, cap_pad_b, rs_cap_b, nullptr, 0, strict,
+                                   (int)blockIdx.x, nblk_b, only);
     else
         prepare_body<T, 64, false>(smem + (size_t)(threadIdx.x >> 6) * wave_bytes, S, users_a, nusers_a, m_in, cap_a, cap_pad_a,
-                                   rs_cap_a, nullptr, 0, strict, ((int)blockIdx.x - nblk_b) * 8 + (int)(threadIdx.x >> 6),
-                                   ((int)gridDim.x - nblk_b) * 8, only);
+                                   rs_cap_a, nullptr, 0, strict, ((int)blockIdx.x - nblk_b) * (WB / 64) + (int)(threadIdx.x >> 6),
+                                   ((int)gridDim.x - nblk_b) * (WB / 64), only);
 
 }
 
@@ -986,8 +986,8 @@ __global__ __launch_bounds__(256) void k_vsweep_wave(Shard<T> S, const int32_t* 
 // Both LDS-resident classes in ONE launch of 512-thread workgroups (the two sweeps are each shorter than a launch
 // round trip, so back to back they cost two kernel latencies and side by side a fork/join): workgroups [0, nblk_b)
 // take the long users of list B one per workgroup, the others take eight short users of list A, one per wave.
-template <typename T, bool HV>
-__global__ __launch_bounds__(512) void k_vsweep_all(Shard<T> S, const int32_t* __restrict__ users_a, int nusers_a, int cap_a,
+template <typename T, bool HV, int WB>
+__global__ __launch_bounds__(WB) void k_vsweep_all(Shard<T> S, const int32_t* __restrict__ users_a, int nusers_a, int cap_a,
                                                     int rs_cap_a, size_t wave_bytes, const int32_t* __restrict__ users_b,
                                                     int nusers_b, int cap_b, int rs_cap_b, int nblk_b,
                                                     const T* __restrict__ bsrc, T* __restrict__ c_out, int strict, const int* skip,
@@ -995,11 +995,11 @@ __global__ __launch_bounds__(512) void k_vsweep_all(Shard<T> S, const int32_t* _
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (skip && *skip) return;
     if ((int)blockIdx.x < nblk_b)
-        vsweep_block_body<T, 512, false, HV>(smem, S, users_b, nusers_b, bsrc, c_out, cap_b, rs_cap_b, nullptr, 0, strict,
-                                             (int)blockIdx.x, nblk_b, only, b_csr);
+        vsweep_block_body<T, WB, false, HV>(smem, S, users_b, nusers_b, bsrc, c_out, cap_b, rs_cap_b, nullptr, 0, strict,
+                                            (int)blockIdx.x, nblk_b, only, b_csr);
     else
         vsweep_wave_body<T, HV>(smem, S, users_a, nusers_a, bsrc, c_out, cap_a, rs_cap_a, wave_bytes, strict,
-                                ((int)blockIdx.x - nblk_b) * 8 + (int)(threadIdx.x >> 6), only, b_csr);
+                                ((int)blockIdx.x - nblk_b) * (WB / 64) + (int)(threadIdx.x >> 6), only, b_csr);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -138,7 +138,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = 1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
-        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0;
+        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -149,6 +149,7 @@ struct Tune {
         pipeline = pcr_tune_int("pipeline", 1); debug = pcr_tune_int("debug", 0); fault_cluster_member = pcr_tune_int("fault_cluster_member", 0);
         ustep_lockstep = pcr_tune_int("ustep_lockstep", -1);
         ustep_gram = pcr_tune_int("ustep_gram", -1); count_rows = pcr_tune_int("count_rows", 0);
+        wide_teams = pcr_tune_int("wide_teams", -1);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -190,6 +191,7 @@ struct Solver final : pcr_solver {
     int spmm_blocks = 0, spmm_tiles = 1;
     bool sddmm_csc = false;                       // the CG's SDDMM walks the SpMM's tile-major CSC (item table beyond the L2s)
     DBuf<T> d_slab;                               // k_spmm partial rows, one per (chunk, item) incidence
+    bool wide_teams = false;                      // k_prepare_all / k_vsweep_all: 1024-thread teams for the long users (few of them)
     int spmm_chunk = 128;
     int sddmm_tile = 0;                           // ratings per lane group of k_sddmm (0 = not chosen yet)
     DBuf<uint16_t> d_lvl, d_slvl;
@@ -587,6 +589,9 @@ struct Solver final : pcr_solver {
         const int prep_wave_cap = 256;
         make_bins(uptr, nu, &lv.run_ofs, pbins, {prep_wave_cap, 4096}, {64, 512, 512});
         for (auto& b : pbins) RC(b.d_users.upload(b.users, st));
+        // (measured, ml1m: 1024-thread teams make both launches slower -- k_vsweep_all 23 -> 31 us, k_prepare_all 99 -> 133 us:
+        // sixteen one-wave users per workgroup cost more occupancy than the longest user's chain gains -- so 512 stays)
+        wide_teams = tune.wide_teams > 0;
         // U step: users with more than 1024 ratings are bound by one CU's gather bandwidth -> clusters of 4 workgroups
         // The U step keeps each user's rows of V in LDS (k_ustep, stage_rows), so its occupancy is set by LDS bytes, not
         // registers: finer length classes than the V side, and a workgroup size that grows with the class.
@@ -861,11 +866,14 @@ struct Solver final : pcr_solver {
     int set_lds_limits() {
         const int lim = 160 * 1024;
         HIPCHK(hipFuncSetAttribute((const void*)k_prepare<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        HIPCHK(hipFuncSetAttribute((const void*)k_prepare_all<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_prepare_all<T, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_prepare_all<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 512, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 512, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
 #define UL(BL, BG, KK, RS, UN) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, BL, BG, KK, RS, UN>, hipFuncAttributeMaxDynamicSharedMemorySize, lim))
         UL(64, false, 1, true, 4); UL(64, false, 1, false, 4); UL(256, false, 1, false, 4);
         UL(512, false, 1, true, 8); UL(512, false, 1, false, 4); UL(512, false, 4, true, 8);
@@ -1053,11 +1061,17 @@ struct Solver final : pcr_solver {
             const int na = (int)ba.users.size(), nb = (int)bb.users.size();
             const int cpa = host_pow2(ba.cap), cpb = host_pow2(bb.cap), rsa = ba.max_lev + 2, rsb = bb.max_lev + 2;
             const size_t wb = (small_common(64) + prepare_bytes<T>(ba.cap, cpa, rsa, 4) + 15) & ~(size_t)15;
-            const size_t lds = std::max(wb * 8, small_common(512) + prepare_bytes<T>(bb.cap, cpb, rsb, 4));
+            // workgroup size of the launch = the long users' teams: 512 threads (1024 behind pcr_tune("wide_teams"): measured slower)
+            const int wbs = wide_teams ? 1024 : 512, wpb = wbs / 64;
+            const size_t lds = std::max(wb * wpb, small_common(wbs) + prepare_bytes<T>(bb.cap, cpb, rsb, 4));
             {
                 ProfScope ps(this, only ? "u:prepare" : "prepare/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
-                hipLaunchKernelGGL((k_prepare_all<T>), dim3(nb + cdiv(na, 8)), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, cpa, rsa, wb,
-                                   bb.d_users.p, nb, bb.cap, cpb, rsb, nb, d_mcsr.p, strict(), only);
+                if (wide_teams)
+                    hipLaunchKernelGGL((k_prepare_all<T, 1024>), dim3(nb + cdiv(na, wpb)), dim3(1024), lds, st, sh, ba.d_users.p, na, ba.cap, cpa, rsa, wb,
+                                       bb.d_users.p, nb, bb.cap, cpb, rsb, nb, d_mcsr.p, strict(), only);
+                else
+                    hipLaunchKernelGGL((k_prepare_all<T, 512>), dim3(nb + cdiv(na, wpb)), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, cpa, rsa, wb,
+                                       bb.d_users.p, nb, bb.cap, cpb, rsb, nb, d_mcsr.p, strict(), only);
             }
             if (!pbins[2].users.empty()) { ProfScope ps(this, pname("prepare", pbins[2]), st, pbins[2].nnz, (int64_t)pbins[2].users.size()); fn(pbins[2], st); }
             HIPCHK(hipGetLastError());
@@ -1102,14 +1116,16 @@ struct Solver final : pcr_solver {
             const int na = (int)ba.users.size(), nb = (int)bb.users.size();
             const int rsa = ba.max_lev + 2, rsb = bb.max_lev + 2;
             const size_t wb = (vsweep_wave_bytes<T>(ba.cap, rsa, two) + 15) & ~(size_t)15;
-            const size_t lds = std::max(wb * 8, small_common(512) + vsweep_bytes<T>(bb.cap, rsb, two));
-            const int grid = nb + cdiv(na, 8);
+            const int wbs = wide_teams ? 1024 : 512, wpb = wbs / 64;
+            const size_t lds = std::max(wb * wpb, small_common(wbs) + vsweep_bytes<T>(bb.cap, rsb, two));
+            const int grid = nb + cdiv(na, wpb);
             {
                 ProfScope ps(this, only ? std::string("u:sweep") : std::string(hv ? "vhv" : "vgrad") + "/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
-                if (hv) hipLaunchKernelGGL((k_vsweep_all<T, true>), dim3(grid), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, rsa, wb,
-                                           bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip, only, bc);
-                else hipLaunchKernelGGL((k_vsweep_all<T, false>), dim3(grid), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, rsa, wb,
-                                        bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip, only, bc);
+#define LVA(HV, WBS) hipLaunchKernelGGL((k_vsweep_all<T, HV, WBS>), dim3(grid), dim3(WBS), lds, st, sh, ba.d_users.p, na, ba.cap, rsa, wb, \
+                                        bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip, only, bc)
+                if (hv) { if (wide_teams) LVA(true, 1024); else LVA(true, 512); }
+                else { if (wide_teams) LVA(false, 1024); else LVA(false, 512); }
+#undef LVA
             }
             if (!sbins[2].users.empty()) { ProfScope ps(this, pname(hv ? "vhv" : "vgrad", sbins[2]), st, sbins[2].nnz, (int64_t)sbins[2].users.size()); fn(sbins[2], st); }
             HIPCHK(hipGetLastError());
