@@ -54,18 +54,18 @@ def algorithmic_bytes(slot, nnz_b, nu_b, d2, r, esz):
     cls = slot.split("/")[0]
     if cls == "sddmm":             # k_sddmm: read item ids, user ids, U, one item-side matrix; write one score per rating
         return nnz_b * (4 + 4 + esz) + F_U + F_V
-    if cls == "prepare":           # k_prepare: read m,lvl,item,cpos; write ms,sitem,slvl,cinv; objp
-        return nnz_b * (esz + 2 + 4 + 4) + nnz_b * (esz + 4 + 2 + 4) + nu_b * 24
-    if cls == "vgrad":             # k_vsweep<GRAD>: read ms,slvl; write c
-        return nnz_b * (esz + 2 + esz) + nu_b * 16
-    if cls == "vhv":               # k_vsweep<HV>: read b,slvl; write c
-        return nnz_b * (esz + 2 + esz) + nu_b * 16
-    if cls == "spmm":              # k_spmm: read c (through cinv), cuser, crow, U rows; write the partial-row slab
-        return nnz_b * (esz + 4 + 4 + 4) + F_U + F_V
+    if cls == "prepare":           # k_prepare: read m,lvl,item; write ms,sitem,slvl,sidx; objp  (the window cache is extra)
+        return nnz_b * (esz + 2 + 4) + nnz_b * (esz + 4 + 2 + 4) + nu_b * 24
+    if cls == "vgrad":             # k_vsweep<GRAD>: read ms,sidx; write c
+        return nnz_b * (esz + 4 + esz) + nu_b * 16
+    if cls == "vhv":               # k_vsweep<HV>: read b,sidx; write c
+        return nnz_b * (esz + 4 + esz) + nu_b * 16
+    if cls == "spmm":              # k_spmm: read c (through the static CSC->CSR map), user|flag word, U rows; write one row per item
+        return nnz_b * (esz + 4 + 4) + F_U + F_V
     if cls == "spmm_fin":          # k_spmm_fin: read slab + base, write out
         return 3 * F_V
-    if cls == "ustep":             # k_ustep: read ms,sitem,slvl,U,V; write U,objp
-        return nnz_b * (esz + 4 + 2) + nu_b * 24 + 2 * F_U + F_V
+    if cls == "ustep":             # k_ustep: read ms,sitem,slvl,U,V; write U,objp and the sorted state of u_new (ms,sitem,slvl,sidx)
+        return nnz_b * (esz + 4 + 2) + nnz_b * (esz + 4 + 2 + 4) + nu_b * 24 + 2 * F_U + F_V
     if cls == "cg":                # k_cg_bc: read p,Hp,rr,delta, write delta,rr,p
         return 7 * F_V
     return 0
