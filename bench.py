@@ -72,7 +72,7 @@ def algorithmic_bytes(slot, nnz_b, nu_b, d2, r, esz):
 
 
 # HIP-event slot -> kernel symbol prefix in a rocprofv3 trace (profiles/, tools/pmc_traffic.py)
-SLOT_KERNEL = {"sddmm": "void k_sddmm<", "spmm": "void k_spmm<", "spmm_fin": "void k_spmm_fin<", "prepare": "void k_prepare<",
+SLOT_KERNEL = {"sddmm": "void k_sddmm<", "spmm": "void k_spmm<", "spmm_fin": "void k_spmm_fin<", "prepare": "void k_prepare",
                "vgrad": "void k_vsweep", "vhv": "void k_vsweep", "ustep": "void k_ustep<", "cg": "void k_cg_"}
 
 
