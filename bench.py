@@ -301,7 +301,7 @@ def main():
         log(f"[data] {args.shape}-shaped x{N}: {R.d1} users x {R.d2} items, {R.nnz} ratings, {n_pairs} ordered pairs, "
             f"{len(R.tval)} test ratings ({time.time() - t0:.1f}s)")
     prec = pcr.PCR_F32 if args.precision == "f32" else pcr.PCR_F64
-    shm = [f"/pcr_bench_{os.getpid()}" if rank == 0 else None]
+    shm = [f"/pcr_bench_{os.getpid()}_{int(time.time()) % 100000}" if rank == 0 else None]
     if N > 1:
         dist.broadcast_object_list(shm, src=0)
     run = timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, device, args, not args.no_profile, shm[0])

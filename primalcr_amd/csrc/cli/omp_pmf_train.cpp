@@ -169,6 +169,7 @@ static int train_multi(const pcr_dataset* ds, const pcr_params& param, int gpus,
     SharedHdr* hdr = new (mem) SharedHdr();
     hdr->id_ready.store(0); hdr->failed.store(0); hdr->nranks_reported.store(0);
     snprintf(hdr->shm_name, sizeof hdr->shm_name, "/pcr_p2p_%d", (int)getpid());
+    shm_unlink(hdr->shm_name);                           // (a stale segment of a crashed job that had this pid)
     double* Ush = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(hdr + 1) + 63) & ~(uintptr_t)63);
     double* Vsh = Ush + nU;
     fflush(stdout); fflush(stderr);
@@ -200,6 +201,7 @@ static int train_multi(const pcr_dataset* ds, const pcr_params& param, int gpus,
             for (pid_t k : kids) if (k != pid) kill(k, SIGTERM);
         }
     }
+    shm_unlink(hdr->shm_name);                           // (rank 0 unlinks it once everyone is attached; a job that failed earlier did not)
     if (bad) { fprintf(stderr, "omp-pmf-train: a GPU worker failed\n"); munmap(mem, bytes); return 1; }
     if (hdr->nranks_reported.load() != gpus) {
         fprintf(stderr, "omp-pmf-train: the communicator reports %d ranks, expected %d\n", hdr->nranks_reported.load(), gpus);

@@ -235,12 +235,13 @@ def test_gpus_option_two_ranks_on_one_gpu_equal_one_rank(solver, tmp_path):
 
 
 @pytest.mark.gpu
-def test_gpus_option_three_ranks_default_precision(tmp_path):
-    """Three ranks on the one GPU in the default precision (fp32 storage): quality lines within 1e-3 of one rank."""
+@pytest.mark.parametrize("n", [3, 5])
+def test_gpus_option_three_ranks_default_precision(n, tmp_path):
+    """Three / five ranks on the one GPU in the default precision (fp32 storage): quality lines within 1e-3 of one rank."""
     g, meta, d = golden_dir("mid5", tmp_path)
     base = [TRAIN, "-k", str(int(g["r"])), "-l", repr(float(g["lam"])), "-t", "3"]
     one = run(base + [d, "one.model"], tmp_path)
-    three = run(base + ["--gpus", "3", "--devices", "0,0,0", "--comm", "p2p", d, "three.model"], tmp_path)
+    three = run(base + ["--gpus", str(n), "--devices", ",".join(["0"] * n), "--comm", "p2p", d, "three.model"], tmp_path)
     assert one.returncode == 0 and three.returncode == 0, three.stderr
     pat = r"^\((Training|Testing)\) pairwise error is (\S+) and ndcg is (\S+)$"
     a = re.findall(pat, one.stdout, re.M); b = re.findall(pat, three.stdout, re.M)
