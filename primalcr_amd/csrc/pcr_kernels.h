@@ -314,7 +314,8 @@ __device__ __forceinline__ int level_of(const int* rs, int nlev, int p) {
 }
 
 // sweep_coeff with cached boundaries (w: ws slots of this item)
-__device__ __forceinline__ double sweep_coeff_win(const uint32_t* __restrict__ w, const double* S, const int* rs, int nlev,
+template <typename W>
+__device__ __forceinline__ double sweep_coeff_win(const W* __restrict__ w, const double* S, const int* rs, int nlev,
                                                   int lev, double xp, double shift) {
     double acc = 0.0;
     for (int l = 0; l < lev; ++l) {
@@ -1430,7 +1431,8 @@ template <typename T, int BLOCK, bool BIG, int K, bool RES, int UNR>
 __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                  T* __restrict__ U, const T* __restrict__ Vm, double lambda, double stepsize0,
                                                  int cg_max, double cg_tol, int strict, int solver1, int cap, int cap_pad, int rs_cap, int rcap, int nchp,
-                                                 char* scratch, size_t stride, unsigned long long* counters, ClusterBufs cb, int fault) {
+                                                 char* scratch, size_t stride, unsigned long long* counters, ClusterBufs cb, int fault,
+                                                 int wcap) {
     typedef typename LiSel<T, BIG>::type LI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // test hook (pcr_tune "fault_cluster_member"): the last member of every cluster leaves at once, so that the others run
@@ -1453,6 +1455,10 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
     constexpr int VEC = VecOf<T>::N;
     const int lstride = nchp * VEC;
     T* rowsL = small.take<T>((size_t)rcap * lstride);
+    // LDS copy of the user's window rows (16-bit: LDS-resident users have fewer than 65536 ratings): the gradient sweep and
+    // every CG sweep read them -- from global memory that is one dependent round trip per sweep, ~2.5 us each while the other
+    // length classes keep the memory pipe busy (wcap = 0: no copy, e.g. the global-scratch classes)
+    uint16_t* winL = small.take<uint16_t>((size_t)wcap);
     Carver big(BIG ? scratch + (size_t)blockIdx.x * stride : small.p);
     T* ms0 = big.take<T>(cap);
     T* key = big.take<T>(cap_pad);
@@ -1531,15 +1537,18 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         for (int t = tid; t < ld; t += BLOCK) uvec[t] = (double)U[(size_t)u * ld + t];
         for (int p = tid; p < n; p += BLOCK) { ms0[p] = S.ms[s0 + p]; lv0[p] = S.slvl[s0 + p]; itm[p] = S.sitem[s0 + p]; }
         for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
+        const uint32_t* win = S.ws ? S.win + (size_t)s0 * S.ws : nullptr;       // windows of the gradient point
+        const bool wl = win && wcap >= n * S.ws;
+        if (wl) for (int i = tid; i < n * S.ws; i += BLOCK) winL[i] = (uint16_t)win[i];
         __syncthreads();
         if (RES && q1 > q0) stage_rows<T, BLOCK>(Vm, itm, q0, q1, rowsL, geo, nchp);      // lands while the gradient sweep runs
         UPROF(0);
         // ---- gradient coefficients, obtain_g_u_new (pcrpp.cpp:506-535)
         block_excl_scan<BLOCK>([&](int i) { return (double)ms0[i]; }, Sx, n, red);
-        const uint32_t* win = S.ws ? S.win + (size_t)s0 * S.ws : nullptr;       // windows of the gradient point
         for (int p = tid; p < n; p += BLOCK)
-            key[p] = (T)(win ? sweep_coeff_win(win + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)ms0[p], 1.0)
-                             : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)ms0[p], 1.0, strict));
+            key[p] = (T)(wl ? sweep_coeff_win(winL + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)ms0[p], 1.0)
+                         : win ? sweep_coeff_win(win + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)ms0[p], 1.0)
+                               : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)ms0[p], 1.0, strict));
         for (int t = tid; t < ld; t += BLOCK) gvec[t] = (n == 0) ? 0.0 : uvec[t] * lambda;   // :495-498
         if (RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the LDS-DMA of stage_rows
         __syncthreads();
@@ -1576,8 +1585,9 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                 UPROF(3);
                 block_excl_scan<BLOCK>([&](int i) { return (double)key[i]; }, Sx, n, red);
                 for (int p = tid; p < n; p += BLOCK)
-                    key[p] = (T)(win ? sweep_coeff_win(win + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)key[p], 0.0)
-                                     : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)key[p], 0.0, strict));
+                    key[p] = (T)(wl ? sweep_coeff_win(winL + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)key[p], 0.0)
+                                 : win ? sweep_coeff_win(win + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)key[p], 0.0)
+                                       : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)key[p], 0.0, strict));
                 __syncthreads();
                 UPROF(4);
                 gather_axpy(key, Hp);

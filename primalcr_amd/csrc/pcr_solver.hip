@@ -85,6 +85,7 @@ struct Bin {
     int rcap = 0;        // k_ustep: rows of V a workgroup keeps resident in LDS
     int unr = 4;         // k_ustep: rows in flight per lane group (8: latency-bound class, one workgroup per CU)
     bool gram = false;   // k_ustep_gram: the dual (Gram-matrix, MFMA) form for users with few ratings
+    int wcap = 0;        // k_ustep: 16-bit window entries cached in LDS (cap * ws, or 0)
     int max_lev = 0;
     int64_t nnz = 0;     // ratings of the users in the bin
     std::vector<int32_t> users;
@@ -138,7 +139,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = 1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
-        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1;
+        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -149,7 +150,7 @@ struct Tune {
         pipeline = pcr_tune_int("pipeline", 1); debug = pcr_tune_int("debug", 0); fault_cluster_member = pcr_tune_int("fault_cluster_member", 0);
         ustep_lockstep = pcr_tune_int("ustep_lockstep", -1);
         ustep_gram = pcr_tune_int("ustep_gram", -1); count_rows = pcr_tune_int("count_rows", 0);
-        wide_teams = pcr_tune_int("wide_teams", -1);
+        wide_teams = pcr_tune_int("wide_teams", -1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -699,6 +700,8 @@ struct Solver final : pcr_solver {
             b.ugrid = b.K > 1 ? std::min(nus, std::max(1, ncu / b.K)) * b.K : (b.big ? std::min(nus, 2 * ncu) : nus);
             if (b.big) { b.scratch_ofs = u_big_blocks; u_big_blocks += b.ugrid; }
         }
+        // window cache (pcr_kernels.h, Shard::win): one slot per other level, up to 9 levels
+        const int sh_ws_for_bins = (tune.window_cache && lv.max_levels >= 2 && lv.max_levels <= 9) ? lv.max_levels - 1 : 0;
         {   // LDS residency: what is left of the 160 KB after the r-vectors and the per-rating arrays, in rows of V
             const int nchp = geo.nchunk | 1;
             const size_t lim = 160 * 1024;
@@ -708,7 +711,14 @@ struct Solver final : pcr_solver {
                 // the LDS image pays where LDS is spare: the one-wave classes of <= 64 ratings, and the latency-bound
                 // 512-thread classes (one workgroup per CU anyway), which keep as many rows as fit beside their arrays
                 const int res_on = bi < nsmall ? (b.block == 64 ? ures[bi] : 0) : (b.unr == 8);
-                const size_t fixed = ustep_small_bytes(geo.ld, b.block, sizeof(T)) +
+                // the window rows of the class's longest user in LDS (16 bit), where that still leaves the class its occupancy:
+                // every class of at most 1024 ratings (8 KB), the one-workgroup-per-CU classes whatever their length
+                b.wcap = 0;
+                if (tune.ustep_win_lds && !b.big && sh_ws_for_bins > 0 && (b.cap <= 1024 || b.unr == 8) &&
+                    ustep_small_bytes(geo.ld, b.block, sizeof(T)) + ustep_big_bytes<T>(b.cap, host_pow2(b.cap), b.max_lev + 2, 4) +
+                        carve_bytes((size_t)b.cap * sh_ws_for_bins, 2) <= lim - 8 * 1024)
+                    b.wcap = b.cap * sh_ws_for_bins;
+                const size_t fixed = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + carve_bytes(b.wcap, 2) +
                                      (b.big ? 0 : ustep_big_bytes<T>(b.cap, host_pow2(b.cap), b.max_lev + 2, 4));
                 const int64_t room = fixed < lim ? (int64_t)((lim - fixed) / ((size_t)nchp * 16)) : 0;
                 const int64_t want = (b.cap + b.K - 1) / b.K;                  // longest slice a member gathers
@@ -741,9 +751,7 @@ struct Solver final : pcr_solver {
         sh.ms = d_ms.p; sh.sitem = d_sitem.p; sh.slvl = d_slvl.p; sh.objp = d_objp.p;
         RC(d_sidx.alloc(nnz_local)); RC(d_objr.alloc(nu));
         sh.sidx = d_sidx.p; sh.objr = d_objr.p;
-        // window cache (pcr_kernels.h, Shard::win): one slot per other level, up to 9 levels
-        sh.ws = (lv.max_levels >= 2 && lv.max_levels <= 9) ? lv.max_levels - 1 : 0;
-        if (!tune.window_cache) sh.ws = 0;
+        sh.ws = sh_ws_for_bins;
         RC(d_win.alloc((size_t)nnz_local * sh.ws));
         sh.win = d_win.p;
 
@@ -1478,14 +1486,14 @@ struct Solver final : pcr_solver {
             const int nus = (int)b.users.size();
             const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
             const int nchp = geo.nchunk | 1;
-            const size_t lds = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + ustep_rows_bytes(b.rcap, nchp) +
+            const size_t lds = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + ustep_rows_bytes(b.rcap, nchp) + carve_bytes(b.wcap, 2) +
                                (b.big ? 0 : ustep_big_bytes<T>(b.cap, cap_pad, rsc, 4));
             const size_t bi = (size_t)(&b - &ubins[0]);
             ClusterBufs cb{bar_p + bi * max_clusters, d_xch.p + bi * max_clusters * xch_stride, xch_stride};
             // clusters: grid <= one workgroup per CU so that every member of every cluster is resident
             const int grid = b.ugrid;
             char* scr = d_scratch.p + (size_t)b.scratch_ofs * scratch_stride;
-#define LU(BL, BG, KK, RS, UN) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb, (tune.fault_cluster_member ? 1 : 0) | (tune.count_rows ? 2 : 0))
+#define LU(BL, BG, KK, RS, UN) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb, (tune.fault_cluster_member ? 1 : 0) | (tune.count_rows ? 2 : 0), b.wcap)
             if (b.gram) {
                 const size_t gl = gram_bytes<T>(b.cap, cap_pad, rsc, geo.ld, nchp, b.block);
                 if (b.block == 64)
