@@ -154,6 +154,7 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *   sweep_wave_cap  ratings up to which a sweep gives a user one wave
  *   wide_teams      1 = 1024-thread workgroups in the merged prepare and sweep launches (default 0: 512)
  *   window_cache    0 = sweeps search their hinge windows instead of caching them
+ *   win16           0 = 32-bit window-cache entries even when every user has fewer than 65536 ratings (default 1: 16-bit)
  *   ustep_win_lds   0 = k_ustep reads the window cache from global memory in every sweep (default 1: LDS copy)
  *   prepare_merged  0 = one prepare launch per length class
  *   lanes           concurrent streams for length classes (1 = none);  pipeline: 0 = host round trip after every U step

@@ -133,9 +133,9 @@ __global__ __launch_bounds__(BLOCK) void k_ustep_gram(Shard<T> S, Geo geo, const
         if (n > 0) stage_rows<T, BLOCK>(Vm, itm, 0, n, X, geo, nchp);             // lands while the gradient sweep runs
         // ---- gradient coefficients (obtain_g_u_new, pcrpp.cpp:506-535): g = lambda u + X^T c
         block_excl_scan<BLOCK>([&](int i) { return md[i]; }, Sx, n, red);
-        const uint32_t* win = S.ws ? S.win + (size_t)s0 * S.ws : nullptr;
+        const bool win = S.ws != 0;
         for (int p = tid; p < n; p += BLOCK)
-            cc[p] = win ? sweep_coeff_win(win + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], md[p], 1.0)
+            cc[p] = win ? sweep_coeff_cached<T>(S, (size_t)s0 + p, Sx, rs, nlev, lv0[p], md[p], 1.0)
                         : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], md[p], 1.0, strict);
         UPROF(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // the LDS-DMA of stage_rows
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep_gram(Shard<T> S, Geo geo, const
                 __syncthreads();
                 block_excl_scan<BLOCK>([&](int i) { return bb[i]; }, Sx, n, red);
                 for (int p = tid; p < n; p += BLOCK)
-                    cc[p] = win ? sweep_coeff_win(win + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], bb[p], 0.0)
+                    cc[p] = win ? sweep_coeff_cached<T>(S, (size_t)s0 + p, Sx, rs, nlev, lv0[p], bb[p], 0.0)
                                 : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], bb[p], 0.0, strict);
                 __syncthreads();
                 UPROF(4);
@@ -295,7 +295,6 @@ __global__ __launch_bounds__(BLOCK) void k_ustep_gram(Shard<T> S, Geo geo, const
             int32_t* stage = reinterpret_cast<int32_t*>(Sx);
             for (int p = tid; p < n; p += BLOCK) stage[p] = S.sidx[s0 + LiOps<LI>::idx(li[p])];
             __syncthreads();
-            uint32_t* wout = S.ws ? S.win + (size_t)s0 * S.ws : nullptr;
             for (int p = tid; p < n; p += BLOCK) {
                 const LI x = li[p];
                 const int lev = (int)LiOps<LI>::lev(x);
@@ -303,7 +302,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep_gram(Shard<T> S, Geo geo, const
                 S.slvl[s0 + p] = (uint16_t)lev;
                 S.sitem[s0 + p] = itm[LiOps<LI>::idx(x)];
                 S.sidx[s0 + p] = stage[p];
-                if (wout) find_windows<T>(key, rs, nlev, lev, key[p], strict, wout + (size_t)p * S.ws);
+                if (S.ws) store_windows<T>(S, (size_t)s0 + p, key, rs, nlev, lev, key[p], strict);
             }
         }
         for (int t = tid; t < ld; t += BLOCK) U[(size_t)u * ld + t] = (T)unew[t];

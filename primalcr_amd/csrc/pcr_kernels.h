@@ -71,8 +71,10 @@ struct Shard {
     // finds it once and every sweep of the V step (gradient + <=10 Hessian-vector products) and of
     // the U step (gradient, objective, CG) reuses it.  ws = slots per item (0 = cache disabled:
     // too many levels; the sweeps then search).
-    uint32_t* win;             // nnz * ws
-    int ws;
+    // Entries are positions inside the user: 16 bits wide when no user of the shard has 65536 ratings or more (w16),
+    // else 32 -- half the bytes of what is the largest per-rating array of the state (4 slots x 5 levels).
+    void* win;                 // nnz * ws entries of uint16_t (w16) or uint32_t
+    int ws, w16;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -288,29 +290,21 @@ __device__ __forceinline__ double sweep_coeff(const T* ms, const double* S, cons
 }
 
 // boundaries of item (lev, mp) in every other run -> w[slot]
-template <typename T>
-__device__ __forceinline__ void find_windows(const T* ms, const int* rs, int nlev, int lev, T mp, int strict, uint32_t* w) {
+template <typename T, typename W>
+__device__ __forceinline__ void find_windows(const T* ms, const int* rs, int nlev, int lev, T mp, int strict, W* w) {
     const T lo = mp - (T)1, hi = mp + (T)1;
     for (int l = 0; l < nlev; ++l) {
         if (l == lev) continue;
         const int s = rs[l], e = rs[l + 1];
-        if (l < lev) w[l] = (uint32_t)(strict ? ubound(ms, s, e, lo) : lbound(ms, s, e, lo));
-        else w[l - 1] = (uint32_t)(strict ? lbound(ms, s, e, hi) : ubound(ms, s, e, hi));
+        if (l < lev) w[l] = (W)(strict ? ubound(ms, s, e, lo) : lbound(ms, s, e, lo));
+        else w[l - 1] = (W)(strict ? lbound(ms, s, e, hi) : ubound(ms, s, e, hi));
     }
 }
-
-// level of sorted position p = the run it lies in (rs: run boundaries in LDS).  With the few levels of star ratings this is
-// cheaper than a 2-byte global load per rating, and the sweeps then read ONE per-rating index stream (sidx) where they
-// used to read one (slvl) before c went out in CSR order.
-__device__ __forceinline__ int level_of(const int* rs, int nlev, int p) {
-    if (nlev <= 8) {
-        int lev = 0;
-        for (int l = 1; l < nlev; ++l) lev += (p >= rs[l]) ? 1 : 0;
-        return lev;
-    }
-    int lo = 0, hi = nlev - 1;                       // last l with rs[l] <= p
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (rs[mid] <= p) lo = mid; else hi = mid - 1; }
-    return lo;
+// the window row of rating `row` (a position in the shard's sorted state), whatever the entry width
+template <typename T>
+__device__ __forceinline__ void store_windows(const Shard<T>& S, size_t row, const T* ms, const int* rs, int nlev, int lev, T mp, int strict) {
+    if (S.w16) find_windows<T>(ms, rs, nlev, lev, mp, strict, reinterpret_cast<uint16_t*>(S.win) + row * S.ws);
+    else find_windows<T>(ms, rs, nlev, lev, mp, strict, reinterpret_cast<uint32_t*>(S.win) + row * S.ws);
 }
 
 // sweep_coeff with cached boundaries (w: ws slots of this item)
@@ -329,17 +323,25 @@ __device__ __forceinline__ double sweep_coeff_win(const W* __restrict__ w, const
     return 2.0 * acc;
 }
 
+// sweep_coeff_win on the shard's window cache, whatever the entry width
+template <typename T>
+__device__ __forceinline__ double sweep_coeff_cached(const Shard<T>& Sh, size_t row, const double* S, const int* rs, int nlev,
+                                                     int lev, double xp, double shift) {
+    return Sh.w16 ? sweep_coeff_win(reinterpret_cast<const uint16_t*>(Sh.win) + row * Sh.ws, S, rs, nlev, lev, xp, shift)
+                  : sweep_coeff_win(reinterpret_cast<const uint32_t*>(Sh.win) + row * Sh.ws, S, rs, nlev, lev, xp, shift);
+}
+
 // block_objective with cached boundaries (win: the user's window rows, ws slots each)
-template <typename T, int BLOCK, class LevF>
+template <typename T, int BLOCK, class LevF, typename W>
 __device__ __forceinline__ double block_objective_win(const T* ms, LevF levf, const int* rs, int nlev, int n,
-                                                      const uint32_t* __restrict__ win, int ws, double* S, double* red) {
+                                                      const W* __restrict__ win, int ws, double* S, double* red) {
     const int tid = btid<BLOCK>();
     double part = 0.0;
     block_excl_scan<BLOCK>([&](int i) { return (double)ms[i] - 1.0; }, S, n, red);
     for (int p = tid; p < n; p += BLOCK) {
         const int lev = levf(p);
         const double m = (double)ms[p];
-        const uint32_t* w = win + (size_t)p * ws;
+        const W* w = win + (size_t)p * ws;
         for (int l = lev + 1; l < nlev; ++l) {
             const int s0 = rs[l], wi = (int)w[l - 1];
             part += (double)(wi - s0) * m * m - 2.0 * m * (S[wi] - S[s0]);
@@ -349,7 +351,7 @@ __device__ __forceinline__ double block_objective_win(const T* ms, LevF levf, co
     block_excl_scan<BLOCK>([&](int i) { double d = (double)ms[i] - 1.0; return d * d; }, S, n, red);
     for (int p = tid; p < n; p += BLOCK) {
         const int lev = levf(p);
-        const uint32_t* w = win + (size_t)p * ws;
+        const W* w = win + (size_t)p * ws;
         for (int l = lev + 1; l < nlev; ++l) part += S[w[l - 1]] - S[rs[l]];
     }
     bsync<BLOCK>();
@@ -807,11 +809,12 @@ __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, cons
         PPROF(2);
         double loss;
         if (S.ws) {
-            uint32_t* win = S.win + (size_t)s0 * S.ws;
             for (int p = tid; p < n; p += BLOCK)
-                find_windows<T>(key, rs, nlev, (int)LiOps<LI>::lev(li[p]), key[p], strict, win + (size_t)p * S.ws);
+                store_windows<T>(S, (size_t)s0 + p, key, rs, nlev, (int)LiOps<LI>::lev(li[p]), key[p], strict);
             PPROF(3);
-            loss = block_objective_win<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, win, S.ws, Sx, red);
+            auto levf = [&](int p) { return (int)LiOps<LI>::lev(li[p]); };
+            loss = S.w16 ? block_objective_win<T, BLOCK>(key, levf, rs, nlev, n, reinterpret_cast<const uint16_t*>(S.win) + (size_t)s0 * S.ws, S.ws, Sx, red)
+                         : block_objective_win<T, BLOCK>(key, levf, rs, nlev, n, reinterpret_cast<const uint32_t*>(S.win) + (size_t)s0 * S.ws, S.ws, Sx, red);
         } else {
             loss = block_objective<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, Sx, red, strict);
         }
@@ -898,9 +901,9 @@ __device__ __forceinline__ void vsweep_block_body(char* smem, const Shard<T>& S,
         __syncthreads();
         block_excl_scan<BLOCK>([&](int i) { return (double)xs[i]; }, Sx, n, red);
         for (int p = tid; p < n; p += BLOCK) {
-            const int lev = level_of(rs, nlev, p);
+            const int lev = S.slvl[s0 + p];
             const double c = S.ws
-                ? sweep_coeff_win(S.win + (size_t)(s0 + p) * S.ws, Sx, rs, nlev, lev, (double)xs[p], HV ? 0.0 : 1.0)
+                ? sweep_coeff_cached<T>(S, (size_t)(s0 + p), Sx, rs, nlev, lev, (double)xs[p], HV ? 0.0 : 1.0)
                 : sweep_coeff<T>(ms, Sx, rs, nlev, lev, ms[p], (double)xs[p], HV ? 0.0 : 1.0, strict);
             // c goes out in CSR order -- a permutation inside this user's own segment, so the lines it touches are written in
             // full by this workgroup (staging the permutation through LDS was measured slower: 2.11 against 1.65 ms per
@@ -966,9 +969,9 @@ __device__ __forceinline__ void vsweep_wave_body(char* smem, const Shard<T>& S, 
     if (lane == 0) Sx[n] = carry;
     wave_sync();
     for (int p = lane; p < n; p += 64) {
-        const int lev = level_of(rs, nlev, p);
+        const int lev = S.slvl[s0 + p];
         const double c = S.ws
-            ? sweep_coeff_win(S.win + (size_t)(s0 + p) * S.ws, Sx, rs, nlev, lev, (double)xs[p], HV ? 0.0 : 1.0)
+            ? sweep_coeff_cached<T>(S, (size_t)(s0 + p), Sx, rs, nlev, lev, (double)xs[p], HV ? 0.0 : 1.0)
             : sweep_coeff<T>(ms, Sx, rs, nlev, lev, ms[p], (double)xs[p], HV ? 0.0 : 1.0, strict);
         c_out[s0 + S.sidx[s0 + p]] = (T)c;
     }
@@ -1537,9 +1540,12 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         for (int t = tid; t < ld; t += BLOCK) uvec[t] = (double)U[(size_t)u * ld + t];
         for (int p = tid; p < n; p += BLOCK) { ms0[p] = S.ms[s0 + p]; lv0[p] = S.slvl[s0 + p]; itm[p] = S.sitem[s0 + p]; }
         for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
-        const uint32_t* win = S.ws ? S.win + (size_t)s0 * S.ws : nullptr;       // windows of the gradient point
+        const bool win = S.ws != 0;                                             // windows of the gradient point are cached
         const bool wl = win && wcap >= n * S.ws;
-        if (wl) for (int i = tid; i < n * S.ws; i += BLOCK) winL[i] = (uint16_t)win[i];
+        if (wl) {
+            if (S.w16) { const uint16_t* wg = reinterpret_cast<const uint16_t*>(S.win) + (size_t)s0 * S.ws; for (int i = tid; i < n * S.ws; i += BLOCK) winL[i] = wg[i]; }
+            else { const uint32_t* wg = reinterpret_cast<const uint32_t*>(S.win) + (size_t)s0 * S.ws; for (int i = tid; i < n * S.ws; i += BLOCK) winL[i] = (uint16_t)wg[i]; }
+        }
         __syncthreads();
         if (RES && q1 > q0) stage_rows<T, BLOCK>(Vm, itm, q0, q1, rowsL, geo, nchp);      // lands while the gradient sweep runs
         UPROF(0);
@@ -1547,7 +1553,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         block_excl_scan<BLOCK>([&](int i) { return (double)ms0[i]; }, Sx, n, red);
         for (int p = tid; p < n; p += BLOCK)
             key[p] = (T)(wl ? sweep_coeff_win(winL + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)ms0[p], 1.0)
-                         : win ? sweep_coeff_win(win + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)ms0[p], 1.0)
+                         : win ? sweep_coeff_cached<T>(S, (size_t)s0 + p, Sx, rs, nlev, lv0[p], (double)ms0[p], 1.0)
                                : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)ms0[p], 1.0, strict));
         for (int t = tid; t < ld; t += BLOCK) gvec[t] = (n == 0) ? 0.0 : uvec[t] * lambda;   // :495-498
         if (RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the LDS-DMA of stage_rows
@@ -1586,7 +1592,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                 block_excl_scan<BLOCK>([&](int i) { return (double)key[i]; }, Sx, n, red);
                 for (int p = tid; p < n; p += BLOCK)
                     key[p] = (T)(wl ? sweep_coeff_win(winL + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)key[p], 0.0)
-                                 : win ? sweep_coeff_win(win + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)key[p], 0.0)
+                                 : win ? sweep_coeff_cached<T>(S, (size_t)s0 + p, Sx, rs, nlev, lv0[p], (double)key[p], 0.0)
                                        : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)key[p], 0.0, strict));
                 __syncthreads();
                 UPROF(4);
@@ -1656,7 +1662,6 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
             int32_t* stage = reinterpret_cast<int32_t*>(Sx);                  // Sx is free again: (cap + 1) doubles >= n ints
             for (int p = tid; p < n; p += BLOCK) stage[p] = S.sidx[s0 + LiOps<LI>::idx(li[p])];
             __syncthreads();                                                  // all of the old map is read before any of it is rewritten
-            uint32_t* wout = S.ws ? S.win + (size_t)s0 * S.ws : nullptr;
             for (int p = tid; p < n; p += BLOCK) {
                 const LI x = li[p];
                 const int lev = (int)LiOps<LI>::lev(x);
@@ -1664,7 +1669,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                 S.slvl[s0 + p] = (uint16_t)lev;
                 S.sitem[s0 + p] = itm[LiOps<LI>::idx(x)];
                 S.sidx[s0 + p] = stage[p];
-                if (wout) find_windows<T>(key, rs, nlev, lev, key[p], strict, wout + (size_t)p * S.ws);
+                if (S.ws) store_windows<T>(S, (size_t)s0 + p, key, rs, nlev, lev, key[p], strict);
             }
         }
         if (mem == 0) for (int t = tid; t < ld; t += BLOCK) U[(size_t)u * ld + t] = (T)unew[t];

@@ -139,7 +139,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = 1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
-        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1;
+        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1, win16 = 1;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -150,7 +150,7 @@ struct Tune {
         pipeline = pcr_tune_int("pipeline", 1); debug = pcr_tune_int("debug", 0); fault_cluster_member = pcr_tune_int("fault_cluster_member", 0);
         ustep_lockstep = pcr_tune_int("ustep_lockstep", -1);
         ustep_gram = pcr_tune_int("ustep_gram", -1); count_rows = pcr_tune_int("count_rows", 0);
-        wide_teams = pcr_tune_int("wide_teams", -1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1);
+        wide_teams = pcr_tune_int("wide_teams", -1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); win16 = pcr_tune_int("win16", 1);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -196,7 +196,7 @@ struct Solver final : pcr_solver {
     int spmm_chunk = 128;
     int sddmm_tile = 0;                           // ratings per lane group of k_sddmm (0 = not chosen yet)
     DBuf<uint16_t> d_lvl, d_slvl;
-    DBuf<uint32_t> d_win;
+    DBuf<uint16_t> d_win;                          // window cache: 16-bit entries (two per 32-bit entry when a user has >= 65536 ratings)
     DBuf<T> d_ms, d_c, d_mcsr, d_b;
     DBuf<double> d_objp;
     std::vector<Bin> bins;
@@ -752,7 +752,12 @@ struct Solver final : pcr_solver {
         RC(d_sidx.alloc(nnz_local)); RC(d_objr.alloc(nu));
         sh.sidx = d_sidx.p; sh.objr = d_objr.p;
         sh.ws = sh_ws_for_bins;
-        RC(d_win.alloc((size_t)nnz_local * sh.ws));
+        {
+            int64_t longest = 0;
+            for (int64_t u = 0; u < nu; ++u) longest = std::max(longest, uptr[u + 1] - uptr[u]);
+            sh.w16 = (longest < 65536 && tune.win16) ? 1 : 0;
+        }
+        RC(d_win.alloc((size_t)nnz_local * sh.ws * (sh.w16 ? 1 : 2)));
         sh.win = d_win.p;
 
         // ---- eval sets (train shard, test shard)
