@@ -92,7 +92,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep_gram(Shard<T> S, Geo geo, const
     double* red = cv.take<double>((size_t)NW * 8 + 8);
     double* wbuf = cv.take<double>((size_t)NW * ld);
     char* img = cv.take<char>(gram_img_bytes<T>(cap, nchp));       // rows of V (16-byte chunks, nchp per row), then K
-    double* md = cv.take<double>(cap);     // scores m = X u (fp64 copies of the sorted state)
+    double* md = cv.take<double>(cap);     // scores: first the sorted state's (gradient sweep), then m = X u recomputed from the staged rows
     double* ad = cv.take<double>(cap);     // delta
     double* kd = cv.take<double>(cap);
     double* ar = cv.take<double>(cap);     // residual
@@ -141,6 +141,15 @@ __global__ __launch_bounds__(BLOCK) void k_ustep_gram(Shard<T> S, Geo geo, const
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // the LDS-DMA of stage_rows
         __syncthreads();
         UPROF(7);
+        // m = X u from the rows just staged -- NOT the scores of the sorted state, which are those of the last TRIED V_new when the
+        // V step's line search failed (quirk q5: the reference computes the gradient coefficients from that stale m, as the sweep
+        // above did, but every b = V_I s and every line-search score from the V it kept, pcrpp.cpp:592-594, :728-744)
+        for (int p = tid; p < n; p += BLOCK) {
+            const T* xr = X + (size_t)p * lstride;
+            double acc0 = 0.0;
+            for (int t = 0; t < ld; ++t) acc0 += (double)xr[t] * uvec[t];
+            md[p] = acc0;
+        }
         // ---- K = X X^T on the matrix cores.  Tile pairs (I <= J) are dealt to the waves; a lane's k range is a contiguous
         // piece of its row (any consistent permutation of k serves a dot product), so it streams through LDS in order.
         const int nt = (n + MM::TS - 1) / MM::TS, npairs = nt * (nt + 1) / 2;
@@ -204,6 +213,9 @@ __global__ __launch_bounds__(BLOCK) void k_ustep_gram(Shard<T> S, Geo geo, const
         double obj_new = prev_obj, loss_new = 0.0;
         int n_cg = 0, n_ls = 0;
         const bool skip = (gn2 < 0.0001) || (solver1 && nlev <= 1);                // pcrpp.cpp:787-790; pcr.cpp:552
+#ifdef PCR_GRAM_DEBUG
+        if (tid == 0 && n == 10) printf("gram u=%d n=%d un2=%g d3=%g %g gn2=%g prev=%g objp=%g md0=%g cc0=%g kc0=%g K00=%g skip=%d\n", u, n, un2, d3[1], d3[2], gn2, prev_obj, S.objp[u], md[0], cc[0], kc[0], (double)K[0], (int)skip);
+#endif
         if (!skip) {
             // ---- CG (solve_delta_u_new, pcrpp.cpp:628-647) on (alpha, a) pairs: delta = 0, rr = -g, p = g
             double al_d = 0.0, al_r = -lambda, al_p = lambda;

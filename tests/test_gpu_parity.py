@@ -360,8 +360,11 @@ def test_pipelined_iterations_equal_the_step_by_step_loop(oracle):
         assert np.array_equal(Ua, Ub) and np.array_equal(Va, Vb)
 
 
-def test_line_search_failure_quirks(oracle):
-    """q5: a V step whose 20 line-search tries all fail keeps V but hands the m of the LAST TRIED V_new to the U step
+@pytest.mark.parametrize("knobs", [{}, {"ustep_gram": 128}, {"ustep_lockstep": 1}], ids=["default", "gram", "lockstep"])
+def test_line_search_failure_quirks(oracle, knobs):
+    """(Every form of the U step: the dual form must take its gradient coefficients from the STALE scores of the rejected V_new
+    but every b = V_I s and every line-search score from the V that was kept -- a fuzz case caught it using the stale ones.)
+    q5: a V step whose 20 line-search tries all fail keeps V but hands the m of the LAST TRIED V_new to the U step
     (pcrpp.cpp:430-431, :443); a U step whose tries all fail returns the last tried u (:794-814).  Forced with an absurd
     initial step size; the next V step must rebuild its state (the U step's skipped users still carry the rejected one)."""
     d1, d2, user, item, val = _mixed_set(seed=14, d1=120)
@@ -369,7 +372,8 @@ def test_line_search_failure_quirks(oracle):
     X = oracle.build_csr(d1, d2, user, item, val)
     U0 = oracle.initial(d1, r) * 0.3; V0 = oracle.initial(d2, r) * 0.3
     ds = pcr.Dataset.from_triplets(d1, d2, user, item, val)
-    s = pcr.Solver(ds, pcr.Parameter(k=r, precision=pcr.PCR_F64, stepsize=step, **{"lambda": lam}))
+    with pcr.tuned(**knobs):
+        s = pcr.Solver(ds, pcr.Parameter(k=r, precision=pcr.PCR_F64, stepsize=step, **{"lambda": lam}))
     s.set_factors(U0, V0)
     U, V = U0, V0
     for it in range(2):
@@ -385,10 +389,13 @@ def test_line_search_failure_quirks(oracle):
         U, V = Un, Vn
 
 
-def test_fuzz_small_shapes_against_oracle(oracle):
+@pytest.mark.parametrize("knobs", [{}, {"ustep_gram": 128}, {"ustep_lockstep": 1}, {"win16": 0, "ustep_win_lds": 0}],
+                         ids=["default", "gram", "lockstep", "win32"])
+def test_fuzz_small_shapes_against_oracle(oracle, knobs):
     """Seeded random shapes around the corners of the launch logic: ranks that are not multiples of 4, 1..12 rating
     levels (window cache on and off), real-valued ratings, users of 0..700 ratings, both solvers; two outer iterations in
-    fp64 must follow the oracle's trajectory (objectives, inner counts, factors)."""
+    fp64 must follow the oracle's trajectory (objectives, inner counts, factors) -- in the default launch configuration and
+    with the alternative U-step forms (dual form on MFMA, lock-step passes) switched on."""
     rng = np.random.default_rng(2026)
     for case in range(80):
         d1 = int(rng.integers(3, 60)); d2 = int(rng.integers(20, 900))
@@ -409,11 +416,12 @@ def test_fuzz_small_shapes_against_oracle(oracle):
         X = oracle.build_csr(d1, d2, user, item, val)
         U0 = oracle.initial(d1, r) * 0.4; V0 = oracle.initial(d2, r) * 0.4
         Uo, Vo, recs = oracle.train(X, U0, V0, lam, 2, solver=solver, do_predict=0)
-        s = pcr.Solver(pcr.Dataset.from_triplets(d1, d2, user, item, val),
-                       pcr.Parameter(k=r, solver_type=solver, precision=pcr.PCR_F64, **{"lambda": lam}))
+        with pcr.tuned(**knobs):
+            s = pcr.Solver(pcr.Dataset.from_triplets(d1, d2, user, item, val),
+                           pcr.Parameter(k=r, solver_type=solver, precision=pcr.PCR_F64, **{"lambda": lam}))
         s.set_factors(U0, V0)
         got = s.iterate(2)
-        tag = dict(case=case, d1=d1, d2=d2, r=r, nlev=nlev, solver=solver, real=real, lam=lam, nnz=int(user.size))
+        tag = dict(case=case, knobs=knobs, d1=d1, d2=d2, r=r, nlev=nlev, solver=solver, real=real, lam=lam, nnz=int(user.size))
         for g, o in zip(got, recs[1:]):
             # (1e-8: case 17 -- solver 1, r = 64, the objective falls 1e7 -> 1e5 -> 1e4 -- amplifies summation-order rounding to
             # 1.0e-9 / 1.3e-9 depending on the SpMM chunk length, with identical inner counts; see tools/dbg_fuzz.py)
