@@ -272,9 +272,10 @@ __global__ __launch_bounds__(BLOCK) void k_ustep_gram(Shard<T> S, Geo geo, const
             double g2[2] = {0.0, 0.0};
             for (int p = tid; p < n; p += BLOCK) { g2[0] += md[p] * ad[p]; g2[1] += ad[p] * kd[p]; }
             block_sums<BLOCK, 2>(g2, red);
-            double step = stepsize0;
+            double step = stepsize0, step_used = stepsize0;
             const int npad = next_pow2(n);
             for (int it = 0; it < 20; ++it) {
+                step_used = step;                                                          // the user gets the LAST TRIED u (:813)
                 const double sc = 1.0 - step * al_d;
                 const double nn = sc * sc * un2 - 2.0 * step * sc * g2[0] + step * step * g2[1];      // |u - s delta|^2
                 for (int p = tid; p < npad; p += BLOCK) {
@@ -294,9 +295,9 @@ __global__ __launch_bounds__(BLOCK) void k_ustep_gram(Shard<T> S, Geo geo, const
             }
             // ---- the second and last pass over the user's rows: u_new = (1 - s alpha_d) u - s X^T a_delta
             {
-                const double sc = 1.0 - step * al_d;
+                const double sc = 1.0 - step_used * al_d;
                 for (int t = tid; t < ld; t += BLOCK) unew[t] = sc * uvec[t];
-                for (int p = tid; p < n; p += BLOCK) cc[p] = ad[p] * -step;
+                for (int p = tid; p < n; p += BLOCK) cc[p] = ad[p] * -step_used;
                 __syncthreads();
                 block_gather_axpy<T, double, BLOCK, false, 4>(Vm, itm, cc, n, unew, wbuf, geo, 0, false);
             }
