@@ -299,3 +299,24 @@ def test_integration_stub_reproduces_the_reference_run(solver, tmp_path):
     V = np.frombuffer(raw, np.float64, d2 * k2, off + 16).reshape(d2, k2)
     assert np.abs(U - g[f"cli_U_s{solver}"]).max() < 1e-6 * np.abs(U).max()
     assert np.abs(V - g[f"cli_V_s{solver}"]).max() < 1e-6 * np.abs(V).max()
+
+
+@pytest.mark.gpu
+def test_gpus_option_large_vectors_take_the_two_phase_exchange(tmp_path):
+    """V-side vectors beyond 256 KB go through the reduce-scatter + all-gather form of the peer-to-peer all-reduce (smaller
+    ones through the one-shot form the golden-set tests exercise): 2500 items x k = 24 in fp64 = 480 KB per vector, three
+    ranks on the one GPU (slices of unequal length), against the single-process run."""
+    R = synth.generate("small", seed=5, d1=400, d2=2500, nnz=30000, mu=4.0, sigma=0.7)
+    d = synth.write_dir(R, str(tmp_path / "data"))
+    base = [TRAIN, "-k", "24", "-l", "50", "-t", "2", "-p", "0", "--f64"]
+    one = run(base + [d, "one.model"], tmp_path)
+    three = run(base + ["--gpus", "3", "--devices", "0,0,0", "--comm", "p2p", d, "three.model"], tmp_path)
+    assert one.returncode == 0 and three.returncode == 0, three.stderr
+    strip = lambda out: [re.sub(r"time \S+", "time T", l) for l in out.split("\n") if l.startswith("Iter")]
+    la, lb = strip(one.stdout), strip(three.stdout)
+    assert len(la) == len(lb) == 3
+    for x, y in zip(la, lb):
+        assert np.allclose([float(v) for v in re.findall(NUM, x)], [float(v) for v in re.findall(NUM, y)], rtol=2e-5), (x, y)
+    a = np.frombuffer(open(tmp_path / "one.model", "rb").read(), np.float64)
+    b = np.frombuffer(open(tmp_path / "three.model", "rb").read(), np.float64)
+    assert a.shape == b.shape and np.nanmax(np.abs(a[2:] - b[2:])) < 1e-9 * np.nanmax(np.abs(a[2:]))
