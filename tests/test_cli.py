@@ -320,3 +320,18 @@ def test_gpus_option_large_vectors_take_the_two_phase_exchange(tmp_path):
     a = np.frombuffer(open(tmp_path / "one.model", "rb").read(), np.float64)
     b = np.frombuffer(open(tmp_path / "three.model", "rb").read(), np.float64)
     assert a.shape == b.shape and np.nanmax(np.abs(a[2:] - b[2:])) < 1e-9 * np.nanmax(np.abs(a[2:]))
+
+
+@pytest.mark.gpu
+def test_gpus_option_a_failing_rank_takes_the_job_down(tmp_path):
+    """A device error on one half of the job must end the WHOLE job with exit code 1 -- not leave a rank waiting in a
+    collective.  The fault-injection knob makes every workgroup cluster lose a member (a bounded hand-off wait -> error flag);
+    the flag rides on the objective's all-reduce, so both ranks see it, report PCR_ERR_DEVICE and leave; the parent reaps them."""
+    R = synth.generate("small", seed=4, d1=40, d2=6000, nnz=60000, mu=7.0, sigma=0.6)       # users of ~1000-3000 ratings
+    d = synth.write_dir(R, str(tmp_path / "data"))
+    cmd = [TRAIN, "-k", "8", "-t", "2", "-p", "0", "--gpus", "2", "--devices", "0,0", "--comm", "p2p", "--tune", "fault_cluster_member=1", d, "m.model"]
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1, r.stderr
+    assert "timed out" in r.stderr and "a GPU worker failed" in r.stderr
+    ok = run([TRAIN, "-k", "8", "-t", "2", "-p", "0", "--gpus", "2", "--devices", "0,0", "--comm", "p2p", d, "m.model"], tmp_path)
+    assert ok.returncode == 0, ok.stderr                               # ... and the GPU is fine afterwards
