@@ -152,6 +152,7 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *   ubins           "cap:block:resident,..." length classes of the U step below 1024 ratings
  *   spmm_tiles, spmm_chunk, sddmm_tile, sddmm_csc   tiling of the rating-parallel kernels
  *   sweep_wave_cap  ratings up to which a sweep gives a user one wave
+ *   sweep_prefetch  0 = the sweeps keep one round of per-rating loads in flight instead of four (default 1)
  *   wide_teams      1 = 1024-thread workgroups in the merged prepare and sweep launches (default 0: 512)
  *   window_cache    0 = sweeps search their hinge windows instead of caching them
  *   win16           0 = 32-bit window-cache entries even when every user has fewer than 65536 ratings (default 1: 16-bit)

@@ -323,6 +323,48 @@ __device__ __forceinline__ double sweep_coeff_win(const W* __restrict__ w, const
     return 2.0 * acc;
 }
 
+// sweep_coeff_win for the common layout -- at most 5 levels (ws == 4), 16-bit entries: the rating's four boundaries arrive as
+// ONE 8-byte load (wv), the loop over the other levels is unrolled with the slot chosen by a select.  Same terms in the same
+// order as sweep_coeff_win (levels ascending), so the result is bitwise the same.
+__device__ __forceinline__ double sweep_coeff_win4(uint2 wv, const double* S, const int* rs, int nlev, int lev, double xp, double shift) {
+    const int w[4] = {(int)(wv.x & 0xFFFFu), (int)(wv.x >> 16), (int)(wv.y & 0xFFFFu), (int)(wv.y >> 16)};
+    double acc = 0.0;
+#pragma unroll
+    for (int l = 0; l < 5; ++l) {
+        if (l >= nlev || l == lev) continue;
+        if (l < lev) {
+            const int wi = w[l < 4 ? l : 3], e = rs[l + 1];
+            acc += (double)(e - wi) * (xp - shift) - (S[e] - S[wi]);
+        } else {
+            const int wi = w[l - 1 >= 0 ? l - 1 : 0], s0 = rs[l];
+            acc += (double)(wi - s0) * (xp + shift) - (S[wi] - S[s0]);
+        }
+    }
+    return 2.0 * acc;
+}
+// the sweep's output loop for that layout: the per-rating loads (level, boundaries, CSR index) of FOUR rounds are issued before
+// the first is used.  The sweep is bound by bytes in flight on large shards (Little's law: ~35 % occupancy x 3 small loads per
+// wave = 1.5 TB/s on the Netflix shape); on ml1m the launch is as long as its longest user and this changes nothing.
+template <typename T, int STRIDE, bool HV>
+__device__ __forceinline__ void sweep_out4(const Shard<T>& S, int64_t s0, int n, int nlev, int tid, const T* xs, const double* Sx,
+                                           const int* rs, T* __restrict__ c_out) {
+    const uint2* __restrict__ w2 = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(S.win) + (size_t)s0 * 4);
+    for (int p0 = tid; p0 < n; p0 += STRIDE * 4) {
+        uint2 wv[4];
+        int lv[4], si[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = p0 + q * STRIDE;
+            if (p < n) { wv[q] = w2[p]; lv[q] = S.slvl[s0 + p]; si[q] = S.sidx[s0 + p]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = p0 + q * STRIDE;
+            if (p < n) c_out[s0 + si[q]] = (T)sweep_coeff_win4(wv[q], Sx, rs, nlev, lv[q], (double)xs[p], HV ? 0.0 : 1.0);
+        }
+    }
+}
+
 // sweep_coeff_win on the shard's window cache, whatever the entry width
 template <typename T>
 __device__ __forceinline__ double sweep_coeff_cached(const Shard<T>& Sh, size_t row, const double* S, const int* rs, int nlev,
@@ -790,6 +832,7 @@ __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, cons
         }
         for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
         const int npad = next_pow2(n);
+#pragma unroll 4
         for (int p = tid; p < npad; p += BLOCK) {
             if (p < n) { li[p] = LiOps<LI>::pack(S.lvl[s0 + p], (unsigned)p); key[p] = m_in[s0 + p]; }
             else { li[p] = LiOps<LI>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
@@ -874,7 +917,8 @@ template <typename T, int BLOCK, bool BIG, bool HV>
 __device__ __forceinline__ void vsweep_block_body(char* smem, const Shard<T>& S, const int32_t* __restrict__ users, int nusers,
                                                   const T* __restrict__ bsrc, T* __restrict__ c_out, int cap, int rs_cap,
                                                   char* scratch, size_t stride, int strict, int blk, int nblk,
-                                                  const uint8_t* __restrict__ only = nullptr, int b_csr = 0) {
+                                                  const uint8_t* __restrict__ only = nullptr, int flags = 0) {
+    const int b_csr = flags & 1, pf4 = flags & 2;       // b in CSR order; four rounds of per-rating loads in flight
     Carver small(smem);
     double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
     Carver big(BIG ? scratch + (size_t)blk * stride : small.p);
@@ -891,15 +935,20 @@ __device__ __forceinline__ void vsweep_block_body(char* smem, const Shard<T>& S,
         const int n = (int)(S.uptr[u + 1] - s0);
         const int nlev = (int)(S.runofs[u + 1] - S.runofs[u]) - 1;
         if (n == 0) continue;
-        if (!HV || !S.ws) for (int p = tid; p < n; p += BLOCK) ms[p] = S.ms[s0 + p];
+        if (!HV || !S.ws) {
+#pragma unroll 4
+            for (int p = tid; p < n; p += BLOCK) ms[p] = S.ms[s0 + p];
+        }
         for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
         const T* xs = ms;
         if (HV) {     // b = u_i . a_item from k_sddmm: in sorted order when it walked sitem, in CSR order when it walked the CSC
+#pragma unroll 4
             for (int p = tid; p < n; p += BLOCK) x[p] = bsrc[s0 + (b_csr ? S.sidx[s0 + p] : p)];
             xs = x;
         }
         __syncthreads();
         block_excl_scan<BLOCK>([&](int i) { return (double)xs[i]; }, Sx, n, red);
+        if (S.ws == 4 && S.w16 && pf4) { sweep_out4<T, BLOCK, HV>(S, s0, n, nlev, tid, xs, Sx, rs, c_out); __syncthreads(); continue; }
         for (int p = tid; p < n; p += BLOCK) {
             const int lev = S.slvl[s0 + p];
             const double c = S.ws
@@ -936,7 +985,8 @@ template <typename T, bool HV>
 __device__ __forceinline__ void vsweep_wave_body(char* smem, const Shard<T>& S, const int32_t* __restrict__ users, int nusers,
                                                  const T* __restrict__ bsrc, T* __restrict__ c_out,
                                                  int cap, int rs_cap, size_t wave_bytes, int strict, int ui,
-                                                 const uint8_t* __restrict__ only = nullptr, int b_csr = 0) {
+                                                 const uint8_t* __restrict__ only = nullptr, int flags = 0) {
+    const int b_csr = flags & 1, pf4 = flags & 2;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (ui >= nusers) return;
     if (only && !only[users[ui]]) return;
@@ -950,10 +1000,14 @@ __device__ __forceinline__ void vsweep_wave_body(char* smem, const Shard<T>& S, 
     const int n = (int)(S.uptr[u + 1] - s0);
     const int nlev = (int)(S.runofs[u + 1] - S.runofs[u]) - 1;
     if (n == 0) return;
-    if (!HV || !S.ws) for (int p = lane; p < n; p += 64) ms[p] = S.ms[s0 + p];
+    if (!HV || !S.ws) {
+#pragma unroll 4
+        for (int p = lane; p < n; p += 64) ms[p] = S.ms[s0 + p];
+    }
     for (int l = lane; l <= nlev; l += 64) rs[l] = S.runstart[S.runofs[u] + l];
     const T* xs = ms;
     if (HV) {
+#pragma unroll 4
         for (int p = lane; p < n; p += 64) x[p] = bsrc[s0 + (b_csr ? S.sidx[s0 + p] : p)];
         xs = x;
     }
@@ -968,6 +1022,7 @@ __device__ __forceinline__ void vsweep_wave_body(char* smem, const Shard<T>& S, 
     }
     if (lane == 0) Sx[n] = carry;
     wave_sync();
+    if (S.ws == 4 && S.w16 && pf4) { sweep_out4<T, 64, HV>(S, s0, n, nlev, lane, xs, Sx, rs, c_out); return; }
     for (int p = lane; p < n; p += 64) {
         const int lev = S.slvl[s0 + p];
         const double c = S.ws
@@ -1538,6 +1593,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
             }
         };
         for (int t = tid; t < ld; t += BLOCK) uvec[t] = (double)U[(size_t)u * ld + t];
+#pragma unroll 4
         for (int p = tid; p < n; p += BLOCK) { ms0[p] = S.ms[s0 + p]; lv0[p] = S.slvl[s0 + p]; itm[p] = S.sitem[s0 + p]; }
         for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
         const bool win = S.ws != 0;                                             // windows of the gradient point are cached
@@ -1551,7 +1607,23 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         UPROF(0);
         // ---- gradient coefficients, obtain_g_u_new (pcrpp.cpp:506-535)
         block_excl_scan<BLOCK>([&](int i) { return (double)ms0[i]; }, Sx, n, red);
-        for (int p = tid; p < n; p += BLOCK)
+        // (classes without the LDS copy read the window rows from global memory: four rounds of 8-byte loads in flight)
+        const bool w4 = win && !wl && S.ws == 4 && S.w16;
+        const uint2* __restrict__ w2 = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(S.win) + (size_t)s0 * 4);
+        auto sweep4 = [&](const T* xin, T* out, double shift) {
+            for (int p0 = tid; p0 < n; p0 += BLOCK * 4) {
+                uint2 wv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (p0 + q * BLOCK < n) wv[q] = w2[p0 + q * BLOCK];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p = p0 + q * BLOCK;
+                    if (p < n) out[p] = (T)sweep_coeff_win4(wv[q], Sx, rs, nlev, lv0[p], (double)xin[p], shift);
+                }
+            }
+        };
+        if (w4) sweep4(ms0, key, 1.0);
+        else for (int p = tid; p < n; p += BLOCK)
             key[p] = (T)(wl ? sweep_coeff_win(winL + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)ms0[p], 1.0)
                          : win ? sweep_coeff_cached<T>(S, (size_t)s0 + p, Sx, rs, nlev, lv0[p], (double)ms0[p], 1.0)
                                : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)ms0[p], 1.0, strict));
@@ -1590,7 +1662,8 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                 exchange_scores(key, n, r0, r1);
                 UPROF(3);
                 block_excl_scan<BLOCK>([&](int i) { return (double)key[i]; }, Sx, n, red);
-                for (int p = tid; p < n; p += BLOCK)
+                if (w4) sweep4(key, key, 0.0);
+                else for (int p = tid; p < n; p += BLOCK)
                     key[p] = (T)(wl ? sweep_coeff_win(winL + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)key[p], 0.0)
                                  : win ? sweep_coeff_cached<T>(S, (size_t)s0 + p, Sx, rs, nlev, lv0[p], (double)key[p], 0.0)
                                        : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)key[p], 0.0, strict));

@@ -139,7 +139,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = 1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
-        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1, win16 = 1;
+        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -150,7 +150,7 @@ struct Tune {
         pipeline = pcr_tune_int("pipeline", 1); debug = pcr_tune_int("debug", 0); fault_cluster_member = pcr_tune_int("fault_cluster_member", 0);
         ustep_lockstep = pcr_tune_int("ustep_lockstep", -1);
         ustep_gram = pcr_tune_int("ustep_gram", -1); count_rows = pcr_tune_int("count_rows", 0);
-        wide_teams = pcr_tune_int("wide_teams", -1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); win16 = pcr_tune_int("win16", 1);
+        wide_teams = pcr_tune_int("wide_teams", -1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); win16 = pcr_tune_int("win16", 1); sweep_prefetch = pcr_tune_int("sweep_prefetch", -1);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -192,6 +192,7 @@ struct Solver final : pcr_solver {
     int spmm_blocks = 0, spmm_tiles = 1;
     bool sddmm_csc = false;                       // the CG's SDDMM walks the SpMM's tile-major CSC (item table beyond the L2s)
     DBuf<T> d_slab;                               // k_spmm partial rows, one per (chunk, item) incidence
+    bool sweep_pf4 = false;                       // sweeps keep four rounds of per-rating loads in flight (large shards)
     bool wide_teams = false;                      // k_prepare_all / k_vsweep_all: 1024-thread teams for the long users (few of them)
     int spmm_chunk = 128;
     int sddmm_tile = 0;                           // ratings per lane group of k_sddmm (0 = not chosen yet)
@@ -593,6 +594,7 @@ struct Solver final : pcr_solver {
         // (measured, ml1m: 1024-thread teams make both launches slower -- k_vsweep_all 23 -> 31 us, k_prepare_all 99 -> 133 us:
         // sixteen one-wave users per workgroup cost more occupancy than the longest user's chain gains -- so 512 stays)
         wide_teams = tune.wide_teams > 0;
+        sweep_pf4 = tune.sweep_prefetch != 0;
         // U step: users with more than 1024 ratings are bound by one CU's gather bandwidth -> clusters of 4 workgroups
         // The U step keeps each user's rows of V in LDS (k_ustep, stage_rows), so its occupancy is set by LDS bytes, not
         // registers: finer length classes than the V side, and a workgroup size that grows with the class.
@@ -1104,7 +1106,7 @@ struct Solver final : pcr_solver {
     }
     // the per-user sweeps alone: b (d_b) -> c (CSR order, d_c); only: lock-step U step, users still taking part
     int launch_sweeps(bool hv, const int* skip, const uint8_t* only, bool b_csr = false) {
-        const int bc = b_csr ? 1 : 0;
+        const int bc = (b_csr ? 1 : 0) | (sweep_pf4 ? 2 : 0);
         const bool two = hv && !sh.ws;                      // scores and sweep values both live in LDS (no window cache)
         auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
