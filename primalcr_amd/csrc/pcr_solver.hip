@@ -139,7 +139,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = 1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
-        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1;
+        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_small_unr = 0;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -151,6 +151,7 @@ struct Tune {
         ustep_lockstep = pcr_tune_int("ustep_lockstep", -1);
         ustep_gram = pcr_tune_int("ustep_gram", -1); count_rows = pcr_tune_int("count_rows", 0);
         wide_teams = pcr_tune_int("wide_teams", -1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); win16 = pcr_tune_int("win16", 1); sweep_prefetch = pcr_tune_int("sweep_prefetch", -1);
+        ustep_small_unr = pcr_tune_int("ustep_small_unr", 0);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -696,6 +697,16 @@ struct Solver final : pcr_solver {
             const size_t fixed = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + ustep_big_bytes<T>(b.cap, host_pow2(b.cap), b.max_lev + 2, 4);
             if (fixed > (size_t)160 * 1024) { b.big = true; b.block = 512; }
         }
+        // the one-wave and 256-thread classes keep 4 rows in flight per lane group (8, pcr_tune("ustep_small_unr"), measured on ml1m:
+        // the one-wave classes alone 1.58 -> 1.67 ms per step, the 256-thread classes too 1.89 ms; Netflix shape U step 52 -> 68 ms:
+        // the registers cost more occupancy than the deeper gathers gain)
+        for (size_t q = 0; q < nsmall && q < ubins.size(); ++q) {
+            Bin& b = ubins[q];
+            if (b.gram || b.users.empty()) continue;
+            b.unr = tune.ustep_small_unr == 8 ? 8 : 4;
+        }
+        for (size_t q = nsmall; q < ubins.size(); ++q)
+            if (ubins[q].block == 256 && !ubins[q].big && tune.ustep_small_unr > 0) ubins[q].unr = tune.ustep_small_unr;
         u_big_blocks = 0;
         for (auto& b : ubins) {
             const int nus = (int)b.users.size();
@@ -891,6 +902,7 @@ struct Solver final : pcr_solver {
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
 #define UL(BL, BG, KK, RS, UN) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, BL, BG, KK, RS, UN>, hipFuncAttributeMaxDynamicSharedMemorySize, lim))
         UL(64, false, 1, true, 4); UL(64, false, 1, false, 4); UL(256, false, 1, false, 4);
+        UL(64, false, 1, true, 8); UL(64, false, 1, false, 8); UL(256, false, 1, false, 8);
         UL(512, false, 1, true, 8); UL(512, false, 1, false, 4); UL(512, false, 4, true, 8);
         UL(512, true, 1, true, 8); UL(512, true, 1, false, 4); UL(512, true, 4, true, 8);
 #undef UL
@@ -1512,7 +1524,9 @@ struct Solver final : pcr_solver {
                 return;
             }
             if (b.big) { if (b.K == 4) LU(512, true, 4, true, 8); else if (b.unr == 8) LU(512, true, 1, true, 8); else LU(512, true, 1, false, 4); }
+            else if (b.block == 64 && b.unr == 8) { if (b.rcap > 0) LU(64, false, 1, true, 8); else LU(64, false, 1, false, 8); }
             else if (b.block == 64) { if (b.rcap > 0) LU(64, false, 1, true, 4); else LU(64, false, 1, false, 4); }
+            else if (b.block == 256 && b.unr == 8) LU(256, false, 1, false, 8);
             else if (b.block == 256) LU(256, false, 1, false, 4);
             else if (b.K == 4) LU(512, false, 4, true, 8);
             else if (b.unr == 8) LU(512, false, 1, true, 8);
