@@ -158,7 +158,8 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *   window_cache    0 = sweeps search their hinge windows instead of caching them
  *   win16           0 = 32-bit window-cache entries even when every user has fewer than 65536 ratings (default 1: 16-bit)
  *   ustep_win_lds   0 = k_ustep reads the window cache from global memory in every sweep (default 1: LDS copy)
- *   prepare_merged  0 = one prepare launch per length class
+ *   prepare_merged  1 / 0 = both LDS classes of k_prepare in one launch, or one launch per length class side by side
+ *                   (default: merged below 4 M ratings per shard)
  *   lanes           concurrent streams for length classes (1 = none);  pipeline: 0 = host round trip after every U step
  *   eval_brute      1 = O(len^2) evaluator
  *   count_rows      1 = the U-step kernels count the rows of V they gather (pcr_solver_counter; a diagnostic that

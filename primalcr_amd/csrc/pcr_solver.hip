@@ -138,7 +138,7 @@ struct pcr_solver {
 // launch knobs: pcr_tune() values read once when the solver is created (include/primalcr.h lists them)
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
-        cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = 1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
+        cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = -1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
         fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_small_unr = 0;
     std::string ubins;
     void read() {
@@ -146,7 +146,7 @@ struct Tune {
         sddmm_csc = pcr_tune_int("sddmm_csc", -1); sddmm_tile = pcr_tune_int("sddmm_tile", 0); sweep_wave_cap = pcr_tune_int("sweep_wave_cap", 0);
         ustep_mode = pcr_tune_int("ustep_mode", 0); ustep_many = pcr_tune_int("ustep_many", 0); cluster_k = pcr_tune_int("cluster_k", 4);
         cluster_users = pcr_tune_int("cluster_users", 0); window_cache = pcr_tune_int("window_cache", 1);
-        prepare_merged = pcr_tune_int("prepare_merged", 1); ustep_seq = pcr_tune_int("ustep_seq", 0); eval_brute = pcr_tune_int("eval_brute", 0);
+        prepare_merged = pcr_tune_int("prepare_merged", -1); ustep_seq = pcr_tune_int("ustep_seq", 0); eval_brute = pcr_tune_int("eval_brute", 0);
         pipeline = pcr_tune_int("pipeline", 1); debug = pcr_tune_int("debug", 0); fault_cluster_member = pcr_tune_int("fault_cluster_member", 0);
         ustep_lockstep = pcr_tune_int("ustep_lockstep", -1);
         ustep_gram = pcr_tune_int("ustep_gram", -1); count_rows = pcr_tune_int("count_rows", 0);
@@ -1064,7 +1064,10 @@ struct Solver final : pcr_solver {
     }
 
     bool prepare_is_single_launch() const {
-        return tune.prepare_merged && !pbins[0].users.empty() && !pbins[1].users.empty();
+        // one merged launch on small shards (no fork / join: the classes are shorter than a launch round trip); on large ones the
+        // per-class launches side by side win (Netflix shape: 7.9 ms against 8.2 + 2.2 ms for the global-scratch class behind it)
+        const bool merged = tune.prepare_merged >= 0 ? tune.prepare_merged != 0 : nnz_local < (int64_t)4000000;
+        return merged && !pbins[0].users.empty() && !pbins[1].users.empty();
     }
     int launch_prepare(const T* Vm, const T* Umat = nullptr, const uint8_t* only = nullptr) {
         RC(launch_sddmm(Vm, d_item.p, d_mcsr.p, nullptr, Umat, only, only ? "u:sddmm" : "sddmm"));

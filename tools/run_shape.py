@@ -34,7 +34,7 @@ s.set_factors(pcr.initial(R.d1, a.k), pcr.initial(R.d2, a.k))
 s.profile(True, period=2)
 recs, lines = s.train(log=lambda l: print("  gpu|", l, flush=True))
 prof = s.profile_all(); tot = sum(v[0] for v in prof.values())
-for kname, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0])[:14]:
+for kname, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0])[:30]:
     print(f"  {kname:14s} {ms:10.2f} ms {n:6d} timed  {1e3*ms/max(n,1):10.1f} us/launch {100*ms/tot:5.1f}%")
 print("inner counts:", [(r["cg_v"], r["ls_v"], r["cg_u"], r["ls_u"]) for r in recs[1:]])
 te = s.evaluate(1, 10); print("test err/ndcg", te, flush=True)
