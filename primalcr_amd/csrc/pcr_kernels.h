@@ -1608,7 +1608,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         // ---- gradient coefficients, obtain_g_u_new (pcrpp.cpp:506-535)
         block_excl_scan<BLOCK>([&](int i) { return (double)ms0[i]; }, Sx, n, red);
         // (classes without the LDS copy read the window rows from global memory: four rounds of 8-byte loads in flight)
-        const bool w4 = win && !wl && S.ws == 4 && S.w16;
+        const bool w4 = BLOCK > 64 && win && !wl && S.ws == 4 && S.w16;      // (the one-wave classes always hold the LDS copy)
         const uint2* __restrict__ w2 = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(S.win) + (size_t)s0 * 4);
         auto sweep4 = [&](const T* xin, T* out, double shift) {
             for (int p0 = tid; p0 < n; p0 += BLOCK * 4) {
