@@ -146,6 +146,8 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *   ustep_mode      1 = latency form of k_ustep for every long class, 2 = throughput form (default: by user count)
  *   ustep_many      user count above which a long class counts as throughput-bound (default CUs/4)
  *   ustep_small_unr 8 = eight rows in flight per lane group in the one-wave and 256-thread classes of k_ustep (default 4)
+ *   ustep_ls_recur  0 = k_ustep's first line-search try gathers the rows for its scores (default 1: m - s sum alpha_k b_k from the
+ *                   CG's own b_k = V_I p_k, no pass)
  *   ustep_seq       1 = the U step's length classes back to back on one stream
  *   ustep_lockstep  1 = U step as rating-parallel lock-step passes over all users (default 0: per-user kernels)
  *   ustep_gram      dual (Gram-matrix on MFMA) U step for users with at most that many ratings (<= 128; default 0 = off)

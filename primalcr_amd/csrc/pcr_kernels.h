@@ -1642,7 +1642,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         // no need to sweep for it again
         const double prev_obj = lambda / 2.0 * un2 + S.objp[u];
         double obj_new = prev_obj, loss_new = 0.0;
-        int n_cg = 0, n_ls = 0;
+        int n_cg = 0, n_ls = 0, ls_free = 0;
         // pcrpp.cpp:787-790; PrimalCR additionally keeps u when no comparable pair exists
         // (cc == 0, pcr.cpp:552)
         const bool skip = (gn2 < 0.0001) || (solver1 && nlev <= 1);
@@ -1653,6 +1653,15 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
             // ---- CG, solve_delta_u_new (pcrpp.cpp:628-647)
             for (int t = tid; t < ld; t += BLOCK) { delta[t] = 0.0; rr[t] = gvec[t] * -1.0; pv[t] = gvec[t]; }
             const double err = sqrt(gn2) * cg_tol;                              // 0.01 in the reference (:632)
+            // The first line-search try needs no pass over the rows: V_I (u - s delta) = m - s sum_k alpha_k (V_I p_k), and
+            // b_k = V_I p_k is what every CG iteration computes anyway.  With the window cache on, the gradient point's scores
+            // ms0 are not needed again after the gradient sweep, so they carry the running m - s0 sum alpha_k b_k; the sweep
+            // writes its coefficients beside b (into the sort's index array, idle until the line search) so that b survives
+            // until alpha is known.  Not when the sorted state belongs to a REJECTED V_new (its m is not V_I u, quirk q5), not
+            // without the window cache (the sweeps then search ms0), not when T is wider than the index array (fp64 in LDS).
+            const bool mrec = (fault & 8) && !(fault & 4) && win && sizeof(T) <= sizeof(LI);
+            T* cst = mrec ? reinterpret_cast<T*>(li) : key;
+            ls_free = mrec ? 1 : 0;
             __syncthreads();
             for (int k = 1; k <= cg_max; ++k) {                                 // 10 in the reference (:636)
                 for (int t = tid; t < ld; t += BLOCK) { vecT[t] = (T)pv[t]; Hp[t] = pv[t] * lambda; }
@@ -1662,14 +1671,14 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                 exchange_scores(key, n, r0, r1);
                 UPROF(3);
                 block_excl_scan<BLOCK>([&](int i) { return (double)key[i]; }, Sx, n, red);
-                if (w4) sweep4(key, key, 0.0);
+                if (w4) sweep4(key, cst, 0.0);
                 else for (int p = tid; p < n; p += BLOCK)
-                    key[p] = (T)(wl ? sweep_coeff_win(winL + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)key[p], 0.0)
+                    cst[p] = (T)(wl ? sweep_coeff_win(winL + (size_t)p * S.ws, Sx, rs, nlev, lv0[p], (double)key[p], 0.0)
                                  : win ? sweep_coeff_cached<T>(S, (size_t)s0 + p, Sx, rs, nlev, lv0[p], (double)key[p], 0.0)
                                        : sweep_coeff<T>(ms0, Sx, rs, nlev, lv0[p], ms0[p], (double)key[p], 0.0, strict));
                 __syncthreads();
                 UPROF(4);
-                gather_axpy(key, Hp);
+                gather_axpy(cst, Hp);
                 UPROF(5);
                 ++n_cg;
                 double a = 0.0, b = 0.0;
@@ -1677,6 +1686,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                 const double pHp = block_sum<BLOCK>(a, red);
                 const double rp = block_sum<BLOCK>(b, red);
                 const double alpha = -1.0 * rp / pHp;
+                if (mrec) { const double sa = stepsize0 * alpha; for (int p = tid; p < n; p += BLOCK) ms0[p] = (T)((double)ms0[p] - sa * (double)key[p]); }
                 a = 0.0; b = 0.0;
                 for (int t = tid; t < ld; t += BLOCK) {
                     delta[t] = delta[t] + pv[t] * alpha;
@@ -1708,8 +1718,12 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                 nn = block_sum<BLOCK>(nn, red);
                 __syncthreads();
                 UPROF(6);
-                sddmm(key);                                                     // compute_mm_old (:728-744)
-                if (K > 1) { __syncthreads(); exchange_scores(key, n, r0, r1); }
+                if (mrec && it == 0) {                                          // scores of u - s0 delta from the CG's own b_k
+                    for (int p = tid; p < n; p += BLOCK) key[p] = ms0[p];
+                } else {
+                    sddmm(key);                                                 // compute_mm_old (:728-744)
+                    if (K > 1) { __syncthreads(); exchange_scores(key, n, r0, r1); }
+                }
                 UPROF(7);
                 for (int p = tid; p < npad; p += BLOCK) {
                     if (p < n) li[p] = LiOps<LI>::pack(lv0[p], (unsigned)p);
@@ -1753,7 +1767,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
             if (n_ls) atomicAdd(counters + 1, (unsigned long long)n_ls);
             // rows of V this user's step gathered: gradient + 2 per CG iteration + 1 per line-search try (diagnostic, only
             // with pcr_tune("count_rows"): a third same-address atomic per user costs the short classes 10-20 %)
-            if (fault & 2) atomicAdd(counters + 2, (unsigned long long)n * (unsigned long long)(1 + 2 * n_cg + n_ls));
+            if (fault & 2) atomicAdd(counters + 2, (unsigned long long)n * (unsigned long long)(1 + 2 * n_cg + n_ls - ls_free));
         }
         __syncthreads();
         UPROF(10);

@@ -139,7 +139,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = -1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
-        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_small_unr = 0;
+        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_small_unr = 0, ustep_ls_recur = 1;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -151,7 +151,7 @@ struct Tune {
         ustep_lockstep = pcr_tune_int("ustep_lockstep", -1);
         ustep_gram = pcr_tune_int("ustep_gram", -1); count_rows = pcr_tune_int("count_rows", 0);
         wide_teams = pcr_tune_int("wide_teams", -1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); win16 = pcr_tune_int("win16", 1); sweep_prefetch = pcr_tune_int("sweep_prefetch", -1);
-        ustep_small_unr = pcr_tune_int("ustep_small_unr", 0);
+        ustep_small_unr = pcr_tune_int("ustep_small_unr", 0); ustep_ls_recur = pcr_tune_int("ustep_ls_recur", 1);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -1515,7 +1515,7 @@ struct Solver final : pcr_solver {
             // clusters: grid <= one workgroup per CU so that every member of every cluster is resident
             const int grid = b.ugrid;
             char* scr = d_scratch.p + (size_t)b.scratch_ofs * scratch_stride;
-#define LU(BL, BG, KK, RS, UN) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb, (tune.fault_cluster_member ? 1 : 0) | (tune.count_rows ? 2 : 0), b.wcap)
+#define LU(BL, BG, KK, RS, UN) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb, (tune.fault_cluster_member ? 1 : 0) | (tune.count_rows ? 2 : 0) | (state_of_rejected_V ? 4 : 0) | (tune.ustep_ls_recur ? 8 : 0), b.wcap)
             if (b.gram) {
                 const size_t gl = gram_bytes<T>(b.cap, cap_pad, rsc, geo.ld, nchp, b.block);
                 if (b.block == 64)
