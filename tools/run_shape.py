@@ -16,12 +16,13 @@ ap.add_argument("--f64", action="store_true"); ap.add_argument("--ref", action="
 ap.add_argument("--threads", type=int, default=16); ap.add_argument("-s", type=int, default=2, help="1 PrimalCR, 2 PrimalCR++")
 ap.add_argument("--cg-iters", type=int, default=10); ap.add_argument("--cg-tol", type=float, default=0.01)
 ap.add_argument("--tune", action="append", default=[], help="key=value launch knob (pcr_tune), repeatable")
+ap.add_argument("--numpy-gen", action="store_true", help="the numpy generator for every shape (round 1's Netflix-shaped set: minutes)")
 a = ap.parse_args()
 for kv in a.tune:
     pcr.tune(*kv.split("=", 1))
 t0 = time.time()
 ap_users = None
-if a.shape in ("netflix", "yahoo"):      # the C++ generator (seconds); --d1 N on yahoo = its first N users
+if a.shape in ("netflix", "yahoo") and not a.numpy_gen:      # the C++ generator (seconds); --d1 N on yahoo = its first N users
     R = synth.generate_fast(a.shape, users=(0, a.d1) if (a.shape == "yahoo" and a.d1) else None, d1=None if a.shape == "yahoo" else a.d1, d2=a.d2, nnz=a.nnz, mu=a.mu, sigma=a.sigma)
 else:
     R = synth.generate(a.shape, d1=a.d1, d2=a.d2, nnz=a.nnz, mu=a.mu, sigma=a.sigma)
