@@ -175,6 +175,32 @@ def test_train_cli_on_the_references_own_rating_files(name, tag, args, tmp_path)
         assert re.sub(NUM, "#", a) == re.sub(NUM, "#", b), (a, b)
         tol = 4e-2 if (noisy and a.startswith("(T")) else 6e-6
         assert np.allclose([float(x) for x in re.findall(NUM, a)], [float(x) for x in re.findall(NUM, b)], rtol=tol, atol=tol), (a, b)
+    if noisy:
+        # ... so this configuration's metrics are pinned here WITHOUT those users: the model our CLI wrote and the model of the
+        # oracle's own training run (bit-for-bit the reference's: tests/test_oracle_golden.py), both evaluated by the oracle's
+        # evaluator over the users that do have a comparable pair, must agree to 1e-6 -- and the noise-ranked users' rows must
+        # have been driven to (rounding) zero in both.
+        from oracle.oracle_py import Oracle
+        orc = Oracle()
+        raw = open(tmp_path / "m.model", "rb").read()
+        d1, k = struct.unpack("ll", raw[:16])
+        U = np.frombuffer(raw, np.float64, d1 * k, 16).reshape(d1, k)
+        off = 16 + 8 * d1 * k
+        d2, _ = struct.unpack("ll", raw[off:off + 16])
+        V = np.frombuffer(raw, np.float64, d2 * k, off + 16).reshape(d2, k)
+        X = orc.build_csr(meta["d1"], meta["d2"], u, i, v)
+        Uo, Vo, _ = orc.train(X, orc.initial(meta["d1"], k), orc.initial(meta["d2"], k), meta["lam"], meta["iters"], solver=2, do_predict=0)
+        lv = np.rint(v).astype(np.int64)
+        lo = np.full(meta["d1"], np.iinfo(np.int64).max); hi = np.full(meta["d1"], np.iinfo(np.int64).min)
+        np.minimum.at(lo, u, lv); np.maximum.at(hi, u, lv)
+        flat = np.flatnonzero((hi == lo) & (np.bincount(u, minlength=meta["d1"]) > 0))   # one lround bucket: no comparable pair
+        assert len(flat) == 112
+        assert np.abs(U[flat]).max() < 1e-12 and np.abs(Uo[flat]).max() < 1e-12
+        keep = ~np.isin(u, flat)
+        XT = orc.build_csr_test(meta["d1"], meta["d2"], u[keep], i[keep], v[keep])
+        e_ours, n_ours = orc.eval(U, V, XT)
+        e_ref, n_ref = orc.eval(Uo, Vo, XT)
+        assert abs(e_ours - e_ref) < 1e-6 and abs(n_ours - n_ref) < 1e-6 * max(1.0, abs(n_ref)), (e_ours, e_ref, n_ours, n_ref)
 
 
 def test_gpus_option_bootstrap_without_a_gpu(tmp_path):
