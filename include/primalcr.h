@@ -145,6 +145,8 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  * No environment variable is read anywhere on the product path.
  *   ustep_mode      1 = latency form of k_ustep for every long class, 2 = throughput form (default: by user count)
  *   ustep_many      user count above which a long class counts as throughput-bound (default CUs/4)
+ *   allreduce_chunks N = item ranges of the SpMM whose all-reduces overlap the next range's SpMM (default: 1 on one GPU or below
+ *                   16 MB per vector, else about one per 4 MB, at most 8)
  *   ustep_small_unr 8 = eight rows in flight per lane group in the one-wave and 256-thread classes of k_ustep (default 4)
  *   ustep_ls_recur  0 = k_ustep's first line-search try gathers the rows for its scores (default 1: m - s sum alpha_k b_k from the
  *                   CG's own b_k = V_I p_k, no pass)

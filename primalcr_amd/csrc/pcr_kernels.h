@@ -1165,14 +1165,15 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const i
 template <typename T, int BLOCK, bool DOTS>
 __global__ __launch_bounds__(BLOCK) void k_spmm_fin(const T* __restrict__ slab, const int32_t* __restrict__ item_slot,
                                                     const T* __restrict__ base, double beta, int d2, T* __restrict__ out,
-                                                    Geo geo, const int* skip, const T* __restrict__ rr, double* __restrict__ part) {
+                                                    Geo geo, const int* skip, const T* __restrict__ rr, double* __restrict__ part,
+                                                    int j0 = 0) {                      // items [j0, d2)
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     __shared__ double red[BLOCK / PCR_WAVE + 1];
     if (skip && *skip) return;
     const int G = geo.G, g = threadIdx.x & (G - 1), ipb = BLOCK / G;
     double x = 0.0, y = 0.0, z = 0.0, w = 0.0;
-    for (int j = (int)blockIdx.x * ipb + (int)threadIdx.x / G; j < d2; j += (int)gridDim.x * ipb) {
+    for (int j = j0 + (int)blockIdx.x * ipb + (int)threadIdx.x / G; j < d2; j += (int)gridDim.x * ipb) {
         const int s0 = item_slot[j], s1 = item_slot[j + 1];
         for (int ch = g; ch < geo.nchunk; ch += G) {
             double acc[VEC];

@@ -139,7 +139,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = -1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
-        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_small_unr = 0, ustep_ls_recur = 1;
+        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_small_unr = 0, ustep_ls_recur = 1, allreduce_chunks = 0;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -152,6 +152,7 @@ struct Tune {
         ustep_gram = pcr_tune_int("ustep_gram", -1); count_rows = pcr_tune_int("count_rows", 0);
         wide_teams = pcr_tune_int("wide_teams", -1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); win16 = pcr_tune_int("win16", 1); sweep_prefetch = pcr_tune_int("sweep_prefetch", -1);
         ustep_small_unr = pcr_tune_int("ustep_small_unr", 0); ustep_ls_recur = pcr_tune_int("ustep_ls_recur", 1);
+        allreduce_chunks = pcr_tune_int("allreduce_chunks", 0);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -191,6 +192,15 @@ struct Solver final : pcr_solver {
     DBuf<int2> d_blk_chunks;                      // k_spmm: first chunk and chunk count of every workgroup
     DBuf<int32_t> d_cuf;                          // k_spmm: user id | new-item flag per CSC entry
     int spmm_blocks = 0, spmm_tiles = 1;
+    // Item ranges of the SpMM (N > 1, wide item tables): k_spmm / k_spmm_fin run range by range and the all-reduce of a finished
+    // range overlaps the SpMM of the next one (stream ar_st).  Range r = items [rng_item[r], rng_item[r+1]): the same cut on
+    // every rank (it depends on d2 alone); its workgroups are blk_chunks[rng_blk[r] .. rng_blk[r+1]).
+    int n_rng = 1;
+    std::vector<int64_t> rng_item;
+    std::vector<int> rng_blk;
+    hipStream_t ar_st = nullptr;
+    std::vector<hipEvent_t> ev_rng;
+    hipEvent_t ev_ar = nullptr;
     bool sddmm_csc = false;                       // the CG's SDDMM walks the SpMM's tile-major CSC (item table beyond the L2s)
     DBuf<T> d_slab;                               // k_spmm partial rows, one per (chunk, item) incidence
     bool sweep_pf4 = false;                       // sweeps keep four rounds of per-rating loads in flight (large shards)
@@ -281,6 +291,9 @@ struct Solver final : pcr_solver {
 #endif
         prof_resolve();
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        if (ar_st) { (void)hipStreamSynchronize(ar_st); (void)hipStreamDestroy(ar_st); }
+        for (hipEvent_t e : ev_rng) (void)hipEventDestroy(e);
+        if (ev_ar) (void)hipEventDestroy(ev_ar);
         if (comm) ncclCommDestroy(comm);
         p2p.reset();
         if (h_scal) (void)hipHostFree(h_scal);
@@ -496,7 +509,25 @@ struct Solver final : pcr_solver {
                 tile_u.push_back(nu);
             }
             ntiles = (int64_t)tile_u.size() - 1;
-            std::vector<int32_t> chunk_ptr, tile_chunk0(ntiles + 1, 0);
+            // item ranges (see n_rng): only with an exchange step and a vector of at least 16 MB (about 4 MB per range, at most 8):
+            // a range costs two more launches and its own ramp and tail, which an exchange of a few MB (50-100 us over xGMI)
+            // does not pay for -- the Yahoo!Music shape's 109 MB do (one exchange ~ a third of a CG iteration at N = 8)
+            {
+                const size_t vec_bytes = (size_t)d2 * geo.ld * sizeof(T);
+                n_rng = 1;
+                if (nranks > 1 && vec_bytes >= ((size_t)16 << 20)) n_rng = (int)std::min<size_t>(8, vec_bytes >> 22);
+                if (tune.allreduce_chunks > 0) n_rng = tune.allreduce_chunks;
+                n_rng = (int)std::max<int64_t>(1, std::min<int64_t>(n_rng, std::min<int64_t>(64, d2)));
+                rng_item.assign(n_rng + 1, 0);
+                for (int r = 0; r <= n_rng; ++r) rng_item[r] = d2 * r / n_rng;
+                if (n_rng > 1) {
+                    HIPCHK(hipStreamCreateWithFlags(&ar_st, hipStreamNonBlocking));
+                    HIPCHK(hipEventCreateWithFlags(&ev_ar, hipEventDisableTiming));
+                    ev_rng.resize(n_rng);
+                    for (auto& e : ev_rng) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                }
+            }
+            std::vector<int32_t> chunk_ptr, trc0((size_t)ntiles * n_rng + 1, 0);      // first chunk of (tile, range)
             std::vector<int64_t> cur(d2);
             int64_t q = 0;
             for (int64_t t = 0; t < ntiles; ++t) {
@@ -504,16 +535,21 @@ struct Solver final : pcr_solver {
                 for (int64_t z = uptr[tile_u[t]]; z < uptr[tile_u[t + 1]]; ++z) cur[item[z]]++;
                 int64_t run = q;
                 for (int64_t j = 0; j < d2; ++j) { const int64_t n = cur[j]; cur[j] = run; run += n; }
+                std::vector<int64_t> cut(n_rng + 1);                       // where the tile's entries cross into each item range
+                for (int r = 0; r < n_rng; ++r) cut[r] = rng_item[r] < d2 ? cur[rng_item[r]] : run;
+                cut[n_rng] = run;
                 for (int64_t u = tile_u[t]; u < tile_u[t + 1]; ++u)
                     for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) {
                         const int64_t p = cur[item[z]]++;
                         cpos[z] = (int32_t)p; cuser[p] = (int32_t)u; crow[p] = item[z];
                     }
-                tile_chunk0[t] = (int32_t)chunk_ptr.size();
-                for (int64_t a = q; a < run; a += spmm_chunk) chunk_ptr.push_back((int32_t)a);      // chunks never straddle tiles
+                for (int r = 0; r < n_rng; ++r) {
+                    trc0[(size_t)t * n_rng + r] = (int32_t)chunk_ptr.size();
+                    for (int64_t a = cut[r]; a < cut[r + 1]; a += spmm_chunk) chunk_ptr.push_back((int32_t)a);   // chunks never straddle tiles or ranges
+                }
                 q = run;
             }
-            tile_chunk0[ntiles] = (int32_t)chunk_ptr.size();
+            trc0[(size_t)ntiles * n_rng] = (int32_t)chunk_ptr.size();
             const int64_t nchunks = (int64_t)chunk_ptr.size();
             chunk_ptr.push_back((int32_t)nnz_local);
             // (chunk, item) incidences in chunk order -> item-major slab rows: the slots of one item are consecutive
@@ -531,19 +567,30 @@ struct Solver final : pcr_solver {
                 std::vector<int32_t> nxt(item_slot.begin(), item_slot.end() - 1);
                 for (size_t i = 0; i < inc_item.size(); ++i) slot_id[i] = nxt[inc_item[i]]++;
             }
-            // workgroup -> chunks: gpb chunks per workgroup, never across tiles; tile t is walked by workgroups b = t mod 8 (mod 8)
+            // workgroup -> chunks: gpb chunks per workgroup, never across tiles; tile t is walked by workgroups b = t mod 8 (mod 8).
+            // One plan per item range, back to back (each a multiple of 8 workgroups, so the affinity holds in a launch of one range
+            // as in a launch of all of them).
             const int gpb = 256 / geo.G;
-            std::vector<std::vector<int2>> per_xcd(8);
-            size_t rr8 = 0;
-            for (int64_t t = 0; t < ntiles; ++t)
-                for (int32_t c = tile_chunk0[t]; c < tile_chunk0[t + 1]; c += gpb)       // fewer than 8 tiles: no affinity, use every XCD
-                    per_xcd[ntiles >= 8 ? t % 8 : rr8++ % 8].push_back(make_int2(c, std::min<int32_t>(gpb, tile_chunk0[t + 1] - c)));
-            size_t deepest = 0;
-            for (auto& v : per_xcd) deepest = std::max(deepest, v.size());
-            std::vector<int2> blk(deepest * 8, make_int2(0, 0));
-            for (int x = 0; x < 8; ++x)
-                for (size_t i = 0; i < per_xcd[x].size(); ++i) blk[i * 8 + x] = per_xcd[x][i];
-            spmm_blocks = (int)blk.size();
+            std::vector<int2> blk;
+            rng_blk.assign(n_rng + 1, 0);
+            for (int r = 0; r < n_rng; ++r) {
+                std::vector<std::vector<int2>> per_xcd(8);
+                size_t rr8 = 0;
+                for (int64_t t = 0; t < ntiles; ++t) {
+                    const int32_t c0 = trc0[(size_t)t * n_rng + r], c1 = trc0[(size_t)t * n_rng + r + 1];
+                    for (int32_t c = c0; c < c1; c += gpb)                                // fewer than 8 tiles: no affinity, use every XCD
+                        per_xcd[ntiles >= 8 ? t % 8 : rr8++ % 8].push_back(make_int2(c, std::min<int32_t>(gpb, c1 - c)));
+                }
+                size_t deepest = 0;
+                for (auto& v : per_xcd) deepest = std::max(deepest, v.size());
+                const size_t base = blk.size();
+                blk.resize(base + deepest * 8, make_int2(0, 0));
+                for (int x = 0; x < 8; ++x)
+                    for (size_t i = 0; i < per_xcd[x].size(); ++i) blk[base + i * 8 + x] = per_xcd[x][i];
+                rng_blk[r + 1] = (int)blk.size();
+            }
+            if (blk.empty()) blk.push_back(make_int2(0, 0));
+            spmm_blocks = rng_blk[n_rng];
             {   // k_spmm's per-entry word: the user id, and in the sign bit "a new item starts here" (never at a chunk start)
                 std::vector<int32_t> cuf(cuser);
                 for (int64_t c = 0; c < nchunks; ++c)
@@ -1168,28 +1215,61 @@ struct Solver final : pcr_solver {
     // out = beta * base + sum c * U-rows (item-major, deterministic slab reduction)
     // dots_rr != nullptr: also leave the partials of base.out and dots_rr.base in d_partA (k_spmm_fin DOTS)
     int fin_blocks() const { return (int)std::min<int64_t>(1024, cdiv(d2, 256 / geo.G)); }
-    int launch_spmm(T* out, const T* base, double beta, const int* skip = nullptr, const T* dots_rr = nullptr) {
-        if (nnz_local > 0) {
+    // one item range of the SpMM: k_spmm over the range's workgroups, k_spmm_fin over its items
+    int launch_spmm_range(int r, T* out, const T* base, double beta, const int* skip, const T* dots_rr) {
+        if (nnz_local > 0 && rng_blk[r + 1] > rng_blk[r]) {
             ProfScope ps(this, "spmm");
-            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(spmm_blocks), dim3(256), 0, st, d_c.p, d_c2r.p, d_cuf.p,
-                               d_chunk_ptr.p, d_slot_base.p, d_slot_id.p, d_blk_chunks.p, d_U.p, d_slab.p, geo, skip);
+            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(rng_blk[r + 1] - rng_blk[r]), dim3(256), 0, st, d_c.p, d_c2r.p, d_cuf.p,
+                               d_chunk_ptr.p, d_slot_base.p, d_slot_id.p, d_blk_chunks.p + rng_blk[r], d_U.p, d_slab.p, geo, skip);
         }
+        const int j0 = (int)rng_item[r], j1 = (int)rng_item[r + 1];
+        if (j1 <= j0) return PCR_OK;
+        const int grid = n_rng == 1 ? fin_blocks() : (int)std::min<int64_t>(1024, cdiv(j1 - j0, 256 / geo.G));
         ProfScope ps2(this, "spmm_fin");
-        if (dots_rr) hipLaunchKernelGGL((k_spmm_fin<T, 256, true>), dim3(fin_blocks()), dim3(256), 0, st, d_slab.p, d_item_slot.p, base, beta, (int)d2, out, geo, skip, dots_rr, d_partA.p);
-        else hipLaunchKernelGGL((k_spmm_fin<T, 256, false>), dim3(fin_blocks()), dim3(256), 0, st, d_slab.p, d_item_slot.p, base, beta, (int)d2, out, geo, skip, (const T*)nullptr, (double*)nullptr);
+        if (dots_rr) hipLaunchKernelGGL((k_spmm_fin<T, 256, true>), dim3(grid), dim3(256), 0, st, d_slab.p, d_item_slot.p, base, beta, j1, out, geo, skip, dots_rr, d_partA.p, j0);
+        else hipLaunchKernelGGL((k_spmm_fin<T, 256, false>), dim3(grid), dim3(256), 0, st, d_slab.p, d_item_slot.p, base, beta, j1, out, geo, skip, (const T*)nullptr, (double*)nullptr, j0);
+        return PCR_OK;
+    }
+    // out = beta * base + sum c * U-rows (item-major, deterministic slab reduction), summed over the ranks.
+    // dots_rr != nullptr (one GPU, one range): also leave the partials of base.out and dots_rr.base in d_partA (k_spmm_fin DOTS)
+    // With item ranges (n_rng > 1) the all-reduce of range r runs on its own stream while the SpMM of range r + 1 computes: the
+    // ranges are queued one ahead of the exchange, so this holds for the host-driven peer-to-peer exchange as for RCCL.
+    int launch_spmm(T* out, const T* base, double beta, const int* skip = nullptr, const T* dots_rr = nullptr) {
+        const size_t n = (size_t)d2 * geo.ld;
+        if (n_rng == 1) {
+            RC(launch_spmm_range(0, out, base, beta, skip, dots_rr));
+            HIPCHK(hipGetLastError());
+            return allreduce_T(out, n);
+        }
+        const bool exch = !single();
+        auto queue = [&](int r) -> int {
+            RC(launch_spmm_range(r, out, base, beta, skip, nullptr));
+            if (exch) HIPCHK(hipEventRecord(ev_rng[r], st));
+            return PCR_OK;
+        };
+        RC(queue(0));
+        for (int r = 0; r < n_rng; ++r) {
+            if (r + 1 < n_rng) RC(queue(r + 1));
+            if (!exch) continue;
+            HIPCHK(hipStreamWaitEvent(ar_st, ev_rng[r], 0));
+            const size_t lo = (size_t)rng_item[r] * geo.ld, hi = (size_t)rng_item[r + 1] * geo.ld;
+            if (hi > lo) RC(allreduce_T(out + lo, hi - lo, ar_st));
+        }
+        if (exch) { HIPCHK(hipEventRecord(ev_ar, ar_st)); HIPCHK(hipStreamWaitEvent(st, ev_ar, 0)); }
         HIPCHK(hipGetLastError());
         return PCR_OK;
     }
 
-    int allreduce_T(T* buf, size_t count) {
+    int allreduce_T(T* buf, size_t count, hipStream_t q = nullptr) {
         if (single()) return PCR_OK;
         if (!comm && !p2p) { pcr_set_error("nranks > 1 but neither pcr_solver_comm_init nor pcr_solver_comm_init_p2p was called"); return PCR_ERR_STATE; }
-        ProfScope ps(this, "allreduce");
+        if (!q) q = st;
+        ProfScope ps(this, "allreduce", q);
         if (p2p) {
-            if (!p2p->allreduce<T>(buf, count, st)) { pcr_set_error("p2p all-reduce: " + p2p->err); return PCR_ERR_COMM; }
+            if (!p2p->allreduce<T>(buf, count, q)) { pcr_set_error("p2p all-reduce: " + p2p->err); return PCR_ERR_COMM; }
             return PCR_OK;
         }
-        NCCLCHK(ncclAllReduce(buf, buf, count, sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, comm, st));
+        NCCLCHK(ncclAllReduce(buf, buf, count, sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, comm, q));
         return PCR_OK;
     }
     int allreduce_f64(double* buf, size_t count) {
@@ -1323,9 +1403,7 @@ struct Solver final : pcr_solver {
     // g = lambda V + sum_i sum_j c_ij u_i   (pcrpp.cpp:140-249) into d_g
     int device_gradient() {
         RC(launch_vsweep(false, nullptr));
-        RC(launch_spmm(d_g.p, d_V.p, rank == 0 ? prm.lambda : 0.0));      // rank 0 carries the lambda*V term
-        RC(allreduce_T(d_g.p, (size_t)d2 * geo.ld));
-        return PCR_OK;
+        return launch_spmm(d_g.p, d_V.p, rank == 0 ? prm.lambda : 0.0);    // rank 0 carries the lambda*V term; summed over the ranks
     }
     int obtain_g(double* g) override {
         RC(need_sorted());
@@ -1335,9 +1413,7 @@ struct Solver final : pcr_solver {
     // out = lambda p + sum c(b) u   (the lambda term on rank 0 only; summed by the all-reduce)
     int device_hv(const T* pvec, T* out, const int* skip = nullptr, const T* dots_rr = nullptr) {
         RC(launch_vsweep(true, pvec, skip));
-        RC(launch_spmm(out, pvec, rank == 0 ? prm.lambda : 0.0, skip, dots_rr));
-        RC(allreduce_T(out, (size_t)d2 * geo.ld));
-        return PCR_OK;
+        return launch_spmm(out, pvec, rank == 0 ? prm.lambda : 0.0, skip, dots_rr);
     }
     int compute_Ha(const double* a, double* Ha) override {
         RC(need_sorted());
@@ -1360,7 +1436,7 @@ struct Solver final : pcr_solver {
         const int* skip = &d_cgp->done;
         // one GPU: Hp is final when k_spmm_fin stores it, so that kernel also produces the p.Hp / rr.p partials;
         // with an all-reduce in between they need their own pass (k_cg_a)
-        const bool fused_dots = single();
+        const bool fused_dots = single() && n_rng == 1;
         const bool exact_rr = prm.cg_tol < 1e-5;                   // the residual recurrence of k_cg_bc cancels below that
         for (int k = 1; k <= prm.cg_max_iter; ++k) {
             RC(device_hv(d_p.p, d_Hp.p, skip, fused_dots ? d_rr.p : nullptr));

@@ -261,6 +261,28 @@ def test_gpus_option_two_ranks_on_one_gpu_equal_one_rank(solver, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranks,chunks", [(2, 3), (3, 7)])
+def test_gpus_option_item_ranges_overlap_the_exchange(ranks, chunks, tmp_path):
+    """The SpMM item range by item range, each range's all-reduce on its own stream while the next range computes
+    (pcr_tune allreduce_chunks; chosen by itself for vectors of 4 MB and more): fp64 over the peer-to-peer exchange on the one
+    GPU, objective lines to the printed digits and the model to summation-order rounding against one rank."""
+    g, meta, d = golden_dir("mid5", tmp_path)
+    base = [TRAIN, "-k", str(int(g["r"])), "-l", repr(float(g["lam"])), "-t", "3", "--f64", "-p", "0"]
+    one = run(base + [d, "one.model"], tmp_path)
+    many = run(base + ["--gpus", str(ranks), "--devices", ",".join(["0"] * ranks), "--comm", "p2p", "--tune", f"allreduce_chunks={chunks}",
+                       d, "many.model"], tmp_path)
+    assert one.returncode == 0 and many.returncode == 0, many.stderr
+    la = [l for l in one.stdout.split("\n") if l.startswith("Iter")]; lb = [l for l in many.stdout.split("\n") if l.startswith("Iter")]
+    assert len(la) == len(lb) == 4
+    for x, y in zip(la, lb):
+        fx = [float(v) for v in re.findall(NUM, x)]; fy = [float(v) for v in re.findall(NUM, y)]
+        assert np.allclose(fx[:1] + fx[2:], fy[:1] + fy[2:], rtol=2e-5, atol=2e-6), (x, y)
+    a = np.frombuffer(open(tmp_path / "one.model", "rb").read(), np.float64)
+    b = np.frombuffer(open(tmp_path / "many.model", "rb").read(), np.float64)
+    assert a.shape == b.shape and np.nanmax(np.abs(a[2:] - b[2:])) < 1e-9 * np.nanmax(np.abs(a[2:]))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [3, 5])
 def test_gpus_option_three_ranks_default_precision(n, tmp_path):
     """Three / five ranks on the one GPU in the default precision (fp32 storage): quality lines within 1e-3 of one rank."""

@@ -270,6 +270,7 @@ VARIANTS = [
     {"ustep_lockstep": "1"}, {"ustep_lockstep": "1", "window_cache": "0"},   # the U step as rating-parallel lock-step passes (large-shard form)
     {"window_cache": "0"}, {"prepare_merged": "0"}, {"ustep_seq": "1"}, {"pipeline": "0"},   # searching sweeps, per-class prepare, serial classes
     {"sddmm_csc": "1"}, {"sddmm_csc": "1", "spmm_tiles": "16"},   # the CG's SDDMM over the tile-major CSC (wide item tables)
+    {"allreduce_chunks": "3"}, {"allreduce_chunks": "5", "spmm_tiles": "16"}, {"allreduce_chunks": "4", "sddmm_csc": "1"},   # SpMM item range by item range (the N > 1 overlap form)
 ]
 
 
