@@ -3,7 +3,10 @@
 + NDCG@10 on ml1m-shaped synthetic ratings, rank 100, lambda 5000, on N MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 without a launcher: the N ranks are started as CHILD processes (python -m torch.distributed.run
+--nproc-per-node N ... bench.py, 127.0.0.1 rendezvous) before this process imports torch or touches a
+GPU, and rank 0's JSON line is relayed; started under torch.distributed.run it is one of the ranks.
 
 A "step" is one outer iteration of pcrpp() (pcrpp.cpp:873-881): one truncated-Newton step on V
 (gradient, <=10 CG Hessian-vector products, line search) and one Newton step per user on U -- the
@@ -11,21 +14,29 @@ same clock scope as the reference's "Iter k time" (no load, no init, no evaluati
 (ratings, factors) are resident in HBM before the timed region starts.
 
 value = #Omega * K / seconds, #Omega = #{(i,j,k): R_ij > R_ik} = the ordered pairs the objective
-sums over.  N > 1 is WEAK scaling: each rank owns 6040 more users of the same item catalogue
-(user-sharded; V-gradient and every Hessian-vector product are all-reduced over RCCL).
+sums over (all ranks).  User-sharded (pcrpp.cpp:825-833): every rank generates and holds ONLY its own users
+(pcr_solver_create_shard), V and the CG vectors are replicated, the V-gradient and every Hessian-vector
+product are all-reduced over RCCL.
+  --shape ml1m     WEAK scaling: rank q owns 6040 users / 939 809 ratings of its own (the numpy generator's set of seed
+                   SEED + q over the item catalogue of seed SEED; rank 0's block is the N = 1 workload, configs[1])
+  --shape netflix  configs[3]: 480 189 x 17 770, 100 M ratings, nnz-balanced user ranges (strong scaling)
+  --shape yahoo    configs[4]: 1.8 M x 136 k, 700 M ratings, k = 200: the first 225 000 N users (N = 8: all of them)
 
 The JSON line also carries
-  roofline      the kernel with the largest share of the timed region: algorithmic bytes per launch
-                 / its average duration from HIP events recorded on the
-                solver's stream during the timed region, against the 8 TB/s HBM3E peak
-  cpu_baseline  the reference's own OpenMP path (oracle/_ref/omp-pmf-train, built from the unmodified
-                reference) on the same data on this host's cores, 2 iterations (rank 0, N = 1 only);
-                falls back to the single-thread C restatement on a user sample when _ref is absent.
+  roofline      the kernel slot with the most GPU time: algorithmic bytes per launch / its average duration
+                from HIP events on its launch stream, against the 8 TB/s HBM3E peak -- and `binding`: the level of the
+                memory hierarchy that actually serves its row gathers (l2-gather / mall-gather / hbm-gather by the size of
+                the gathered table), its measured ceiling from MI355X_MICROARCH.md and the fraction of THAT
+  cpu_baseline  the reference's own OpenMP path (oracle/_ref/omp-pmf-train, built from the unmodified reference) on the same
+                data on this host's cores (rank 0, N = 1 only); the single-thread C restatement when _ref is absent
+  f64           the same K steps with fp64 storage (the reference's arithmetic type), with its own roofline blocks
+  netflix       (default N = 1 run) configs[3] on this GPU: a few steps of the Netflix-shaped set, same fields
 """
 import argparse
 import json
 import os
 import re
+import socket
 import subprocess
 import sys
 import tempfile
@@ -37,18 +48,33 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-TRAFFIC_FILE = "r02_traffic.json"   # PMC passes of this command at this round's kernels (tools/collect_profiles.sh)
+# MI355X_MICROARCH.md, "Indexed rows": measured chip-wide row-gather ceilings by where the table is served from
+GATHER_CEILING_GBS = {"l2-gather": 18800.0,     # table shared by every workgroup, in each XCD's 4 MiB L2: 16.8-18.8 TB/s
+                      "mall-gather": 8600.0,    # 38 MB table, uniformly random rows (Infinity Cache): 8.6 TB/s; 151 MB: 7.4-7.9
+                      "hbm-gather": 6100.0}     # tables beyond the 256 MiB Infinity Cache: 6.0-6.1 TB/s
+TRAFFIC_FILE = "r03_traffic.json"   # PMC passes of this command at this round's kernels (tools/collect_profiles.sh)
 USERS_PER_GPU = 6040
 D2, NNZ_PER_GPU = 3952, 939809
+YAHOO_USERS_PER_GPU = 225000
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def gather_level(table_bytes):
+    """Which level serves uniformly random row gathers from a table of that size (MI355X_MICROARCH.md: 4 MiB L2 per XCD,
+    every XCD caching its own copy; 256 MiB Infinity Cache)."""
+    if table_bytes <= (4 << 20):
+        return "l2-gather"
+    if table_bytes <= (256 << 20):
+        return "mall-gather"
+    return "hbm-gather"
+
+
 def algorithmic_bytes(slot, nnz_b, nu_b, d2, r, esz):
     """Compulsory HBM bytes of ONE launch of a per-user kernel over a length bin holding nnz_b
-    ratings of nu_b users (ideal caching: every operand crosses HBM once).  DESIGN.md section 4."""
+    ratings of nu_b users (ideal caching: every operand crosses HBM once).  DESIGN.md section 3.5."""
     F_U = nu_b * r * esz           # the bin's user factors
     F_V = d2 * r * esz             # one item-side matrix
     cls = slot.split("/")[0]
@@ -77,7 +103,7 @@ SLOT_KERNEL = {"sddmm": "void k_sddmm<", "spmm": "void k_spmm<", "spmm_fin": "vo
 
 
 def slot_kernel_match(slot, kernel_name, prec):
-    """Does a rocprof kernel name belong to this HIP-event slot (class/workgroup size[.bound][g][c][t])?"""
+    """Does a rocprof kernel name belong to this HIP-event slot (class/workgroup size[.bound][g][c][#symbol id])?"""
     cls, _, tag = slot.partition("/")
     if not kernel_name.startswith(SLOT_KERNEL.get(cls, "\0")):
         return False
@@ -96,6 +122,7 @@ def slot_kernel_match(slot, kernel_name, prec):
         return False
     if not tag:
         return True
+    tag, _, sym = tag.partition("#")                           # k_ustep: the symbol id of classes that share a workgroup form
     flags = tag.lstrip("0123456789.")
     block = tag[:len(tag) - len(flags)].partition(".")[0]
     big, clu = "g" in flags, "c" in flags
@@ -104,7 +131,7 @@ def slot_kernel_match(slot, kernel_name, prec):
     if cls in ("vgrad", "vhv"):
         return (args[3] == "true") == (cls == "vhv")
     if cls == "ustep":
-        return (args[3] != "1") == clu
+        return (args[3] != "1") == clu and (len(args) < 7 or args[6] == (sym or "0"))
     return True
 
 
@@ -121,17 +148,17 @@ def host_cores():
     return n
 
 
-def cpu_baseline(R, n_pairs, r, lam):
+def cpu_baseline(R, n_pairs, r, lam, sample_ratings=2_000_000, single_thread=True):
     """Reference OpenMP path on this host (kind "reference"), else the C restatement (kind "port").
     BASELINE.md 3.3: timed at -n <all cores of this box's share> AND at -n 1.
-    Bounded: data sets beyond 2 M ratings are timed on a prefix of their users (same shape, fewer users)."""
+    Bounded: data sets beyond `sample_ratings` ratings are timed on a prefix of their users (same shape, fewer users)."""
     from oracle import oracle_py
     from primalcr_amd import synth
     cores = host_cores()
     sample_note = "the full data set"
     user, tuser = R.user, R.tuser
-    if R.nnz > 2_000_000:
-        nu = int(user[2_000_000])                 # whole users within the first 2 M ratings (triplets are user-sorted)
+    if R.nnz > sample_ratings:
+        nu = int(user[sample_ratings])            # whole users within the first `sample_ratings` ratings (triplets are user-sorted)
         keep, tkeep = user < nu, tuser < nu
         R = synth.Ratings(nu, R.d2, user[keep], R.item[keep], R.val[keep], tuser[tkeep], R.titem[tkeep], R.tval[tkeep])
         n_pairs = synth.count_pairs(R)
@@ -151,12 +178,14 @@ def cpu_baseline(R, n_pairs, r, lam):
             d = synth.write_dir(R, os.path.join(td, "data"))
             it_all, it_one = 2, 1
             secs = ref_run(cores, it_all, d, td)
-            secs1 = ref_run(1, it_one, d, td)
-        return {"value": n_pairs * it_all / secs, "unit": "pairs/s", "cores": cores, "kind": "reference",
-                "sample": f"omp-pmf-train -s 2 -k {r} -l {lam:g} -t {it_all} -p 0 -n {cores} on {sample_note}; "
-                          f"'Iter {it_all} time' = {secs:.3f} s", "s_per_iter": secs / it_all,
-                "single_thread": {"value": n_pairs * it_one / secs1, "unit": "pairs/s", "cores": 1, "s_per_iter": secs1 / it_one,
-                                  "sample": f"the same command with -n 1 -t {it_one}: 'Iter {it_one} time' = {secs1:.3f} s"}}
+            secs1 = ref_run(1, it_one, d, td) if single_thread else None
+        out = {"value": n_pairs * it_all / secs, "unit": "pairs/s", "cores": cores, "kind": "reference",
+               "sample": f"omp-pmf-train -s 2 -k {r} -l {lam:g} -t {it_all} -p 0 -n {cores} on {sample_note}; "
+                         f"'Iter {it_all} time' = {secs:.3f} s", "s_per_iter": secs / it_all}
+        if secs1 is not None:
+            out["single_thread"] = {"value": n_pairs * it_one / secs1, "unit": "pairs/s", "cores": 1, "s_per_iter": secs1 / it_one,
+                                    "sample": f"the same command with -n 1 -t {it_one}: 'Iter {it_one} time' = {secs1:.3f} s"}
+        return out
     orc = oracle_py.Oracle()
     nu = 400
     keep = R.user < nu
@@ -169,20 +198,70 @@ def cpu_baseline(R, n_pairs, r, lam):
             "sample": f"C restatement, first {nu} users ({int(keep.sum())} ratings, {pairs} pairs), 1 iteration = {secs:.2f} s"}
 
 
-def timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, local_rank, args, profile, shm_name, count_rows=False):
+class Job:
+    """The process group (or none) and this rank's place in it."""
+
+    def __init__(self, args, torch, dist, rank, N, device):
+        self.args, self.torch, self.dist, self.rank, self.N, self.device = args, torch, dist, rank, N, device
+
+    def allsum(self, x):
+        if self.N == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda" if self.args.rendezvous == "nccl" else "cpu")
+        self.dist.all_reduce(t)
+        return type(x)(t.item())
+
+    def allmax(self, x):
+        if self.N == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda" if self.args.rendezvous == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def bcast(self, obj):
+        if self.N == 1:
+            return obj
+        box = [obj if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+
+def make_shard(shape, job, users=None, nnz=None):
+    """This rank's users of the workload, and nothing else: (ratings of the shard, first user, users of the job, notes)."""
+    import primalcr_amd as pcr
+    from primalcr_amd import synth
+    rank, N = job.rank, job.N
+    if shape == "ml1m":
+        nu, nz = users or USERS_PER_GPU, nnz or NNZ_PER_GPU
+        R = synth.generate("ml1m", seed=synth.SEED + rank, d1=nu, nnz=nz, item_seed=synth.SEED if rank else None)
+        return R, rank * nu, nu * N, "weak", nz * N
+    s = synth.SHAPES[shape]
+    d1_shape = s[0] if (users is None or shape == "yahoo") else users       # netflix --users: a smaller shape; yahoo --users: a prefix
+    ctr, _ = synth.generate_fast(shape, d1=None if shape == "yahoo" else d1_shape, nnz=nnz, counts_only=True)
+    total = d1_shape if shape == "netflix" else min(s[0], users or YAHOO_USERS_PER_GPU * N)
+    index = np.concatenate([[0], np.cumsum(ctr[:total])]).astype(np.int64)
+    bounds = pcr.partition_users(index, N)                                   # nnz-balanced contiguous user ranges (SURVEY 8e)
+    u0, u1 = int(bounds[rank]), int(bounds[rank + 1])
+    R = synth.generate_fast(shape, d1=None if shape == "yahoo" else d1_shape, nnz=nnz, users=(u0, u1))
+    return R, u0, total, "strong", int(index[-1])
+
+
+def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name, count_rows=False):
     """One solver, `warmup` untimed + exactly `steps` timed outer iterations (barrier + synchronize on both sides, MAX over
     ranks), then the quality after warmup + steps iterations."""
-    p = pcr.Parameter(k=r, precision=prec, device=local_rank, do_predict=0, maxiter=1, **{"lambda": lam})
+    import primalcr_amd as pcr
+    args, torch, dist, rank, N = job.args, job.torch, job.dist, job.rank, job.N
+    first, total = shard
+    p = pcr.Parameter(k=r, precision=prec, device=job.device, do_predict=0, maxiter=1, **{"lambda": lam})
     with pcr.tuned(**({"count_rows": 1} if count_rows else {})):
-        s = pcr.Solver(ds, p, rank, N)
+        s = pcr.Solver(ds, p, rank, N, shard=shard)
     if N > 1:
         if args.comm == "p2p":
             s.comm_init_p2p(shm_name + ("_64" if prec == pcr.PCR_F64 else "_32") + ("c" if count_rows else ""))
         else:
-            ids = [pcr.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            s.comm_init(ids[0])
-    s.set_factors(pcr.initial(R.d1, r), pcr.initial(R.d2, r))       # the reference's init stream (util.cpp:80)
+            s.comm_init(job.bcast(pcr.comm_unique_id() if rank == 0 else None))
+    # the reference's init stream (util.cpp:80): this rank's rows of initial(d1, k), and V = initial(d2, k)
+    s.set_factors_local(pcr.initial_rows(total, r, first, s.n_users), pcr.initial(d2, r))
 
     def barrier():
         s.sync()
@@ -190,12 +269,12 @@ def timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, local_rank, args, 
         if N > 1:
             dist.barrier()
 
-    objs = [rec["obj"] for rec in s.iterate(args.warmup)]
+    objs = [rec["obj"] for rec in s.iterate(warmup)]
     prof_period = 0
     if profile:
         # sampled: every n-th launch of each kernel carries an event pair (an event pair costs ~3 us of queue time: every 4th
         # launch adds 6.6 % to the timed region, every 16th 1.9 %, with the same per-kernel averages)
-        prof_period = args.profile_period if args.profile_period > 0 else max(1, min(16, 11 * args.steps // 12))
+        prof_period = args.profile_period if args.profile_period > 0 else max(1, min(16, 11 * steps // 12))
         s.profile(True, period=prof_period)
         s.profile_reset()
     barrier()
@@ -203,27 +282,268 @@ def timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, local_rank, args, 
     t0 = time.perf_counter()
     inner = {"cg_v": 0, "ls_v": 0, "cg_u": 0, "ls_u": 0}
     # exactly K steps = K outer iterations (V step + U step) of the training loop, as pcr_train runs them (pcr_iterate)
-    for rec in s.iterate(args.steps):
+    for rec in s.iterate(steps):
         objs.append(rec["obj"])
         for key in inner:
             inner[key] += rec[key]
     barrier()
-    secs = time.perf_counter() - t0
-    if N > 1:
-        tt = torch.tensor([secs], device="cuda" if args.rendezvous == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        secs = float(tt.item())
+    secs = job.allmax(time.perf_counter() - t0)
     prof = s.profile_all() if profile else {}
     launches = {name: s.profile_launches(name) for name in prof}
     scope = {name: s.profile_scope(name) for name in prof}
     s.profile(False)
+    rows_by_class = s.class_row_gathers() if count_rows else {}
     te_err, te_ndcg = s.evaluate(1, 10)
     tr_err, tr_ndcg = s.evaluate(0, 10)
     out = dict(secs=secs, objs=objs, inner=inner, prof=prof, launches=launches, scope=scope, prof_period=prof_period,
-               u_rows=s.counter("ustep_row_gathers") - rows0,
+               u_rows=s.counter("ustep_row_gathers") - rows0, rows_by_class=rows_by_class, steps=steps,
                te=(te_err, te_ndcg), tr=(tr_err, tr_ndcg), comm_nranks=s.comm_nranks(), shard=(s.first_user, s.n_users, s.nnz_local))
     s.close()
     return out
+
+
+def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False):
+    """Roofline blocks of one timed run.  wl: dict(d1, d2, nnz, r) of the JOB; run["shard"] is this rank's part."""
+    secs, inner, prof, steps = run["secs"], run["inner"], run["prof"], run["steps"]
+    d1, d2, nnz, r = wl["d1"], wl["d2"], wl["nnz"], wl["r"]
+    esz = 4 if prec_name == "f32" else 8
+    ld = (r + 3) & ~3
+    nu_loc, nnz_loc = run["shard"][1], run["shard"][2]
+    # which level of the hierarchy serves the row gathers (DESIGN.md 3.5): the per-user kernels and k_sddmm gather rows of the
+    # item table V (d2 x ld x esz); k_spmm (and k_sddmm in its tile-major form, item tables beyond the L2s) gathers rows of U
+    # from a user tile cut to fit one XCD's L2 (<= 1.25 MB)
+    v_table = d2 * ld * esz
+    lvl_v = gather_level(v_table)
+    lvl_slot = lambda cls: "l2-gather" if cls == "spmm" or (cls == "sddmm" and v_table > (32 << 20)) else lvl_v
+    u_rows = (rows_run or {}).get("u_rows", 0)
+    rows_by_class = (rows_run or {}).get("rows_by_class", {})
+    roof, roof_phase, kernels = None, {}, {}
+    if prof:
+        traffic, traffic_src = {}, None
+        tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)      # PMC passes of this command (tools/pmc_traffic.py)
+        if os.path.exists(tpath) and traffic_key:
+            tj = json.load(open(tpath)).get("workloads", {}).get(traffic_key)      # taken on exactly this workload, or absent
+            if tj:
+                traffic, traffic_src = tj.get("kernels", {}), tj.get("source")
+        # Launches are SAMPLED, so a slot's time in the region is its average times ALL its launches.
+        est = {name: ((ms / n) * max(run["launches"][name], n) if n else 0.0) for name, (ms, n) in prof.items()}
+        total_ms = sum(v for k, v in est.items() if not k.startswith("wall:"))
+        for name, (ms, n) in prof.items():
+            cls, _, tag = name.partition("/")
+            if cls not in SLOT_KERNEL or n == 0:
+                continue
+            nnz_b, nu_b = run["scope"][name]              # ratings / users one launch of this slot covers
+            ab = algorithmic_bytes(name, nnz_b, nu_b, d2, r, esz)
+            avg_s = ms / n / 1e3
+            tr = None
+            # (every k_ustep length class has a kernel symbol of its own -- template parameter CLS -- so a per-symbol PMC
+            # average belongs to one slot; a slot that still shares its symbol with another one carries no traffic figure)
+            shared = sum(1 for other in prof if other != name and prof[other][1] and other.partition("/")[0] == cls and
+                         any(slot_kernel_match(other, kn, prec_name) and slot_kernel_match(name, kn, prec_name) for kn in traffic))
+            for kname, t in traffic.items():
+                if not shared and slot_kernel_match(name, kname, prec_name):
+                    # MI355X_MICROARCH.md (HBM): FETCH_SIZE counts wide coalesced reads at half their bytes on gfx950 ->
+                    # doubled; WRITE_SIZE is exact
+                    tr = int(2 * t["fetch_bytes_per_launch_raw"] + t["write_bytes_per_launch"])
+            # row gathers of one launch: one ld*esz-byte factor row per rating and half-pass
+            g_rows = {"sddmm": nnz_b, "spmm": nnz_b}.get(cls)
+            if cls == "ustep" and name in rows_by_class and run["launches"][name]:
+                g_rows = rows_by_class[name] / max(rows_run["launches_counted"].get(name, 0), 1)
+            kernels[name] = {"avg_us": round(avg_s * 1e6, 2), "timed_launches": int(n), "launches": int(run["launches"][name]),
+                             "gpu_time_share": round(est[name] / total_ms, 4), "concurrent_group": cls in ("ustep", "prepare", "eval"),
+                             "algorithmic_bytes": int(ab), "achieved_GBs": round(ab / avg_s / 1e9, 2),
+                             "frac_hbm_peak": round(ab / avg_s / 1e9 / HBM_PEAK_GBS, 5), "traffic_bytes": tr,
+                             "traffic_over_algorithmic": round(tr / ab, 2) if tr else None}
+            if g_rows:
+                lv = lvl_slot(cls)
+                gb = g_rows * r * esz / avg_s / 1e9
+                kernels[name]["binding"] = {"level": lv, "gathered_row_bytes": int(g_rows * r * esz), "achieved_GBs": round(gb, 1),
+                                            "ceiling_GBs": GATHER_CEILING_GBS[lv], "frac": round(gb / GATHER_CEILING_GBS[lv], 4)}
+        if verbose:
+            for k, (ms, n) in sorted(prof.items(), key=lambda kv: -est[kv[0]]):
+                extra = f"  alg {kernels[k]['achieved_GBs']:8.1f} GB/s  gpu-time share {100 * kernels[k]['gpu_time_share']:5.1f} %" if k in kernels else ""
+                log(f"  {k:16s} {est[k]:9.3f} ms  {n:6d} timed  {1e3 * ms / max(n, 1):9.1f} us/launch{extra}")
+        # dominant kernel = the slot with the most GPU time (average duration x launches), the way `rocprofv3 --stats` ranks
+        # kernels -- concurrent length classes are NOT discounted for running side by side
+        dom = max(kernels, key=lambda k: kernels[k]["gpu_time_share"])
+        kd = kernels[dom]
+        roof = {"bound": "hbm", "kernel": dom, "achieved": kd["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": kd["frac_hbm_peak"], "traffic": kd["traffic_bytes"], "traffic_over_algorithmic": kd["traffic_over_algorithmic"],
+                "avg_launch_us": kd["avg_us"],
+                "launches_timed": kd["timed_launches"], "algorithmic_bytes_per_launch": kd["algorithmic_bytes"],
+                "share_of_gpu_time": kd["gpu_time_share"], "binding": kd.get("binding"),
+                "traffic_source": (traffic_src or f"profiles/{TRAFFIC_FILE}") + ": stored rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                  "command (separate runs), per launch, 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md); not "
+                                  "measured by this run" if kd["traffic_bytes"] is not None else None,
+                "note": "dominant = largest GPU time (average launch duration x launches, HIP events on the launch stream), as "
+                        f"rocprofv3 --stats ranks kernels; every {run['prof_period']}th launch of a kernel is event-timed (once-per-step "
+                        "kernels every 4th). 'frac' prices the launch's ALGORITHMIC bytes against the HBM peak (the north star's "
+                        "yardstick); 'binding' names the level that serves this kernel's row gathers on this shape (by the size of "
+                        "the gathered table), its measured ceiling (MI355X_MICROARCH.md, Indexed rows) and the fraction of that; all "
+                        "slots in 'kernels', phases in 'roofline_phase' (DESIGN.md 3.5, 4)"}
+
+        # phases: algorithmic bytes of everything a phase launches per step / its wall time per step
+        def phase(names, wall_ms_per_step, gather_bytes, level):
+            ab = sum(kernels[k]["algorithmic_bytes"] * run["launches"][k] / steps for k in names)
+            gb = gather_bytes / (wall_ms_per_step / 1e3) / 1e9
+            return {"bound": "hbm", "algorithmic_bytes_per_step": int(ab), "wall_us_per_step": round(1e3 * wall_ms_per_step, 1),
+                    "achieved": round(ab / (wall_ms_per_step / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ab / (wall_ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "share_of_step": round(wall_ms_per_step / (1e3 * secs / steps), 4),
+                    "gathered_row_bytes_per_step": int(gather_bytes), "gather_GBs": round(gb, 1),
+                    "binding": {"level": level, "ceiling_GBs": GATHER_CEILING_GBS[level], "achieved_GBs": round(gb, 1),
+                                "frac": round(gb / GATHER_CEILING_GBS[level], 4)}}
+        un = [k for k in kernels if k.startswith("ustep/")]
+        if un and prof.get("wall:ustep", (0, 0))[1]:
+            wm, wn = prof["wall:ustep"]
+            u_gather = u_rows / steps / N * r * esz           # this rank's share (the counter is the all-rank total)
+            roof_phase["u_step"] = dict(phase(un, wm / wn, u_gather, lvl_v), kernels=un,
+                                        note="all length classes of k_ustep, launched side by side: sum of their algorithmic bytes / fork..join wall "
+                                             "time on the solver's stream; gather_GBs = rows of V actually gathered (counted in the kernel: per user "
+                                             "1 + 2 per CG iteration + 1 per line-search try, x its ratings) x row bytes / that wall time, against "
+                                             "the ceiling of the level that serves the item table of this shape (binding)")
+        vn = [k for k in kernels if k.partition("/")[0] in ("sddmm", "spmm", "spmm_fin", "vhv", "vgrad", "cg", "prepare")]
+        if vn:
+            u_wall = roof_phase.get("u_step", {}).get("wall_us_per_step", 0.0) / 1e3
+            v_ms = 1e3 * secs / steps - u_wall               # the two half steps alternate on one stream: the rest of a step is the V step
+            v_gather = (inner["ls_v"] / steps + 2 * (inner["cg_v"] / steps) + 1) * esz * r * nnz_loc
+            roof_phase["v_step"] = dict(phase(vn, v_ms, v_gather, "l2-gather" if v_table > (32 << 20) else lvl_v), kernels=vn,
+                                        note="gradient + CG (SDDMM, sweep, SpMM, finish, vector update) + line search, back to back on the "
+                                             "solver's stream: step time minus the U step's wall time; gather_GBs = (1 SpMM + n_cg x (SDDMM + "
+                                             "SpMM) + n_ls SDDMM) x ratings x row bytes / that time (the SpMM's user tiles are cut to one "
+                                             "XCD's L2; the SDDMM gathers the item table, or user tiles when the item table is beyond the L2s)")
+    passes = (1 + (inner["cg_v"] + inner["ls_v"]) / steps) + (1 + (inner["cg_u"] + inner["ls_u"]) / steps / max(d1, 1))
+    # SURVEY 8d, the whole-iteration figure: compulsory bytes W of one outer iteration with ideal caching (esz-byte factors,
+    # int32 item, uint8 level, esz-byte m, uint32 permutation) at the EXECUTED inner counts, over the measured time per
+    # iteration -- all ranks' bytes over the job's time, against N x 8 TB/s.
+    n_cg, n_ls = inner["cg_v"] / steps, inner["ls_v"] / steps
+    B_csr, F_U, F_V = 5 * nnz + 8 * (d1 + 1), esz * r * d1, esz * r * d2 * N      # V is replicated on every rank
+    P_m, P_sort = B_csr + F_U + F_V + esz * nnz, 8 * nnz
+    P_hv, P_obj, P_u = B_csr + 8 * nnz + F_U + 2 * F_V, B_csr + 8 * nnz, B_csr + esz * nnz + 2 * F_U + F_V
+    W = P_m + P_sort + P_hv + n_cg * P_hv + P_obj + n_ls * (P_m + P_sort + P_obj) + P_u
+    it_roof = {"bound": "hbm", "algorithmic_bytes_per_iteration": int(W), "achieved": round(W / (secs / steps) / 1e9, 2),
+               "peak": HBM_PEAK_GBS * N, "unit": "GB/s", "frac": round(W / (secs / steps) / 1e9 / (HBM_PEAK_GBS * N), 5),
+               "note": "SURVEY 8d: W = P_m + P_sort + P_g + n_cg P_Hv + P_obj + n_ls (P_m + P_sort + P_obj) + P_U at the executed "
+                       "n_cg, n_ls; where the factor tables are cache-resident the path is gather/latency-bound and "
+                       "this fraction is small by construction (DESIGN.md 3.5) -- see 'gather' for the level that binds"}
+    # SURVEY 8d, secondary (diagnostic) figure: row-gather bytes.  One SDDMM or SpMM half-pass moves G = esz * r bytes per
+    # rating; per outer iteration the V side makes (1 + n_ls) SDDMMs of the prepares + n_cg of the CG + (1 + n_cg) SpMMs, the
+    # U side per rating 1 (gradient) + 2 per CG iteration + 1 per line-search try.
+    G = esz * r * nnz
+    n_cg_u, n_ls_u = inner["cg_u"] / steps / max(d1, 1), inner["ls_u"] / steps / max(d1, 1)
+    u_half_passes = u_rows / steps / max(nnz, 1)       # counted in k_ustep: rating-weighted, not user-averaged
+    gather_passes = (n_ls + n_cg) + (1 + n_cg) + u_half_passes
+    gg = gather_passes * G / (secs / steps) / 1e9
+    gather = {"bytes_per_half_pass": int(G), "half_passes_per_iteration": round(gather_passes, 2),
+              "u_side_half_passes": round(u_half_passes, 2), "u_side_user_average": round(1 + 2 * n_cg_u + n_ls_u, 2),
+              "achieved_GBs": round(gg, 1), "item_table_bytes": int(v_table), "level": lvl_v,
+              "ceiling_GBs": GATHER_CEILING_GBS[lvl_v] * N, "frac": round(gg / (GATHER_CEILING_GBS[lvl_v] * N), 4),
+              "note": "row gathers (one esz*r-byte factor row per rating and half-pass) sustained over the WHOLE iteration, all "
+                      "ranks, against the ceiling of the level the item table of this shape lives in (U side: rows counted by the "
+                      "kernel -- long users run more CG iterations than the user average, so the rating-weighted pass count is the "
+                      "higher one)"}
+    return dict(roofline=roof, roofline_phase=roof_phase, roofline_iteration=it_roof, gather=gather, kernels=kernels,
+                passes_per_step=passes)
+
+
+def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=("f32", "f64"), profile=True, cpu=True,
+            cpu_sample=2_000_000, cpu_single=True, verbose=False):
+    """Generate this rank's shard of `shape`, run the timed legs, return rank 0's record (None on the other ranks)."""
+    import primalcr_amd as pcr
+    from primalcr_amd import synth
+    args, rank, N = job.args, job.rank, job.N
+    t0 = time.time()
+    R, first, total, scaling, nnz_job = make_shard(shape, job, users, nnz)
+    ds = pcr.Dataset.from_ratings(R)
+    n_pairs = int(job.allsum(float(ds.count_pairs())))
+    tnnz = int(job.allsum(float(len(R.tval))))
+    note = {"ml1m": f"ml1m-shaped PrimalCR++ -k {r} -l {lam:g} (configs[1])",
+            "netflix": f"Netflix-shaped PrimalCR++ -k {r} -l {lam:g} (configs[3])",
+            "yahoo": f"Yahoo!Music-shaped PrimalCR++ -k {r} -l {lam:g} (configs[4]" +
+                     ("" if total == synth.SHAPES["yahoo"][0] else f": first {total} of 1.8 M users") + ")"}[shape]
+    if rank == 0:
+        log(f"[data] {shape}-shaped x{N}: {total} users x {R.d2} items, {nnz_job} ratings, {n_pairs} ordered pairs, "
+            f"{tnnz} test ratings; this rank: users [{first}, {first + R.d1}), {R.nnz} ratings ({time.time() - t0:.1f}s)")
+    shm = job.bcast(f"/pcr_bench_{os.getpid()}_{int(time.time()) % 100000}_{shape}")
+    wl = dict(d1=total, d2=R.d2, nnz=nnz_job, r=r)
+    shard = (first, total)
+    runs = {}
+    for pn in precisions:
+        prec = pcr.PCR_F32 if pn == "f32" else pcr.PCR_F64
+        runs[pn] = timed_run(job, ds, shard, R.d2, r, lam, prec, steps, warmup, profile, shm)
+        # diagnostic replay of the same iterations with the U-step kernels counting the rows of V they gather (an extra atomic
+        # per user, so it is kept out of the timed run): the rating-weighted pass count of the U step, per length class
+        rr = timed_run(job, ds, shard, R.d2, r, lam, prec, steps, warmup, False, shm, count_rows=True)
+        runs[pn]["rows"] = dict(u_rows=rr["u_rows"], rows_by_class=rr["rows_by_class"],
+                                launches_counted={k: (warmup + steps) for k in rr["rows_by_class"]})
+    bounds = None
+    if N > 1:
+        import torch
+        t = torch.zeros(N, 3, dtype=torch.float64, device="cuda" if args.rendezvous == "nccl" else "cpu")
+        t[rank] = torch.tensor([float(x) for x in runs[precisions[0]]["shard"]], dtype=torch.float64)
+        job.dist.all_reduce(t)
+        bounds = [[int(v) for v in row] for row in t.tolist()]
+    if rank != 0:
+        return None
+    main_p = precisions[0]
+    run = runs[main_p]
+    secs, objs, inner = run["secs"], run["objs"], run["inner"]
+    tkey = f"{shape}:{main_p}" if (users is None and nnz is None and N == 1 and r == (200 if shape == "yahoo" else 100)) else None
+    an = analyse(run, run["rows"], wl, main_p, N, tkey, verbose)
+    value = n_pairs * steps / secs
+    rec = {
+        "value": value, "unit": "pairs/s", "ms_per_step": 1e3 * secs / steps, "s_per_iter": secs / steps, "steps": steps, "warmup": warmup,
+        "dtype": main_p, "scaling": scaling,
+        "workload": f"{note}; {total} users x {R.d2} items, {nnz_job} ratings, {n_pairs} ordered pairs; 1 step = 1 outer "
+                    f"iteration (V step + U step)",
+        "ndcg10_test": run["te"][1], "pairwise_error_test": run["te"][0], "ndcg10_train": run["tr"][1], "pairwise_error_train": run["tr"][0],
+        "outer_iterations_run": warmup + steps, "objective": objs[-1],
+        "inner_per_step": {k: v / steps for k, v in inner.items()},
+        # SURVEY 8d, kernel-level figure: ordered pairs swept per second over the EXECUTED sweep passes of a step
+        # (V side: gradient + Hessian-vector products + line-search objectives; U side the same per user, averaged)
+        "passes_per_step": an["passes_per_step"], "sweep_pairs_per_s": value * an["passes_per_step"],
+        "comm_nranks": run["comm_nranks"], "shards": bounds,
+        "roofline": an["roofline"], "roofline_phase": an["roofline_phase"], "roofline_iteration": an["roofline_iteration"],
+        "gather": an["gather"], "kernels": an["kernels"],
+    }
+    if "f64" in runs and main_p == "f32":
+        # the reference computes in fp64 throughout (SURVEY 8): the same K steps with fp64 storage, same clock, same barriers
+        r64 = runs["f64"]
+        a64 = analyse(r64, r64["rows"], wl, "f64", N, f"{shape}:f64" if tkey else None)
+        rec["f64"] = {"dtype": "f64", "ms_per_step": 1e3 * r64["secs"] / steps, "value": n_pairs * steps / r64["secs"],
+                      "unit": "pairs/s", "ndcg10_test": r64["te"][1], "pairwise_error_test": r64["te"][0],
+                      "objective": r64["objs"][-1], "inner_per_step": {k: v / steps for k, v in r64["inner"].items()},
+                      "roofline": a64["roofline"], "roofline_phase": a64["roofline_phase"], "roofline_iteration": a64["roofline_iteration"],
+                      "gather": a64["gather"], "kernels": a64["kernels"],
+                      "note": "second timed run of the same workload with U, V, m and the CG vectors stored in fp64 (the reference's "
+                              "arithmetic type); 'value' above is the fp32-storage / fp64-accumulation run the north star allows "
+                              "('within fp32 tolerance')"}
+        rec["f64_minus_f32"] = {"ndcg10_test": r64["te"][1] - run["te"][1], "pairwise_error_test": r64["te"][0] - run["te"][0],
+                                "objective_rel": r64["objs"][-1] / objs[-1] - 1}
+    if cpu and N == 1:
+        rec["cpu_baseline"] = cpu_baseline(R, n_pairs, r, lam, cpu_sample, cpu_single)
+        rec["speedup_vs_cpu_baseline"] = value / rec["cpu_baseline"]["value"]
+    else:
+        rec["cpu_baseline"] = None
+    return rec
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(N):
+    """--gpus N > 1 without a launcher: start the ranks as child processes of THIS one -- which has not imported torch and
+    never touches a GPU -- and relay what rank 0 prints (the children inherit stdout / stderr).  Never an exec."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL / the peer-to-peer exchange across processes need it here
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // N)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={N}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] --gpus {N}: launching {N} ranks: {' '.join(cmd[1:9])} bench.py ...")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -233,8 +553,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--shape", choices=["ml1m", "netflix", "yahoo"], default="ml1m",
                     help="ml1m: configs[1], 6040 users per GPU (weak scaling); netflix: configs[3], 480189 x 17770, 100 M ratings in "
-                         "total, user-sharded over the GPUs (strong scaling); yahoo: configs[4] shape -- give --users (a user prefix)")
-    ap.add_argument("--users", type=int, default=None, help="override the user count of the shape (total for netflix/yahoo, per GPU for ml1m)")
+                         "total, user-sharded over the GPUs (strong scaling); yahoo: configs[4], 225000 users per GPU of the 1.8 M "
+                         "(all of them at 8 GPUs)")
+    ap.add_argument("--users", type=int, default=None, help="override the user count of the shape (per GPU for ml1m, total for netflix, "
+                                                            "length of the user prefix for yahoo)")
     ap.add_argument("--nnz", type=int, default=None, help="override the rating count likewise")
     ap.add_argument("--rank-k", type=int, default=None, help="factor rank (BASELINE: 100; yahoo: 200)")
     ap.add_argument("--lam", type=float, default=5000.0)
@@ -244,8 +566,10 @@ def main():
                                                     "fewer GPUs than ranks; needs --comm p2p and --rendezvous gloo: RCCL refuses two ranks on one device)")
     ap.add_argument("--rendezvous", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend of the barriers and the id broadcast")
     ap.add_argument("--tune", action="append", default=[], help="key=value launch knob (pcr_tune), repeatable -- for A/B runs")
+    ap.add_argument("--lib", default=None, help="A/B: load this libprimalcr.so instead of primalcr_amd/lib/libprimalcr.so")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-f64", action="store_true", help="skip the second timed run in the reference's arithmetic type")
+    ap.add_argument("--no-netflix", action="store_true", help="skip the Netflix-shaped sub-record of the default N = 1 run")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--profile-period", type=int, default=0,
                     help="event-time every n-th launch of each kernel (the first one included); 0 = as sparse as leaves a dozen "
@@ -253,14 +577,12 @@ def main():
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))                 # (before torch is imported: this process never initialises a GPU)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    N = args.gpus
-    if world != N:
-        if world == 1 and N > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        N = world
+    N = world
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the training path)")
@@ -274,196 +596,40 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    if local_rank == 0 and not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "primalcr_amd", "lib", "libprimalcr.so")):
+    if local_rank == 0 and not args.lib and not os.path.exists(os.path.join(ROOT, "primalcr_amd", "lib", "libprimalcr.so")):
         import __graft_entry__                   # clean checkout: compile the product first (no fallback exists)
         __graft_entry__.build()
     if N > 1:
         dist.barrier()                           # (every rank, whether or not it saw the library missing)
     import primalcr_amd as pcr
-    from primalcr_amd import synth
-
+    if args.lib:
+        pcr.use_library(args.lib)
     for kv in args.tune:
         pcr.tune(*kv.split("=", 1))
+    job = Job(args, torch, dist, rank, N, device)
     r, lam = args.rank_k or (200 if args.shape == "yahoo" else 100), args.lam
-    t0 = time.time()
-    if args.shape == "ml1m":
-        R = synth.generate("ml1m", d1=(args.users or USERS_PER_GPU) * N, nnz=(args.nnz or NNZ_PER_GPU) * N)
-        scaling, shape_note = "weak", f"ml1m-shaped PrimalCR++ -k {r} -l {lam:g} (configs[1])"
-    elif args.shape == "netflix":
-        R = synth.generate_fast("netflix", d1=args.users, nnz=args.nnz)
-        scaling, shape_note = "strong", f"Netflix-shaped PrimalCR++ -k {r} -l {lam:g} (configs[3])"
-    else:
-        R = synth.generate_fast("yahoo", users=(0, args.users or 225000))
-        scaling, shape_note = "strong", f"Yahoo!Music-shaped PrimalCR++ -k {r} -l {lam:g} (configs[4]: first {R.d1} of 1.8 M users)"
-    ds = pcr.Dataset.from_ratings(R)
-    n_pairs = ds.count_pairs()
+    precisions = (args.precision,) if (args.no_f64 or args.precision == "f64") else ("f32", "f64")
+    rec = measure(job, args.shape, r, lam, args.steps, args.warmup, args.users, args.nnz, precisions, not args.no_profile,
+                  not args.no_cpu, verbose=args.verbose)
+    # configs[3] in the driver's line: the default N = 1 run also times a few steps of the Netflix-shaped set (north star "Target")
+    nf = None
+    if (N == 1 and args.shape == "ml1m" and not args.no_netflix and args.users is None and args.nnz is None and args.rank_k is None
+            and args.precision == "f32"):
+        nf = measure(job, "netflix", 100, lam, 3, 1, None, None, precisions, not args.no_profile, not args.no_cpu,
+                     cpu_sample=1_000_000, cpu_single=False)
     if rank == 0:
-        log(f"[data] {args.shape}-shaped x{N}: {R.d1} users x {R.d2} items, {R.nnz} ratings, {n_pairs} ordered pairs, "
-            f"{len(R.tval)} test ratings ({time.time() - t0:.1f}s)")
-    prec = pcr.PCR_F32 if args.precision == "f32" else pcr.PCR_F64
-    shm = [f"/pcr_bench_{os.getpid()}_{int(time.time()) % 100000}" if rank == 0 else None]
-    if N > 1:
-        dist.broadcast_object_list(shm, src=0)
-    run = timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, device, args, not args.no_profile, shm[0])
-    # the same workload in the reference's arithmetic type (fp64 storage as well as fp64 accumulation), timed the same way
-    run64 = None
-    if prec == pcr.PCR_F32 and not args.no_f64:
-        run64 = timed_run(pcr, torch, dist, ds, R, r, lam, pcr.PCR_F64, rank, N, device, args, False, shm[0])
-    # diagnostic replay of the same iterations with the U-step kernels counting the rows of V they gather (an extra atomic per
-    # user, so it is kept out of the timed run): the rating-weighted pass count of the U step
-    run["u_rows"] = timed_run(pcr, torch, dist, ds, R, r, lam, prec, rank, N, device, args, False, shm[0], count_rows=True)["u_rows"]
-    secs, objs, inner, prof = run["secs"], run["objs"], run["inner"], run["prof"]
-    te_err, te_ndcg = run["te"]; tr_err, tr_ndcg = run["tr"]
-    prof_period = run["prof_period"]
-
-    if rank != 0:
-        if N > 1:
-            dist.barrier(); dist.destroy_process_group()
-        return
-
-    # ---- per-kernel rooflines (rank 0's shard)
-    roof, roof_phase, kernels = None, {}, {}
-    esz = 4 if prec == pcr.PCR_F32 else 8
-    if prof:
-        traffic, traffic_src = {}, None
-        tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)      # PMC passes of this command (tools/pmc_traffic.py)
-        if os.path.exists(tpath) and args.shape == "ml1m" and not args.users and not args.nnz and r == 100 and N == 1 and prec == pcr.PCR_F32:
-            tj = json.load(open(tpath))             # the PMC passes were taken on exactly this workload
-            traffic, traffic_src = tj.get("kernels", tj), tj.get("source")
-        # Launches are SAMPLED, so a slot's time in the region is its average times ALL its launches.
-        est = {name: ((ms / n) * max(run["launches"][name], n) if n else 0.0) for name, (ms, n) in prof.items()}
-        total_ms = sum(v for k, v in est.items() if not k.startswith("wall:"))
-        for name, (ms, n) in prof.items():
-            cls, _, tag = name.partition("/")
-            if cls not in SLOT_KERNEL or n == 0:
-                continue
-            nnz_b, nu_b = run["scope"][name]              # ratings / users one launch of this slot covers
-            ab = algorithmic_bytes(name, nnz_b, nu_b, R.d2, r, esz)
-            avg_s = ms / n / 1e3
-            tr = None
-            # several slots can share one kernel symbol (k_ustep of one workgroup size serves several length classes):
-            # a per-symbol PMC average cannot be split between them, so those slots carry no traffic figure
-            shared = sum(1 for other in prof if other != name and prof[other][1] and other.partition("/")[0] == cls and
-                         any(slot_kernel_match(other, kn, args.precision) and slot_kernel_match(name, kn, args.precision) for kn in traffic))
-            for kname, t in traffic.items():
-                if not shared and slot_kernel_match(name, kname, args.precision):
-                    # MI355X_MICROARCH.md (HBM): FETCH_SIZE counts wide coalesced reads at half their bytes on gfx950 ->
-                    # doubled; WRITE_SIZE is exact
-                    tr = int(2 * t["fetch_bytes_per_launch_raw"] + t["write_bytes_per_launch"])
-            kernels[name] = {"avg_us": round(avg_s * 1e6, 2), "timed_launches": int(n), "launches": int(run["launches"][name]),
-                             "gpu_time_share": round(est[name] / total_ms, 4), "concurrent_group": cls in ("ustep", "prepare", "eval"),
-                             "algorithmic_bytes": int(ab), "achieved_GBs": round(ab / avg_s / 1e9, 2),
-                             "frac_hbm_peak": round(ab / avg_s / 1e9 / HBM_PEAK_GBS, 5), "traffic_bytes": tr}
-        if args.verbose:
-            for k, (ms, n) in sorted(prof.items(), key=lambda kv: -est[kv[0]]):
-                extra = f"  alg {kernels[k]['achieved_GBs']:8.1f} GB/s  gpu-time share {100 * kernels[k]['gpu_time_share']:5.1f} %" if k in kernels else ""
-                log(f"  {k:14s} {est[k]:9.3f} ms  {n:6d} timed  {1e3 * ms / max(n, 1):9.1f} us/launch{extra}")
-        # dominant kernel = the slot with the most GPU time (average duration x launches), the way `rocprofv3 --stats` ranks
-        # kernels -- concurrent length classes are NOT discounted for running side by side
-        dom = max(kernels, key=lambda k: kernels[k]["gpu_time_share"])
-        kd = kernels[dom]
-        roof = {"bound": "hbm", "kernel": dom, "achieved": kd["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": kd["frac_hbm_peak"], "traffic": kd["traffic_bytes"], "avg_launch_us": kd["avg_us"],
-                "launches_timed": kd["timed_launches"], "algorithmic_bytes_per_launch": kd["algorithmic_bytes"],
-                "share_of_gpu_time": kd["gpu_time_share"],
-                "traffic_source": (traffic_src or f"profiles/{TRAFFIC_FILE}") + ": stored rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                  "command (separate runs), per launch, 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md); not "
-                                  "measured by this run" if kd["traffic_bytes"] is not None else None,
-                "note": "dominant = largest GPU time (average launch duration x launches, HIP events on the launch stream), as "
-                        f"rocprofv3 --stats ranks kernels; every {prof_period}th launch of a kernel is event-timed (once-per-step "
-                        "kernels every 4th); all slots in 'kernels', phases in 'roofline_phase' (DESIGN.md 3.5, 4)"}
-        # phases: algorithmic bytes of everything a phase launches per step / its wall time per step
-        def phase(names, wall_ms_per_step):
-            ab = sum(kernels[k]["algorithmic_bytes"] * run["launches"][k] / args.steps for k in names)
-            return {"bound": "hbm", "algorithmic_bytes_per_step": int(ab), "wall_us_per_step": round(1e3 * wall_ms_per_step, 1),
-                    "achieved": round(ab / (wall_ms_per_step / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ab / (wall_ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "share_of_step": round(wall_ms_per_step / (1e3 * secs / args.steps), 4)}
-        un = [k for k in kernels if k.startswith("ustep/")]
-        if un and prof.get("wall:ustep", (0, 0))[1]:
-            wm, wn = prof["wall:ustep"]
-            u_gather = run["u_rows"] / args.steps / N * r * esz           # this rank's share (the counter is the all-rank total)
-            roof_phase["u_step"] = dict(phase(un, wm / wn), kernels=un, gathered_row_bytes_per_step=int(u_gather),
-                                        gather_GBs=round(u_gather / (wm / wn / 1e3) / 1e9, 1),
-                                        note="all length classes of k_ustep, launched side by side: sum of their algorithmic bytes / fork..join wall "
-                                             "time on the solver's stream; gather_GBs = rows of V actually gathered (counted in the kernel: per user "
-                                             "1 + 2 per CG iteration + 1 per line-search try, x its ratings) x row bytes / that wall time -- the "
-                                             "L2 -> CU row-gather rate this phase runs at (measured ceiling 16.8-18.8 TB/s, MI355X_MICROARCH.md)")
-        vn = [k for k in kernels if k.partition("/")[0] in ("sddmm", "spmm", "spmm_fin", "vhv", "vgrad", "cg", "prepare")]
-        if vn:
-            u_wall = roof_phase.get("u_step", {}).get("wall_us_per_step", 0.0) / 1e3
-            v_ms = 1e3 * secs / args.steps - u_wall               # the two half steps alternate on one stream: the rest of a step is the V step
-            v_gather = ((n_ls_v := inner["ls_v"] / args.steps) + 2 * (inner["cg_v"] / args.steps) + 1) * esz * r * run["shard"][2]
-            roof_phase["v_step"] = dict(phase(vn, v_ms), kernels=vn, gathered_row_bytes_per_step=int(v_gather),
-                                        gather_GBs=round(v_gather / (v_ms / 1e3) / 1e9, 1),
-                                        note="gradient + CG (SDDMM, sweep, SpMM, finish, vector update) + line search, back to back on the "
-                                             "solver's stream: step time minus the U step's wall time; gather_GBs = (1 SpMM + n_cg x (SDDMM + "
-                                             "SpMM) + n_ls SDDMM) x ratings x row bytes / that time")
-    cpu = None
-    if N == 1 and not args.no_cpu:
-        cpu = cpu_baseline(R, n_pairs, r, lam)
-
-    value = n_pairs * args.steps / secs
-    passes = (1 + (inner["cg_v"] + inner["ls_v"]) / args.steps) + (1 + (inner["cg_u"] + inner["ls_u"]) / args.steps / max(R.d1, 1))
-    # SURVEY 8d, the whole-iteration figure: compulsory bytes W of one outer iteration with ideal caching (esz-byte factors,
-    # int32 item, uint8 level, esz-byte m, uint32 permutation) at the EXECUTED inner counts, over the measured time per
-    # iteration -- all ranks' bytes over the job's time, against N x 8 TB/s.
-    esz_w = esz
-    n_cg, n_ls = inner["cg_v"] / args.steps, inner["ls_v"] / args.steps
-    B_csr, F_U, F_V = 5 * R.nnz + 8 * (R.d1 + 1), esz_w * r * R.d1, esz_w * r * R.d2 * N      # V is replicated on every rank
-    P_m, P_sort = B_csr + F_U + F_V + esz_w * R.nnz, 8 * R.nnz
-    P_hv, P_obj, P_u = B_csr + 8 * R.nnz + F_U + 2 * F_V, B_csr + 8 * R.nnz, B_csr + esz_w * R.nnz + 2 * F_U + F_V
-    W = P_m + P_sort + P_hv + n_cg * P_hv + P_obj + n_ls * (P_m + P_sort + P_obj) + P_u
-    it_roof = {"bound": "hbm", "algorithmic_bytes_per_iteration": int(W), "achieved": round(W / (secs / args.steps) / 1e9, 2),
-               "peak": HBM_PEAK_GBS * N, "unit": "GB/s", "frac": round(W / (secs / args.steps) / 1e9 / (HBM_PEAK_GBS * N), 5),
-               "note": "SURVEY 8d: W = P_m + P_sort + P_g + n_cg P_Hv + P_obj + n_ls (P_m + P_sort + P_obj) + P_U at the executed "
-                       "n_cg, n_ls; the factor tables of this shape are L2-resident, so the path is gather/latency-bound and "
-                       "this fraction is small by construction (DESIGN.md 3.5)"}
-    # SURVEY 8d, secondary (diagnostic) figure: row-gather bytes.  One SDDMM or SpMM half-pass moves G = esz * r bytes per
-    # rating; per outer iteration the V side makes (1 + n_ls) SDDMMs of the prepares + n_cg of the CG + (1 + n_cg) SpMMs, the
-    # U side per rating 1 (gradient) + 2 per CG iteration + 1 per line-search try.
-    G = esz_w * r * R.nnz
-    n_cg_u, n_ls_u = inner["cg_u"] / args.steps / max(R.d1, 1), inner["ls_u"] / args.steps / max(R.d1, 1)
-    u_half_passes = run["u_rows"] / args.steps / max(R.nnz, 1)       # counted in k_ustep: rating-weighted, not user-averaged
-    gather_passes = (n_ls + n_cg) + (1 + n_cg) + u_half_passes
-    gather = {"bytes_per_half_pass": int(G), "half_passes_per_iteration": round(gather_passes, 2),
-              "u_side_half_passes": round(u_half_passes, 2), "u_side_user_average": round(1 + 2 * n_cg_u + n_ls_u, 2),
-              "achieved_GBs": round(gather_passes * G / (secs / args.steps) / 1e9, 1),
-              "note": "row gathers (one esz*r-byte factor row per rating and half-pass) sustained over the WHOLE iteration, all "
-                      "ranks; on this shape they are served by the L2s (U side: rows counted by the kernel -- long users run more CG "
-                      "iterations than the user average, so the rating-weighted pass count is the higher one)"}
-    out = {
-        "metric": "pairwise-comparisons/sec", "value": value, "unit": "pairs/s", "n_gpus": N, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps, "higher_is_better": True, "scaling": scaling,
-        "vs_baseline": None, "dtype": "f32" if prec == pcr.PCR_F32 else "f64", "data": "synthetic",
-        "config": {"workload": f"{shape_note}; {R.d1} users x {R.d2} items, "
-                               f"{R.nnz} ratings, {n_pairs} ordered pairs; 1 step = 1 outer iteration (V step + U step)",
-                   "solver": "PrimalCR++", "rank": r, "lambda": lam, "parallelism": f"user-sharded x{N}",
-                   "accumulation": "f64", "storage": "f32" if prec == pcr.PCR_F32 else "f64",
-                   "exchange": None if N == 1 else args.comm},
-        "ndcg10_test": te_ndcg, "pairwise_error_test": te_err, "ndcg10_train": tr_ndcg, "pairwise_error_train": tr_err,
-        "outer_iterations_run": args.warmup + args.steps, "objective": objs[-1],
-        "inner_per_step": {k: v / args.steps for k, v in inner.items()},
-        # SURVEY 8d, kernel-level figure: ordered pairs swept per second over the EXECUTED sweep passes of a step
-        # (V side: gradient + Hessian-vector products + line-search objectives; U side the same per user, averaged)
-        "passes_per_step": passes, "sweep_pairs_per_s": value * passes, "s_per_iter": secs / args.steps,
-        "comm_nranks": run["comm_nranks"],
-        "roofline": roof, "roofline_phase": roof_phase, "roofline_iteration": it_roof, "gather": gather, "cpu_baseline": cpu,
-        "kernels": kernels,
-    }
-    if run64:
-        # the reference computes in fp64 throughout: the same K steps with fp64 storage, same clock, same barriers
-        out["f64"] = {"dtype": "f64", "ms_per_step": 1e3 * run64["secs"] / args.steps, "value": n_pairs * args.steps / run64["secs"],
-                      "unit": "pairs/s", "ndcg10_test": run64["te"][1], "pairwise_error_test": run64["te"][0],
-                      "objective": run64["objs"][-1], "inner_per_step": {k: v / args.steps for k, v in run64["inner"].items()},
-                      "note": "second timed run of the same workload with U, V, m and the CG vectors stored in fp64 (the reference's "
-                              "arithmetic type); 'value' above is the fp32-storage / fp64-accumulation run the north star allows "
-                              "('within fp32 tolerance')"}
-        out["f64_minus_f32"] = {"ndcg10_test": run64["te"][1] - te_ndcg, "pairwise_error_test": run64["te"][0] - te_err,
-                                "objective_rel": run64["objs"][-1] / objs[-1] - 1}
-    if cpu:
-        out["speedup_vs_cpu_baseline"] = value / cpu["value"]
-    print(json.dumps(out), flush=True)
+        out = {"metric": "pairwise-comparisons/sec", "value": rec["value"], "unit": "pairs/s", "n_gpus": N, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": rec["scaling"],
+               "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic",
+               "config": {"workload": rec["workload"], "solver": "PrimalCR++", "rank": r, "lambda": lam,
+                          "parallelism": f"user-sharded x{N}", "accumulation": "f64", "storage": rec["dtype"],
+                          "exchange": None if N == 1 else args.comm}}
+        for k, v in rec.items():
+            if k not in out and k not in ("workload", "scaling", "dtype", "steps", "warmup"):
+                out[k] = v
+        if nf:
+            out["netflix"] = nf
+        print(json.dumps(out), flush=True)
     if N > 1:
         dist.barrier(); dist.destroy_process_group()
 

@@ -86,6 +86,10 @@ const char *pcr_version(void);                                            /* [ho
 /* util.cpp:80-93 initial(): N(0,1) from a default-seeded std::default_random_engine
  * through std::normal_distribution<double>; a fresh engine per call. */
 int pcr_initial(double *X, int64_t n, int64_t k);                         /* [host] */
+/* rows [row0, row0 + nrows) of what pcr_initial(., n, k) would produce, into X (nrows x k): the stream is
+ * sequential (libstdc++'s polar normal_distribution consumes a data-dependent number of draws), so the rows before
+ * row0 are generated and dropped -- for a rank that holds only its own users' rows of a large U. */
+int pcr_initial_rows(double *X, int64_t n, int64_t k, int64_t row0, int64_t nrows);   /* [host] */
 
 typedef struct pcr_dataset pcr_dataset;   /* training CSR + test CSR, host memory */
 
@@ -145,8 +149,10 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  * No environment variable is read anywhere on the product path.
  *   ustep_mode      1 = latency form of k_ustep for every long class, 2 = throughput form (default: by user count)
  *   ustep_many      user count above which a long class counts as throughput-bound (default CUs/4)
- *   allreduce_chunks N = item ranges of the SpMM whose all-reduces overlap the next range's SpMM (default: 1 on one GPU or below
- *                   16 MB per vector, else about one per 4 MB, at most 8)
+ *   allreduce_chunks N = item ranges of the SpMM whose all-reduces overlap the next range's SpMM (default 1: one all-reduce per
+ *                   vector on the solver's stream; opt-in, meant for vectors of 16 MB and more -- about one range per 4 MB)
+ *   cluster_fence   0 = the hand-off between the workgroups of a cluster without the agent-scope release / acquire (its payload
+ *                   is sc1 both ways; measured valid on gfx950, not an architectural guarantee; default 1: fenced)
  *   ustep_small_unr 8 = eight rows in flight per lane group in the one-wave and 256-thread classes of k_ustep (default 4)
  *   ustep_ls_recur  0 = k_ustep's first line-search try gathers the rows for its scores (default 1: m - s sum alpha_k b_k from the
  *                   CG's own b_k = V_I p_k, no pass)
@@ -179,6 +185,13 @@ typedef struct pcr_solver pcr_solver;
  * device state.  Replaces convert(R), convert(T) at pcrpp.cpp:850-851. */
 int pcr_solver_create(const pcr_dataset *ds, const pcr_params *p, int rank, int nranks,
                       pcr_solver **out);                                   /* [device] */
+/* The same for a job whose rating set no single process holds (configs[4]: 700 M ratings over 8 GPUs): `ds_local` contains
+ * ONLY this rank's users, renumbered from 0 -- users [first_user, first_user + d1(ds_local)) of a job with d1_total users; the
+ * host application chooses the ranges (pcr_partition_users on the per-user counts) so that they tile [0, d1_total) in rank
+ * order.  Its test set must be empty on every rank or on none.  Replaces the same call sites as pcr_solver_create;
+ * the user loop being sharded is pcrpp.cpp:825-833. */
+int pcr_solver_create_shard(const pcr_dataset *ds_local, const pcr_params *p, int rank, int nranks,
+                            int64_t first_user, int64_t d1_total, pcr_solver **out);   /* [device] */
 void pcr_solver_destroy(pcr_solver *s);
 
 /* RCCL bootstrap for nranks > 1 (one process per GPU): rank 0 obtains an id
@@ -198,7 +211,10 @@ int pcr_solver_comm_nranks(pcr_solver *s);
  *   "ustep_row_gathers"  rows of V the U steps gathered (per user: 1 for the gradient + 2 per CG iteration + 1 per
  *                        line-search try, times its rating count; all ranks; counted only under pcr_tune("count_rows")) --
  *                        the U step's gather rate = this x k x sizeof(storage type) / its wall time */
+/*   "ustep_row_gathers/<slot>"  the same count for ONE length class of the U step on THIS rank (<slot> = its profile slot
+ *                        name, e.g. "ustep/256.512"; pcr_solver_ustep_classes lists them, comma-separated) */
 int pcr_solver_counter(pcr_solver *s, const char *name, double *value);
+int pcr_solver_ustep_classes(pcr_solver *s, char *buf, int64_t cap);
 /* Shard-local mode for a solver created with nranks > 1 and no communicator: every collective
  * becomes a no-op, so pcr_obtain_g / pcr_compute_Ha / pcr_objective return THIS SHARD'S PARTIAL
  * (rank 0 carries the lambda term).  Lets a host application combine shards itself, and lets one
@@ -212,6 +228,9 @@ int pcr_solver_shard(const pcr_solver *s, int64_t *first_user, int64_t *n_users,
  * writes only its own rows [first_user, first_user+n_users). V is d2 x k. */
 int pcr_solver_set_factors(pcr_solver *s, const double *U, const double *V);
 int pcr_solver_get_factors(pcr_solver *s, double *U, double *V);
+/* the same with U_local = this rank's n_users x k rows only (what a rank created by pcr_solver_create_shard holds) */
+int pcr_solver_set_factors_local(pcr_solver *s, const double *U_local, const double *V);
+int pcr_solver_get_factors_local(pcr_solver *s, double *U_local, double *V);
 
 /* pcrpp.cpp:17-35 comp_m_new (pcr.cpp:47 comp_m): m = u_i . v_j for every rating,
  * from the current device U, V; also builds the per-user (level, m)-sorted state
@@ -262,9 +281,10 @@ int pcr_predict(const double *U, int64_t d1, const double *V, int64_t d2, int64_
                 int device);                                               /* [device] */
 
 /* per-kernel device timing (HIP events on the solver's stream, one pair per launch).
- * slot names: "<class>/<workgroup size>[.<length bound>][g][c][t]" for the per-user kernels (classes
- * prepare, vgrad, vhv, ustep; g = global-scratch variant, c = workgroup clusters, t = the one-workgroup
- * tail of a cluster class; "vgrad/all", "vhv/all" = both LDS classes in one launch), "wall:<class>" for
+ * slot names: "<class>/<workgroup size>[.<length bound>][g][c][#n]" for the per-user kernels (classes
+ * prepare, vgrad, vhv, ustep; g = global-scratch variant, c = workgroup clusters, #n = the n-th kernel symbol
+ * of a workgroup form that two length classes of the U step share -- every class is its own symbol in a
+ * profiler's per-kernel tables; "vgrad/all", "vhv/all" = both LDS classes in one launch), "wall:<class>" for
  * the fork..join wall time of a class whose length classes run concurrently, and "sddmm", "spmm",
  * "spmm_fin", "cg", "eval", "allreduce".
  * pcr_profile_list writes the comma-separated names of the slots seen so far.

@@ -10,7 +10,7 @@ and ``initial`` are usable), but every training entry point raises ``PcrError`` 
 library or a GPU is missing.
 """
 from .api import (PCR_F32, PCR_F64, PCR_SOLVER_PCR, PCR_SOLVER_PCRPP, Dataset, Parameter, PcrError, Solver,
-                  comm_unique_id, initial, lib, lib_path, model_load, model_save, partition_users, predict, tune, tuned)
+                  comm_unique_id, initial, initial_rows, lib, lib_path, use_library, model_load, model_save, partition_users, predict, tune, tuned)
 
 __all__ = ["PCR_F32", "PCR_F64", "PCR_SOLVER_PCR", "PCR_SOLVER_PCRPP", "Dataset", "Parameter", "PcrError", "Solver",
-           "comm_unique_id", "initial", "lib", "lib_path", "model_load", "model_save", "partition_users", "predict", "tune", "tuned"]
+           "comm_unique_id", "initial", "initial_rows", "lib", "lib_path", "use_library", "model_load", "model_save", "partition_users", "predict", "tune", "tuned"]

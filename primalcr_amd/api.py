@@ -12,9 +12,18 @@ PCR_F32, PCR_F64 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+_LIB_OVERRIDE = None
+
+
+def use_library(path):
+    """Developer hook for A/B runs of two builds (tools/): load `path` instead of lib/libprimalcr.so.  Call before anything
+    else of the package; the product path reads no environment variable (include/primalcr.h)."""
+    global _LIB_OVERRIDE, _lib
+    _LIB_OVERRIDE, _lib = path, None
+
+
 def lib_path() -> str:
-    # PCR_LIB: developer override for A/B runs of two builds in one process launch each
-    return os.environ.get("PCR_LIB") or os.path.join(_HERE, "lib", "libprimalcr.so")
+    return _LIB_OVERRIDE or os.path.join(_HERE, "lib", "libprimalcr.so")
 
 
 class PcrError(RuntimeError):
@@ -67,6 +76,7 @@ def lib():
     L.pcr_version.restype = C.c_char_p
     L.pcr_params_default.argtypes = [C.POINTER(Parameter)]
     L.pcr_initial.argtypes = [_dp, i64, i64]
+    L.pcr_initial_rows.argtypes = [_dp, i64, i64, i64, i64]
     L.pcr_dataset_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.pcr_dataset_load_cached.argtypes = [C.c_char_p, ci, C.c_char_p, C.POINTER(vp)]
     L.pcr_dataset_load_cache.argtypes = [C.c_char_p, C.POINTER(vp)]
@@ -83,16 +93,20 @@ def lib():
     L.pcr_model_load.argtypes = [C.c_char_p, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), vp, vp]
     L.pcr_partition_users.argtypes = [_lp, i64, ci, _lp]
     L.pcr_solver_create.argtypes = [vp, C.POINTER(Parameter), ci, ci, C.POINTER(vp)]
+    L.pcr_solver_create_shard.argtypes = [vp, C.POINTER(Parameter), ci, ci, i64, i64, C.POINTER(vp)]
     L.pcr_solver_destroy.argtypes = [vp]
     L.pcr_comm_unique_id.argtypes = [vp]
     L.pcr_solver_comm_init.argtypes = [vp, vp]
     L.pcr_solver_comm_init_p2p.argtypes = [vp, C.c_char_p]
     L.pcr_solver_comm_nranks.argtypes = [vp]
     L.pcr_solver_counter.argtypes = [vp, C.c_char_p, C.POINTER(cd)]
+    L.pcr_solver_ustep_classes.argtypes = [vp, C.c_char_p, i64]
     L.pcr_solver_set_local_only.argtypes = [vp, ci]
     L.pcr_solver_shard.argtypes = [vp] + [C.POINTER(i64)] * 3
     L.pcr_solver_set_factors.argtypes = [vp, vp, vp]
     L.pcr_solver_get_factors.argtypes = [vp, vp, vp]
+    L.pcr_solver_set_factors_local.argtypes = [vp, vp, vp]
+    L.pcr_solver_get_factors_local.argtypes = [vp, vp, vp]
     L.pcr_comp_m.argtypes = [vp, vp]
     L.pcr_objective.argtypes = [vp, C.POINTER(cd)]
     L.pcr_obtain_g.argtypes = [vp, _dp]
@@ -146,6 +160,13 @@ def initial(n, k):
     """util.cpp:80-93 initial()."""
     X = np.empty((n, k), np.float64)
     _chk(lib().pcr_initial(X, n, k))
+    return X
+
+
+def initial_rows(n, k, row0, nrows):
+    """Rows [row0, row0 + nrows) of initial(n, k) (the stream is sequential: the rows before are generated and dropped)."""
+    X = np.empty((nrows, k), np.float64)
+    _chk(lib().pcr_initial_rows(X, n, k, row0, nrows))
     return X
 
 
@@ -269,12 +290,17 @@ class Dataset:
 class Solver:
     """Device solver: the reference's pcrpp()/pcr() and their building blocks on one MI355X."""
 
-    def __init__(self, ds: Dataset, param: Parameter, rank=0, nranks=1):
+    def __init__(self, ds: Dataset, param: Parameter, rank=0, nranks=1, shard=None):
+        """shard = (first_user, d1_total): ds holds ONLY this rank's users (pcr_solver_create_shard)."""
         self.ds, self.param, self.rank, self.nranks = ds, param, rank, nranks
         self.d1, self.d2, self.nnz, self.tnnz = ds.dims()
         self.k = param.k
         h = C.c_void_p()
-        _chk(lib().pcr_solver_create(ds._h, C.byref(param), rank, nranks, C.byref(h)))
+        if shard is None:
+            _chk(lib().pcr_solver_create(ds._h, C.byref(param), rank, nranks, C.byref(h)))
+        else:
+            _chk(lib().pcr_solver_create_shard(ds._h, C.byref(param), rank, nranks, int(shard[0]), int(shard[1]), C.byref(h)))
+            self.d1 = int(shard[1])
         self._h = h
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         _chk(lib().pcr_solver_shard(h, a, b, c))
@@ -293,6 +319,16 @@ class Solver:
         _chk(lib().pcr_solver_counter(self._h, name.encode(), v))
         return v.value
 
+    def ustep_classes(self):
+        """Profile slot names of the U step's length classes on this rank."""
+        buf = C.create_string_buffer(4096)
+        _chk(lib().pcr_solver_ustep_classes(self._h, buf, 4096))
+        return [n for n in buf.value.decode().split(",") if n]
+
+    def class_row_gathers(self):
+        """{U-step class slot: rows of V it has gathered since the solver was created} (needs tuned(count_rows=1))."""
+        return {n: self.counter("ustep_row_gathers/" + n) for n in self.ustep_classes()}
+
     def comm_nranks(self):
         return lib().pcr_solver_comm_nranks(self._h)
 
@@ -308,6 +344,19 @@ class Solver:
     def get_factors(self):
         U = np.zeros((self.d1, self.k)); V = np.zeros((self.d2, self.k))
         _chk(lib().pcr_solver_get_factors(self._h, U.ctypes.data, V.ctypes.data))
+        return U, V
+
+    def set_factors_local(self, U_local=None, V=None):
+        """U_local: this rank's n_users x k rows only."""
+        U = None if U_local is None else np.ascontiguousarray(U_local, np.float64)
+        V = None if V is None else np.ascontiguousarray(V, np.float64)
+        if U is not None and U.shape != (self.n_users, self.k):
+            raise ValueError(f"U_local must be {self.n_users} x {self.k}")
+        _chk(lib().pcr_solver_set_factors_local(self._h, None if U is None else U.ctypes.data, None if V is None else V.ctypes.data))
+
+    def get_factors_local(self):
+        U = np.zeros((self.n_users, self.k)); V = np.zeros((self.d2, self.k))
+        _chk(lib().pcr_solver_get_factors_local(self._h, U.ctypes.data, V.ctypes.data))
         return U, V
 
     def comp_m(self, want=True):

@@ -22,6 +22,7 @@
 //                     all-gather of pcr_solver_comm_init_p2p
 //   --tune key=value  a launch knob of pcr_tune() (repeatable)
 #include <atomic>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -108,9 +109,19 @@ static void write_outputs(const pcr_params& param, const std::string& model, con
 // Shared between the parent and its workers (anonymous MAP_SHARED, made before the fork): the RCCL id, the result factors.
 struct SharedHdr {
     std::atomic<int> id_ready, failed, nranks_reported;
+    std::atomic<int> done[16];               // rank q has deposited its rows of U (and rank 0 V): all of them before the model is written
     unsigned char nccl_id[128];
     char shm_name[64];
 };
+
+// the parent's children, for the signal handler: killing the parent must not leave GPU workers behind
+static volatile sig_atomic_t g_nkids = 0;
+static pid_t g_kids[16];
+static volatile sig_atomic_t g_signalled = 0;
+static void forward_signal(int sig) {
+    g_signalled = sig;
+    for (int i = 0; i < g_nkids; ++i) if (g_kids[i] > 0) kill(g_kids[i], SIGTERM);
+}
 
 // body of worker `rank`: everything that touches a GPU happens here, after the fork
 static int worker(const pcr_dataset* ds, pcr_params param, int rank, int nranks, const std::string& comm_kind, SharedHdr* hdr,
@@ -154,6 +165,7 @@ static int worker(const pcr_dataset* ds, pcr_params param, int rank, int nranks,
         printf("Wall-time: %lg secs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         fflush(stdout);
     }
+    hdr->done[rank].store(1, std::memory_order_release);
     pcr_solver_destroy(s);
     return 0;
 }
@@ -168,16 +180,27 @@ static int train_multi(const pcr_dataset* ds, const pcr_params& param, int gpus,
     if (mem == MAP_FAILED) { perror("mmap"); return 1; }
     SharedHdr* hdr = new (mem) SharedHdr();
     hdr->id_ready.store(0); hdr->failed.store(0); hdr->nranks_reported.store(0);
-    snprintf(hdr->shm_name, sizeof hdr->shm_name, "/pcr_p2p_%d", (int)getpid());
-    shm_unlink(hdr->shm_name);                           // (a stale segment of a crashed job that had this pid)
+    for (auto& d : hdr->done) d.store(0);
+    {   // the control block's name: pid + something a bystander cannot predict
+        unsigned long long rnd = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+        if (FILE* ur = fopen("/dev/urandom", "rb")) { if (fread(&rnd, sizeof rnd, 1, ur) != 1) rnd ^= (unsigned long long)getpid() << 32; fclose(ur); }
+        snprintf(hdr->shm_name, sizeof hdr->shm_name, "/pcr_p2p_%d_%016llx", (int)getpid(), rnd);
+    }
     double* Ush = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(hdr + 1) + 63) & ~(uintptr_t)63);
     double* Vsh = Ush + nU;
     fflush(stdout); fflush(stderr);
     std::vector<pid_t> kids;
+    struct sigaction sa_new, sa_int, sa_term;
+    memset(&sa_new, 0, sizeof sa_new);
+    sa_new.sa_handler = forward_signal;                   // (no SA_RESTART: wait() returns EINTR and the loop below sees g_signalled)
+    sigemptyset(&sa_new.sa_mask);
+    sigaction(SIGINT, &sa_new, &sa_int);
+    sigaction(SIGTERM, &sa_new, &sa_term);
     for (int q = 0; q < gpus; ++q) {
         const pid_t pid = fork();
         if (pid < 0) { perror("fork"); for (pid_t k : kids) kill(k, SIGKILL); return 1; }
         if (pid == 0) {
+            signal(SIGINT, SIG_DFL); signal(SIGTERM, SIG_DFL);
             pcr_params p = param;
             p.device = devices.empty() ? q : devices[q];
             const int rc = worker(ds, p, q, gpus, comm_kind, hdr, Ush, Vsh, U, V, d1, d2, snapshot_every, model);
@@ -185,6 +208,7 @@ static int train_multi(const pcr_dataset* ds, const pcr_params& param, int gpus,
             _exit(rc);
         }
         kids.push_back(pid);
+        g_kids[g_nkids] = pid; g_nkids = g_nkids + 1;
     }
     // the parent never touches a GPU: it waits; the first worker that fails takes the others with it (a rank blocked in an
     // RCCL collective whose peer died would wait forever)
@@ -192,7 +216,17 @@ static int train_multi(const pcr_dataset* ds, const pcr_params& param, int gpus,
     for (size_t left = kids.size(); left > 0;) {
         int st = 0;
         const pid_t pid = wait(&st);
-        if (pid < 0) break;
+        if (pid < 0) {
+            if (errno == EINTR) {                          // a signal for the parent: its handler has told the workers; keep reaping
+                if (g_signalled && !bad) { bad = 1; hdr->failed.store(1); }
+                continue;
+            }
+            perror("wait");                                // ECHILD etc.: the job's outcome is unknown -> failure
+            bad = 1;
+            hdr->failed.store(1);
+            for (pid_t k : kids) kill(k, SIGTERM);
+            break;
+        }
         --left;
         const bool ok = WIFEXITED(st) && WEXITSTATUS(st) == 0;
         if (!ok && !bad) {
@@ -201,7 +235,13 @@ static int train_multi(const pcr_dataset* ds, const pcr_params& param, int gpus,
             for (pid_t k : kids) if (k != pid) kill(k, SIGTERM);
         }
     }
+    g_nkids = 0;
+    sigaction(SIGINT, &sa_int, nullptr);
+    sigaction(SIGTERM, &sa_term, nullptr);
     shm_unlink(hdr->shm_name);                           // (rank 0 unlinks it once everyone is attached; a job that failed earlier did not)
+    if (g_signalled) bad = 1;
+    for (int q = 0; q < gpus && !bad; ++q)
+        if (!hdr->done[q].load(std::memory_order_acquire)) { fprintf(stderr, "omp-pmf-train: rank %d left without depositing its factors\n", q); bad = 1; }
     if (bad) { fprintf(stderr, "omp-pmf-train: a GPU worker failed\n"); munmap(mem, bytes); return 1; }
     if (hdr->nranks_reported.load() != gpus) {
         fprintf(stderr, "omp-pmf-train: the communicator reports %d ranks, expected %d\n", hdr->nranks_reported.load(), gpus);

@@ -51,6 +51,18 @@ extern "C" int pcr_initial(double* X, int64_t n, int64_t k) {
     return PCR_OK;
 }
 
+extern "C" int pcr_initial_rows(double* X, int64_t n, int64_t k, int64_t row0, int64_t nrows) {
+    if (!X || n < 0 || k < 0 || row0 < 0 || nrows < 0 || row0 + nrows > n) { pcr_set_error("pcr_initial_rows: bad argument"); return PCR_ERR_ARG; }
+    std::default_random_engine generator;
+    std::normal_distribution<double> distribution(0.0, 1.0);
+    for (int64_t i = 0; i < row0 + nrows; ++i)
+        for (int64_t j = 0; j < k; ++j) {
+            const double v = distribution(generator);
+            if (i >= row0) X[(i - row0) * k + j] = v;
+        }
+    return PCR_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // CSR conversion
 // ------------------------------------------------------------------------------------------
@@ -176,7 +188,7 @@ static std::mutex g_tune_mu;
 static std::map<std::string, std::string>& tune_table() { static std::map<std::string, std::string> t; return t; }
 static const char* const TUNE_KEYS[] = {"ustep_mode", "ustep_many", "cluster_k", "cluster_users", "ubins", "spmm_tiles", "spmm_chunk", "sddmm_tile",
                                         "sddmm_csc", "lanes", "window_cache", "prepare_merged", "sweep_wave_cap", "eval_brute", "pipeline",
-                                        "ustep_seq", "ustep_lockstep", "ustep_gram", "count_rows", "wide_teams", "ustep_win_lds", "win16", "sweep_prefetch", "ustep_small_unr", "ustep_ls_recur", "allreduce_chunks", "debug", "fault_cluster_member", nullptr};
+                                        "ustep_seq", "ustep_lockstep", "ustep_gram", "count_rows", "wide_teams", "ustep_win_lds", "win16", "sweep_prefetch", "ustep_small_unr", "ustep_ls_recur", "allreduce_chunks", "cluster_fence", "debug", "fault_cluster_member", nullptr};
 extern "C" int pcr_tune(const char* key, const char* value) {
     if (!key) { pcr_set_error("pcr_tune: null key"); return PCR_ERR_ARG; }
     bool known = false;

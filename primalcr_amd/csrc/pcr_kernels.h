@@ -1427,27 +1427,34 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_cg_stop(const double* __restri
 // decisions are recomputed redundantly and are bitwise identical, so the members never have to
 // agree on control flow), but each member gathers only its 1/K slice of the rows; slices of scores
 // and partial r-vectors are exchanged through global memory.
-// Hand-off protocol (cdna_hip_programming.md Guideline 16, the write-through form): every handed-off byte is stored by an
-// agent-scope (sc1) store -> every wave s_waitcnt vmcnt(0) -> workgroup barrier -> lane 0: relaxed agent atomic add on the
-// cluster's arrival counter -> relaxed poll (bounded, with s_sleep) -> workgroup barrier -> EVERY load of handed-off bytes is
-// an agent-scope (sc1) load.  No release / acquire fence: nothing else a member reads in the launch is written by another
-// workgroup (a user's state and factor row are read by all members at its start and rewritten by member 0 at its end), and
-// the fences cost 5 % of the cluster class (ml1m: 409 -> 388 us).  Placement-independent; the launch keeps the grid <= one
-// workgroup per CU so all members are co-resident.
+// Hand-off protocol (cdna_hip_programming.md Guideline 16): every handed-off byte is stored by an agent-scope (sc1, written
+// through) store -> every wave s_waitcnt vmcnt(0) -> workgroup barrier -> lane 0: agent-scope RELEASE, vmcnt(0), relaxed agent
+// atomic add on the cluster's arrival counter -> relaxed poll (bounded, with s_sleep) -> agent-scope ACQUIRE, vmcnt(0) ->
+// workgroup barrier -> loads of the handed-off bytes (agent-scope, sc1).  That is the formally ordered form and the default.
+// fenced = false (pcr_tune "cluster_fence" = 0) drops the release and the acquire: the payload is sc1 both ways, which is the
+// first row of MI355X_MICROARCH.md's table of hand-offs measured valid WITHOUT the acquire on gfx950 -- measured, "not an
+// architectural guarantee", and its "one workgroup per CU" cell does not hold while other length classes share the CUs -- for
+// 5 % of the cluster class (ml1m: 409 -> 388 us, 1 % of a step).  Placement-independent either way; the launch keeps the grid
+// <= one workgroup per CU so all members are co-resident.
 // ---------------------------------------------------------------------------------------
 struct ClusterBufs {
     unsigned* bar;          // one arrival counter per cluster (zeroed before every launch)
     char* xch;              // per cluster: 2 x cap_pad scores (T) + 2 x K x ld doubles
     size_t xch_stride;
+    unsigned long long* rows;   // this length class's cumulative count of gathered rows (pcr_tune "count_rows"; never reset)
 };
 
 template <int K>
-__device__ __forceinline__ void cluster_barrier(unsigned* bar, unsigned& phase, unsigned long long* err) {
+__device__ __forceinline__ void cluster_barrier(unsigned* bar, unsigned& phase, unsigned long long* err, bool fenced) {
     if (K == 1) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // every storing wave drains its write-through stores
     __syncthreads();
     phase += 1;
     if (threadIdx.x == 0) {
+        if (fenced) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (explicit: the compiler may drop the wait behind the write-back)
+        }
         __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = phase * K;
         unsigned spins = 0;
@@ -1457,6 +1464,10 @@ __device__ __forceinline__ void cluster_barrier(unsigned* bar, unsigned& phase, 
             __builtin_amdgcn_s_sleep(2);
             if ((++spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
             if (spins > (1u << 21)) { atomicAdd(err, 1ull); break; }
+        }
+        if (fenced) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");            // (no instruction: keeps the payload loads below the poll)
@@ -1492,7 +1503,9 @@ static inline size_t ustep_xch_bytes(int cap_pad, int ld, int K) {
 // RES: the workgroup keeps rows of V in LDS (rcap > 0); UNR: rows in flight per lane group of the L2 gathers (8 for the
 // latency-bound classes with few users, one workgroup per CU; 4 keeps the kernel at <= 128 VGPRs so that two 512-thread
 // workgroups share a CU in the throughput-bound classes with many users).
-template <typename T, int BLOCK, bool BIG, int K, bool RES, int UNR>
+// CLS: nothing but a distinct kernel SYMBOL for two length classes that run the same workgroup form, so that a profiler's
+// per-symbol figures (rocprofv3 --stats, --pmc) belong to one class each.
+template <typename T, int BLOCK, bool BIG, int K, bool RES, int UNR, int CLS = 0>
 __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                  T* __restrict__ U, const T* __restrict__ Vm, double lambda, double stepsize0,
                                                  int cg_max, double cg_tol, int strict, int solver1, int cap, int cap_pad, int rs_cap, int rcap, int nchp,
@@ -1552,7 +1565,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         // exchange buffers are re-used, and the per-XCD L2s are not coherent with each other: every
         // store and load of handed-off bytes is agent-scope (sc1: write-through / L2-revalidated)
         for (int p = r0 + tid; p < r1; p += BLOCK) __hip_atomic_store(buf + p, key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cluster_barrier<K>(bar, phase, counters + 3);
+        cluster_barrier<K>(bar, phase, counters + 3, !(fault & 16));
         for (int p = tid; p < n; p += BLOCK) key[p] = __hip_atomic_load(buf + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
     };
@@ -1562,7 +1575,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         double* buf = (xv_par & 1) ? xv1 : xv0; xv_par += 1;
         for (int t = tid; t < ld; t += BLOCK)
             __hip_atomic_store(buf + (size_t)mem * ld + t, part[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cluster_barrier<K>(bar, phase, counters + 3);
+        cluster_barrier<K>(bar, phase, counters + 3, !(fault & 16));
         for (int t = tid; t < ld; t += BLOCK) {
             double sum = 0.0;
             for (int j = 0; j < K; ++j) sum += __hip_atomic_load(buf + (size_t)j * ld + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1774,7 +1787,11 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
             if (n_ls) atomicAdd(counters + 1, (unsigned long long)n_ls);
             // rows of V this user's step gathered: gradient + 2 per CG iteration + 1 per line-search try (diagnostic, only
             // with pcr_tune("count_rows"): a third same-address atomic per user costs the short classes 10-20 %)
-            if (fault & 2) atomicAdd(counters + 2, (unsigned long long)n * (unsigned long long)(1 + 2 * n_cg + n_ls - ls_free));
+            if (fault & 2) {
+                const unsigned long long rows = (unsigned long long)n * (unsigned long long)(1 + 2 * n_cg + n_ls - ls_free);
+                atomicAdd(counters + 2, rows);
+                atomicAdd(cb.rows, rows);
+            }
         }
         __syncthreads();
         UPROF(10);

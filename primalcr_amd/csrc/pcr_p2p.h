@@ -27,13 +27,20 @@
 #include <string>
 #include <thread>
 
+#include <algorithm>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 #define PCR_P2P_MAXR 16
 
-struct P2PCtl {                               // in POSIX shared memory, zero-filled when created
+#define PCR_P2P_MAGIC 0x50435250325033ull     // "PCRP2P3"
+struct P2PCtl {                               // in POSIX shared memory, created (O_EXCL) and zero-filled by rank 0
+    std::atomic<uint64_t> magic;              // written LAST by rank 0: the block is ready
+    uint64_t created_ns;                      // CLOCK_REALTIME at creation: a block older than the rendezvous time-out is a dead job's
+    uint32_t nranks_expected;
     std::atomic<uint32_t> count, gen, attached;
     std::atomic<int32_t> error;
     std::atomic<uint32_t> posted[PCR_P2P_MAXR];
@@ -102,24 +109,58 @@ struct P2PComm {
         return ctl->error.load() == 0 || fail("a peer rank reported an error");
     }
 
+    static uint64_t now_ns() { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec; }
     // elems_max: longest vector (elements of elt bytes) that will be all-reduced
+    // Rendezvous: rank 0 removes whatever carries the name (a crashed job's segment still holds posted[] = 1, dead IPC handles,
+    // maybe error = 1), creates the block with O_CREAT | O_EXCL, fills it and writes the magic word LAST; the other ranks open
+    // the name until they find a block whose magic, rank count and age say it is THIS job's.  Callers should put something
+    // unpredictable into the name (the CLI and bench.py do).
     bool init(const char* name, int rank_, int nranks_, size_t elems_max, size_t elt) {
         rank = rank_; nranks = nranks_;
         if (nranks > PCR_P2P_MAXR) return fail("p2p communicator: at most 16 ranks");
         shm_name = name;
-        const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
-        if (fd < 0) return fail(std::string("shm_open ") + name + ": " + strerror(errno));
-        if (ftruncate(fd, sizeof(P2PCtl)) != 0) { close(fd); return fail("ftruncate on the control block failed"); }
-        void* m = mmap(nullptr, sizeof(P2PCtl), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        close(fd);
-        if (m == MAP_FAILED) return fail("mmap of the control block failed");
-        ctl = static_cast<P2PCtl*>(m);
+        const auto t_open = std::chrono::steady_clock::now();
+        auto waited = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count(); };
+        if (rank == 0) {
+            shm_unlink(name);
+            const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+            if (fd < 0) return fail(std::string("shm_open ") + name + ": " + strerror(errno));
+            if (ftruncate(fd, sizeof(P2PCtl)) != 0) { close(fd); shm_unlink(name); return fail("ftruncate on the control block failed"); }
+            void* m = mmap(nullptr, sizeof(P2PCtl), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (m == MAP_FAILED) { shm_unlink(name); return fail("mmap of the control block failed"); }
+            ctl = static_cast<P2PCtl*>(m);
+            ctl->created_ns = now_ns();
+            ctl->nranks_expected = (uint32_t)nranks;
+            ctl->magic.store(PCR_P2P_MAGIC, std::memory_order_release);
+        } else {
+            for (;;) {
+                const int fd = shm_open(name, O_RDWR, 0600);
+                if (fd >= 0) {
+                    struct stat sb;
+                    void* m = (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= sizeof(P2PCtl))
+                                  ? mmap(nullptr, sizeof(P2PCtl), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+                    close(fd);
+                    if (m != MAP_FAILED) {
+                        P2PCtl* c = static_cast<P2PCtl*>(m);
+                        const uint64_t age = now_ns() - c->created_ns;
+                        if (c->magic.load(std::memory_order_acquire) == PCR_P2P_MAGIC && c->nranks_expected == (uint32_t)nranks &&
+                            age < (uint64_t)(timeout_s * 1e9)) { ctl = c; break; }
+                        munmap(m, sizeof(P2PCtl));               // not (yet) this job's block: rank 0 will replace it
+                    }
+                }
+                if (waited() > timeout_s) { err = "no control block from rank 0 (rendezvous timed out)"; return false; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+        }
         cap_bytes = ((elems_max * elt) + 255) & ~(size_t)255;
         const size_t per = (elems_max + nranks - 1) / nranks;
         slice_bytes = ((per * elt) + 255) & ~(size_t)255;
         if (hipMalloc((void**)&xbuf, total_bytes()) != hipSuccess) return fail("hipMalloc of the exchange buffer failed");
         if (hipMemset(xbuf, 0, total_bytes()) != hipSuccess) return fail("hipMemset of the exchange buffer failed");
-        if (hipIpcGetMemHandle(&ctl->handle[rank], xbuf) != hipSuccess) return fail("hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)");
+        // (dmabuf IPC: on hosts whose driver has no legacy IPC mode the process must run with HSA_ENABLE_IPC_MODE_LEGACY=0 --
+        // an environment prerequisite of the ROCm runtime, listed in include/primalcr.h; the library itself reads no variable)
+        if (hipIpcGetMemHandle(&ctl->handle[rank], xbuf) != hipSuccess) return fail("hipIpcGetMemHandle failed (on dmabuf-only hosts run with HSA_ENABLE_IPC_MODE_LEGACY=0)");
         ctl->bytes[rank] = total_bytes();
         ctl->posted[rank].store(1, std::memory_order_release);
         const auto t0 = std::chrono::steady_clock::now();
@@ -140,6 +181,7 @@ struct P2PComm {
         ctl->attached.fetch_add(1);
         if (!barrier()) return false;
         if (rank == 0) shm_unlink(name);      // everyone is attached: the name can go (the mapping lives on)
+        ready = true;
         return true;
     }
 
@@ -179,7 +221,24 @@ struct P2PComm {
 
     void abort_peers() { if (ctl) ctl->error.store(1); }
 
+    // Closing rendezvous: the last all-reduce launched its reduce / gather kernel asynchronously after its last host barrier, so a
+    // peer's kernel may still be reading this rank's buffers when this rank gets here.  Drain the device, then meet the peers
+    // once more (short time-out, the error flag tolerated: a failed job must still be able to leave) before anything is unmapped.
+    void finalize() {
+        if (finalized || !ctl) return;
+        finalized = true;
+        (void)hipDeviceSynchronize();
+        if (!ready) return;                                    // the rendezvous never completed: nobody maps this rank's buffer
+        const double keep = timeout_s;
+        const std::string keep_err = err;
+        timeout_s = std::min(timeout_s, 10.0);
+        (void)barrier();                                       // (false when a peer failed or is gone: leave anyway)
+        err = keep_err; timeout_s = keep;
+    }
+    bool finalized = false, ready = false;
+
     ~P2PComm() {
+        finalize();
         for (int r = 0; r < nranks; ++r) if (r != rank && peer[r]) (void)hipIpcCloseMemHandle(peer[r]);
         if (xbuf) (void)hipFree(xbuf);
         if (ctl) munmap(ctl, sizeof(P2PCtl));

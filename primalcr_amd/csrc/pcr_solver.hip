@@ -86,6 +86,7 @@ struct Bin {
     int unr = 4;         // k_ustep: rows in flight per lane group (8: latency-bound class, one workgroup per CU)
     bool gram = false;   // k_ustep_gram: the dual (Gram-matrix, MFMA) form for users with few ratings
     int wcap = 0;        // k_ustep: 16-bit window entries cached in LDS (cap * ws, or 0)
+    int sym = 0;         // k_ustep: symbol id (template parameter CLS) among the classes that run the same workgroup form
     int max_lev = 0;
     int64_t nnz = 0;     // ratings of the users in the bin
     std::vector<int32_t> users;
@@ -108,8 +109,8 @@ struct ProfSlot {
 
 struct pcr_solver {
     virtual ~pcr_solver() {}
-    virtual int set_factors(const double* U, const double* V) = 0;
-    virtual int get_factors(double* U, double* V) = 0;
+    virtual int set_factors(const double* U, const double* V, bool local) = 0;
+    virtual int get_factors(double* U, double* V, bool local) = 0;
     virtual int comp_m(double* m_out) = 0;
     virtual int objective(double* obj) = 0;
     virtual int obtain_g(double* g) = 0;
@@ -125,6 +126,8 @@ struct pcr_solver {
     virtual void comm_abort() = 0;
     virtual int comm_nranks() = 0;
     virtual int sync() = 0;
+    virtual std::string ustep_classes() = 0;                       // comma-separated profile slot names of the U-step length classes
+    virtual int class_rows(const std::string& slot, double* v) = 0; // rows of V that class has gathered so far (pcr_tune "count_rows")
     int64_t first_user = 0, n_users = 0, nnz_local = 0;
     double ustep_rows = 0.0;      // rows of V gathered by all U steps so far (all ranks); pcr_solver_counter("ustep_row_gathers")
     bool prof_on = false;
@@ -139,7 +142,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = -1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
-        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_small_unr = 0, ustep_ls_recur = 1, allreduce_chunks = 0;
+        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_small_unr = 0, ustep_ls_recur = 1, allreduce_chunks = 0, cluster_fence = 1;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -152,7 +155,7 @@ struct Tune {
         ustep_gram = pcr_tune_int("ustep_gram", -1); count_rows = pcr_tune_int("count_rows", 0);
         wide_teams = pcr_tune_int("wide_teams", -1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); win16 = pcr_tune_int("win16", 1); sweep_prefetch = pcr_tune_int("sweep_prefetch", -1);
         ustep_small_unr = pcr_tune_int("ustep_small_unr", 0); ustep_ls_recur = pcr_tune_int("ustep_ls_recur", 1);
-        allreduce_chunks = pcr_tune_int("allreduce_chunks", 0);
+        allreduce_chunks = pcr_tune_int("allreduce_chunks", 0); cluster_fence = pcr_tune_int("cluster_fence", 1);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -218,6 +221,7 @@ struct Solver final : pcr_solver {
     unsigned* bar_p = nullptr;                    // cluster arrival counters: live behind the 68 counters of d_counters (one memset)
     size_t bar_n = 0;
     DBuf<char> d_xch;
+    DBuf<unsigned long long> d_rowcnt;            // per U-step class: rows of V gathered since the solver was created (count_rows)
     size_t xch_stride = 0;
     int max_clusters = 1;
     // ---- lock-step U step (pcr_kernels.h, "Lock-step U step"): user-major slab SpMM over the CSR + per-user CG state
@@ -410,7 +414,9 @@ struct Solver final : pcr_solver {
             });
     }
 
-    int init(const pcr_dataset* ds, const pcr_params* p, int rank_, int nranks_) {
+    // shard_first >= 0: `ds` holds ONLY this rank's users (renumbered from 0) -- users [shard_first, shard_first + ds.d1) of a
+    // job with d1_total users (pcr_solver_create_shard); else the whole data set, partitioned here by pcr_partition_users
+    int init(const pcr_dataset* ds, const pcr_params* p, int rank_, int nranks_, int64_t shard_first = -1, int64_t d1_total = 0) {
         prm = *p; rank = rank_; nranks = nranks_;
         tune.read();
         if (prm.cg_max_iter == 0) prm.cg_max_iter = 10;      // zero-filled extension fields = the reference's constants
@@ -448,22 +454,30 @@ struct Solver final : pcr_solver {
         geo.nchunk = geo.ld / VecOf<T>::N;
         geo.G = std::min(64, host_pow2(geo.nchunk));
 
-        std::vector<int64_t> bounds(nranks + 1);
-        RC(pcr_partition_users(X.index.data(), d1, nranks, bounds.data()));
-        first_user = bounds[rank];
-        n_users = bounds[rank + 1] - bounds[rank];
-        const int64_t z0 = X.index[first_user], z1 = X.index[first_user + n_users];
+        int64_t ds_u0 = 0;                                   // this rank's first user inside the data set's arrays
+        if (shard_first >= 0) {
+            if (d1_total < shard_first + X.d1 || d1_total >= (int64_t)1 << 31) { pcr_set_error("pcr_solver_create_shard: the shard does not fit the job's user range"); return PCR_ERR_ARG; }
+            if (ds->test.d1 != X.d1) { pcr_set_error("pcr_solver_create_shard: train and test user counts differ"); return PCR_ERR_ARG; }
+            first_user = shard_first; n_users = X.d1; d1 = d1_total;
+        } else {
+            std::vector<int64_t> bounds(nranks + 1);
+            RC(pcr_partition_users(X.index.data(), d1, nranks, bounds.data()));
+            first_user = bounds[rank];
+            n_users = bounds[rank + 1] - bounds[rank];
+            ds_u0 = first_user;
+        }
+        const int64_t z0 = X.index[ds_u0], z1 = X.index[ds_u0 + n_users];
         nnz_local = z1 - z0;
         if (nnz_local >= ((int64_t)1 << 31) - 1) { pcr_set_error("more than 2^31 ratings on one GPU"); return PCR_ERR_UNSUPPORTED; }
         const int64_t nu = n_users;
 
         // ---- host-side shard preparation
         std::vector<int64_t> uptr(nu + 1);
-        for (int64_t u = 0; u <= nu; ++u) uptr[u] = X.index[first_user + u] - z0;
+        for (int64_t u = 0; u <= nu; ++u) uptr[u] = X.index[ds_u0 + u] - z0;
         std::vector<int32_t> item(X.item.begin() + z0, X.item.begin() + z1);
         PcrLevels lv;
         std::string err;
-        int rc = pcr_build_levels(X, first_user, first_user + nu, prm.solver_type, lv, err);
+        int rc = pcr_build_levels(X, ds_u0, ds_u0 + nu, prm.solver_type, lv, err);
         if (rc != PCR_OK) { pcr_set_error(err); return rc; }
         // Tile-major CSC of the shard (pcr_kernels.h, k_spmm): users are cut into tiles of about equal rating count whose
         // rows of U take at most 1.25 MB (measured on a 48 k x 17.8 k, 10 M shape: 1.2 MB tiles 379 us, 2.4 MB tiles 595 us =
@@ -509,13 +523,14 @@ struct Solver final : pcr_solver {
                 tile_u.push_back(nu);
             }
             ntiles = (int64_t)tile_u.size() - 1;
-            // item ranges (see n_rng): only with an exchange step and a vector of at least 16 MB (about 4 MB per range, at most 8):
-            // a range costs two more launches and its own ramp and tail, which an exchange of a few MB (50-100 us over xGMI)
-            // does not pay for -- the Yahoo!Music shape's 109 MB do (one exchange ~ a third of a CG iteration at N = 8)
+            // item ranges (see n_rng): OPT-IN through pcr_tune("allreduce_chunks", n) -- the overlap of one range's all-reduce with the
+            // next range's SpMM is equality-tested with several ranks on one device, but has never run across two physical GPUs
+            // (no multi-GPU node was available to this build), so the default exchange is the plain one: one all-reduce per vector
+            // on the solver's stream.  Where it should pay: vectors of 16 MB and more (the Yahoo!Music shape's 109 MB: one exchange
+            // ~ a third of a CG iteration at N = 8), about one range per 4 MB, at most 8; a range costs two more launches and its
+            // own ramp and tail, which an exchange of a few MB does not pay for.
             {
-                const size_t vec_bytes = (size_t)d2 * geo.ld * sizeof(T);
                 n_rng = 1;
-                if (nranks > 1 && vec_bytes >= ((size_t)16 << 20)) n_rng = (int)std::min<size_t>(8, vec_bytes >> 22);
                 if (tune.allreduce_chunks > 0) n_rng = tune.allreduce_chunks;
                 n_rng = (int)std::max<int64_t>(1, std::min<int64_t>(n_rng, std::min<int64_t>(64, d2)));
                 rng_item.assign(n_rng + 1, 0);
@@ -793,6 +808,18 @@ struct Solver final : pcr_solver {
             xch_stride = (need_x + 255) & ~(size_t)255;
             bar_n = (size_t)max_clusters * ubins.size();               // the classes run concurrently: one set per class
             RC(d_xch.alloc(xch_stride * (size_t)max_clusters * ubins.size()));
+            RC(d_rowcnt.alloc(ubins.size()));
+            HIPCHK(hipMemset(d_rowcnt.p, 0, std::max<size_t>(ubins.size(), 1) * sizeof(unsigned long long)));
+        }
+        {   // two length classes that run the same workgroup form get kernel symbols of their own (k_ustep's CLS), so that
+            // rocprofv3's per-symbol durations and PMC bytes belong to one class each
+            std::map<std::string, int> seen;
+            for (auto& b : ubins) {
+                if (b.users.empty() || b.gram) continue;
+                const std::string key = std::to_string(b.block) + (b.big ? "g" : "") + "k" + std::to_string(b.K) + (b.rcap > 0 ? "r" : "") + "u" + std::to_string(b.unr);
+                const bool two = !b.big && b.K == 1 && b.rcap == 0 && b.unr == 4;       // the forms instantiated twice (set_lds_limits)
+                b.sym = two ? (seen[key]++ & 1) : 0;
+            }
         }
 
         RC(d_uptr.upload(uptr, st)); RC(d_item.upload(item, st)); RC(d_lvl.upload(lv.level, st));
@@ -824,10 +851,10 @@ struct Solver final : pcr_solver {
         for (int w = 0; w < 2; ++w) {
             const PcrCsr& E = w == 0 ? ds->train : ds->test;
             EvalSet& es = ev[w];
-            const int64_t a = E.index[first_user], b = E.index[first_user + nu];
+            const int64_t a = E.index[ds_u0], b = E.index[ds_u0 + nu];
             es.nnz = b - a;
             es.h_uptr.resize(nu + 1);
-            for (int64_t u = 0; u <= nu; ++u) es.h_uptr[u] = E.index[first_user + u] - a;
+            for (int64_t u = 0; u <= nu; ++u) es.h_uptr[u] = E.index[ds_u0 + u] - a;
             es.h_val.assign(E.val.begin() + a, E.val.begin() + b);
             if (w == 1) {
                 std::vector<int32_t> it(E.item.begin() + a, E.item.begin() + b);
@@ -841,7 +868,7 @@ struct Solver final : pcr_solver {
             {
                 PcrLevels rl;
                 std::string e2;
-                if (pcr_build_levels(E, first_user, first_user + nu, PCR_SOLVER_PCR, rl, e2) == PCR_OK) {
+                if (pcr_build_levels(E, ds_u0, ds_u0 + nu, PCR_SOLVER_PCR, rl, e2) == PCR_OK) {
                     es.max_raw_levels = rl.max_levels;
                     RC(es.elvl.upload(rl.level, st)); RC(es.erunofs.upload(rl.run_ofs, st)); RC(es.erunstart.upload(rl.run_start, st));
                     make_bins(es.h_uptr, nu, &rl.run_ofs, es.bins);
@@ -949,6 +976,9 @@ struct Solver final : pcr_solver {
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
 #define UL(BL, BG, KK, RS, UN) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, BL, BG, KK, RS, UN>, hipFuncAttributeMaxDynamicSharedMemorySize, lim))
         UL(64, false, 1, true, 4); UL(64, false, 1, false, 4); UL(256, false, 1, false, 4);
+#define UL1(BL) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, BL, false, 1, false, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim))
+        UL1(64); UL1(256); UL1(512);
+#undef UL1
         UL(64, false, 1, true, 8); UL(64, false, 1, false, 8); UL(256, false, 1, false, 8);
         UL(512, false, 1, true, 8); UL(512, false, 1, false, 4); UL(512, false, 4, true, 8);
         UL(512, true, 1, true, 8); UL(512, true, 1, false, 4); UL(512, true, 4, true, 8);
@@ -1063,7 +1093,24 @@ struct Solver final : pcr_solver {
         if (b.gram) return std::string(cls) + "/gram" + std::to_string(b.block) + "." + std::to_string(b.limit);
         std::string s = std::string(cls) + "/" + std::to_string(b.block);
         if (!strcmp(cls, "ustep") && b.limit) s += "." + std::to_string(b.limit);
-        return s + (b.big ? "g" : "") + (b.K > 1 ? "c" : "");
+        return s + (b.big ? "g" : "") + (b.K > 1 ? "c" : "") + (b.sym ? "#" + std::to_string(b.sym) : "");
+    }
+    std::string ustep_classes() override {
+        std::string all;
+        for (auto& b : ubins) if (!b.users.empty()) { if (!all.empty()) all += ","; all += pname("ustep", b); }
+        return all;
+    }
+    int class_rows(const std::string& slot, double* v) override {
+        for (size_t bi = 0; bi < ubins.size(); ++bi) {
+            if (ubins[bi].users.empty() || pname("ustep", ubins[bi]) != slot) continue;
+            unsigned long long x = 0;
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipMemcpy(&x, d_rowcnt.p + bi, sizeof x, hipMemcpyDeviceToHost));
+            *v = (double)x;
+            return PCR_OK;
+        }
+        pcr_set_error("pcr_solver_counter: no U-step class '" + slot + "'");
+        return PCR_ERR_ARG;
     }
     size_t small_common(int block) const { return carve_bytes(geo.ld, sizeof(T)) + carve_bytes(block / PCR_WAVE + 1, 8); }
     int strict() const { return prm.solver_type == PCR_SOLVER_PCR ? 1 : 0; }
@@ -1367,14 +1414,15 @@ struct Solver final : pcr_solver {
         return PCR_OK;
     }
 
-    int set_factors(const double* U, const double* V) override {
-        if (U) { RC(upload_mat(U + first_user * geo.r, n_users, d_U.p)); unorm_valid = false; }
+    // local: U holds this rank's n_users rows only (else the full d1 x k matrix, of which this rank touches its own rows)
+    int set_factors(const double* U, const double* V, bool local) override {
+        if (U) { RC(upload_mat(U + (local ? 0 : first_user * geo.r), n_users, d_U.p)); unorm_valid = false; }
         if (V) RC(upload_mat(V, d2, d_V.p));
         have_sorted = false; state_of_rejected_V = false;
         return PCR_OK;
     }
-    int get_factors(double* U, double* V) override {
-        if (U) RC(download_mat(d_U.p, n_users, U + first_user * geo.r));
+    int get_factors(double* U, double* V, bool local) override {
+        if (U) RC(download_mat(d_U.p, n_users, U + (local ? 0 : first_user * geo.r)));
         if (V) RC(download_mat(d_V.p, d2, V));
         return PCR_OK;
     }
@@ -1587,11 +1635,13 @@ struct Solver final : pcr_solver {
             const size_t lds = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + ustep_rows_bytes(b.rcap, nchp) + carve_bytes(b.wcap, 2) +
                                (b.big ? 0 : ustep_big_bytes<T>(b.cap, cap_pad, rsc, 4));
             const size_t bi = (size_t)(&b - &ubins[0]);
-            ClusterBufs cb{bar_p + bi * max_clusters, d_xch.p + bi * max_clusters * xch_stride, xch_stride};
+            ClusterBufs cb{bar_p + bi * max_clusters, d_xch.p + bi * max_clusters * xch_stride, xch_stride, d_rowcnt.p + bi};
             // clusters: grid <= one workgroup per CU so that every member of every cluster is resident
             const int grid = b.ugrid;
             char* scr = d_scratch.p + (size_t)b.scratch_ofs * scratch_stride;
-#define LU(BL, BG, KK, RS, UN) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb, (tune.fault_cluster_member ? 1 : 0) | (tune.count_rows ? 2 : 0) | (state_of_rejected_V ? 4 : 0) | (tune.ustep_ls_recur ? 8 : 0), b.wcap)
+#define LUS(BL, BG, KK, RS, UN, SY) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN, SY>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb, (tune.fault_cluster_member ? 1 : 0) | (tune.count_rows ? 2 : 0) | (state_of_rejected_V ? 4 : 0) | (tune.ustep_ls_recur ? 8 : 0) | (tune.cluster_fence ? 0 : 16), b.wcap)
+#define LU(BL, BG, KK, RS, UN) LUS(BL, BG, KK, RS, UN, 0)
+#define LU2(BL) do { if (b.sym) LUS(BL, false, 1, false, 4, 1); else LUS(BL, false, 1, false, 4, 0); } while (0)
             if (b.gram) {
                 const size_t gl = gram_bytes<T>(b.cap, cap_pad, rsc, geo.ld, nchp, b.block);
                 if (b.block == 64)
@@ -1604,13 +1654,15 @@ struct Solver final : pcr_solver {
             }
             if (b.big) { if (b.K == 4) LU(512, true, 4, true, 8); else if (b.unr == 8) LU(512, true, 1, true, 8); else LU(512, true, 1, false, 4); }
             else if (b.block == 64 && b.unr == 8) { if (b.rcap > 0) LU(64, false, 1, true, 8); else LU(64, false, 1, false, 8); }
-            else if (b.block == 64) { if (b.rcap > 0) LU(64, false, 1, true, 4); else LU(64, false, 1, false, 4); }
+            else if (b.block == 64) { if (b.rcap > 0) LU(64, false, 1, true, 4); else LU2(64); }
             else if (b.block == 256 && b.unr == 8) LU(256, false, 1, false, 8);
-            else if (b.block == 256) LU(256, false, 1, false, 4);
+            else if (b.block == 256) LU2(256);
             else if (b.K == 4) LU(512, false, 4, true, 8);
             else if (b.unr == 8) LU(512, false, 1, true, 8);
-            else LU(512, false, 1, false, 4);
+            else LU2(512);
+#undef LU2
 #undef LU
+#undef LUS
         };
         if (tune.ustep_seq) RC(for_bins_seq(ubins, "ustep", fn)); else RC(for_ubins(fn));
         return PCR_OK;
@@ -1872,7 +1924,7 @@ struct Solver final : pcr_solver {
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-int pcr_solver_create(const pcr_dataset* ds, const pcr_params* p, int rank, int nranks, pcr_solver** out) {
+static int solver_create(const pcr_dataset* ds, const pcr_params* p, int rank, int nranks, int64_t shard_first, int64_t d1_total, pcr_solver** out) {
     if (!ds || !p || !out || nranks < 1 || rank < 0 || rank >= nranks) { pcr_set_error("pcr_solver_create: bad argument"); return PCR_ERR_ARG; }
     if (p->solver_type != PCR_SOLVER_PCR && p->solver_type != PCR_SOLVER_PCRPP) {
         pcr_set_error("wrong solver type (" + std::to_string(p->solver_type) + "): 1 = PrimalCR, 2 = PrimalCR++");
@@ -1881,12 +1933,12 @@ int pcr_solver_create(const pcr_dataset* ds, const pcr_params* p, int rank, int 
     int rc;
     if (p->precision == PCR_F64) {
         auto* s = new Solver<double>();
-        rc = s->init(ds, p, rank, nranks);
+        rc = s->init(ds, p, rank, nranks, shard_first, d1_total);
         if (rc != PCR_OK) { delete s; return rc; }
         *out = s;
     } else if (p->precision == PCR_F32) {
         auto* s = new Solver<float>();
-        rc = s->init(ds, p, rank, nranks);
+        rc = s->init(ds, p, rank, nranks, shard_first, d1_total);
         if (rc != PCR_OK) { delete s; return rc; }
         *out = s;
     } else {
@@ -1894,6 +1946,14 @@ int pcr_solver_create(const pcr_dataset* ds, const pcr_params* p, int rank, int 
         return PCR_ERR_ARG;
     }
     return PCR_OK;
+}
+int pcr_solver_create(const pcr_dataset* ds, const pcr_params* p, int rank, int nranks, pcr_solver** out) {
+    return solver_create(ds, p, rank, nranks, -1, 0, out);
+}
+int pcr_solver_create_shard(const pcr_dataset* ds_local, const pcr_params* p, int rank, int nranks, int64_t first_user, int64_t d1_total,
+                            pcr_solver** out) {
+    if (first_user < 0) { pcr_set_error("pcr_solver_create_shard: first_user must be >= 0"); return PCR_ERR_ARG; }
+    return solver_create(ds_local, p, rank, nranks, first_user, d1_total, out);
 }
 void pcr_solver_destroy(pcr_solver* s) { delete s; }
 
@@ -1917,6 +1977,7 @@ int pcr_solver_counter(pcr_solver* s, const char* name, double* value) {
     S_OR_ARG;
     if (!name || !value) { pcr_set_error("pcr_solver_counter: bad argument"); return PCR_ERR_ARG; }
     if (!strcmp(name, "ustep_row_gathers")) { *value = s->ustep_rows; return PCR_OK; }
+    if (!strncmp(name, "ustep_row_gathers/", 18)) return s->class_rows(name + 18, value);
     pcr_set_error(std::string("pcr_solver_counter: unknown counter '") + name + "'");
     return PCR_ERR_ARG;
 }
@@ -1930,8 +1991,10 @@ int pcr_solver_shard(const pcr_solver* s, int64_t* first_user, int64_t* n_users,
     if (nnz_local) *nnz_local = s->nnz_local;
     return PCR_OK;
 }
-int pcr_solver_set_factors(pcr_solver* s, const double* U, const double* V) { S_OR_ARG; return s->set_factors(U, V); }
-int pcr_solver_get_factors(pcr_solver* s, double* U, double* V) { S_OR_ARG; return s->get_factors(U, V); }
+int pcr_solver_set_factors(pcr_solver* s, const double* U, const double* V) { S_OR_ARG; return s->set_factors(U, V, false); }
+int pcr_solver_get_factors(pcr_solver* s, double* U, double* V) { S_OR_ARG; return s->get_factors(U, V, false); }
+int pcr_solver_set_factors_local(pcr_solver* s, const double* U_local, const double* V) { S_OR_ARG; return s->set_factors(U_local, V, true); }
+int pcr_solver_get_factors_local(pcr_solver* s, double* U_local, double* V) { S_OR_ARG; return s->get_factors(U_local, V, true); }
 int pcr_comp_m(pcr_solver* s, double* m_out) { S_OR_ARG; return s->comp_m(m_out); }
 int pcr_objective(pcr_solver* s, double* obj) { S_OR_ARG; return s->objective(obj); }
 int pcr_obtain_g(pcr_solver* s, double* g) { S_OR_ARG; return s->obtain_g(g); }
@@ -1949,6 +2012,13 @@ int pcr_profile_reset(pcr_solver* s) {
     S_OR_ARG;
     s->sync(); s->prof_resolve();
     for (auto& kv : s->prof) { kv.second.ms = 0.0; kv.second.n = 0; kv.second.seen = 0; }
+    return PCR_OK;
+}
+int pcr_solver_ustep_classes(pcr_solver* s, char* buf, int64_t cap) {
+    S_OR_ARG;
+    const std::string all = s->ustep_classes();
+    if (!buf || cap < (int64_t)all.size() + 1) { pcr_set_error("buffer too small"); return PCR_ERR_ARG; }
+    memcpy(buf, all.c_str(), all.size() + 1);
     return PCR_OK;
 }
 int pcr_profile_list(pcr_solver* s, char* buf, int64_t cap) {

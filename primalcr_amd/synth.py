@@ -121,9 +121,24 @@ def _sample_items(rng, cnt, d2, chunk_users=1 << 16):
     return np.concatenate(users_out), np.concatenate(items_out)
 
 
+def _draw_sets(seed, d1, d2, nnz, mu, sigma, n_test, lo):
+    """The part of generate() up to the ground-truth factors: (rng, cnt, cnt_all, user, item, Ug, Vg)."""
+    rng = np.random.default_rng(seed)
+    cnt = _user_counts(rng, d1, d2, nnz, mu, sigma, lo)
+    cnt_all = np.minimum(cnt + n_test, d2)
+    user, item = _sample_items(rng, cnt_all, d2)
+    # rank-8 ground truth + noise
+    k = 8
+    Ug = rng.normal(0.0, np.sqrt(1.0 / k), size=(d1, k))
+    Vg = rng.normal(0.0, 1.0, size=(d2, k))
+    return rng, cnt, cnt_all, user, item, Ug, Vg
+
+
 def generate(shape: str = "ml1m", seed: int = SEED, *, d1=None, d2=None, nnz=None,
-             mu=None, sigma=None, real_valued=None, n_test=None, min_count=None) -> Ratings:
-    """Generate a synthetic rating set of a named shape (or override the fields)."""
+             mu=None, sigma=None, real_valued=None, n_test=None, min_count=None, item_seed=None) -> Ratings:
+    """Generate a synthetic rating set of a named shape (or override the fields).
+    item_seed: take the items' ground-truth factors from the set of THAT seed (same shape) -- independent user blocks of one
+    item catalogue (bench.py --gpus N: rank q's users are the set of seed SEED + q, the catalogue that of seed SEED)."""
     s = SHAPES[shape]
     d1 = s[0] if d1 is None else d1
     d2 = s[1] if d2 is None else d2
@@ -132,15 +147,10 @@ def generate(shape: str = "ml1m", seed: int = SEED, *, d1=None, d2=None, nnz=Non
     sigma = s[4] if sigma is None else sigma
     real_valued = s[5] if real_valued is None else real_valued
     n_test = s[6] if n_test is None else n_test
-    rng = np.random.default_rng(seed)
     lo = (10 if d2 >= 64 else 2) if min_count is None else min_count
-    cnt = _user_counts(rng, d1, d2, nnz, mu, sigma, lo)
-    cnt_all = np.minimum(cnt + n_test, d2)
-    user, item = _sample_items(rng, cnt_all, d2)
-    # rank-8 ground truth + noise
-    k = 8
-    Ug = rng.normal(0.0, np.sqrt(1.0 / k), size=(d1, k))
-    Vg = rng.normal(0.0, 1.0, size=(d2, k))
+    rng, cnt, cnt_all, user, item, Ug, Vg = _draw_sets(seed, d1, d2, nnz, mu, sigma, n_test, lo)
+    if item_seed is not None and item_seed != seed:
+        Vg = _draw_sets(item_seed, d1, d2, nnz, mu, sigma, n_test, lo)[6]
     score = np.empty(user.shape[0], np.float64)
     B = 1 << 22
     for a in range(0, user.shape[0], B):
@@ -225,8 +235,10 @@ def _slib():
 
 
 def generate_fast(shape: str = "netflix", seed: int = SEED, *, d1=None, d2=None, nnz=None, mu=None, sigma=None,
-                  real_valued=None, n_test=None, min_count=None, users=None, threads=0) -> CsrRatings:
-    """The shape (or overrides) from the C++ generator; users=(u0, u1) generates only that user range of it."""
+                  real_valued=None, n_test=None, min_count=None, users=None, threads=0, counts_only=False) -> CsrRatings:
+    """The shape (or overrides) from the C++ generator; users=(u0, u1) generates only that user range of it;
+    counts_only: just the per-user (training, held-out) rating counts of the whole shape -- what a rank needs to pick its
+    nnz-balanced user range before it generates anything."""
     s = SHAPES[shape]
     d1 = s[0] if d1 is None else d1
     d2 = s[1] if d2 is None else d2
@@ -238,6 +250,8 @@ def generate_fast(shape: str = "netflix", seed: int = SEED, *, d1=None, d2=None,
     ctr, cte = np.empty(d1, np.int64), np.empty(d1, np.int64)
     if L.pcr_synth_counts(P, ctr.ctypes.data, cte.ctypes.data) != 0:
         raise RuntimeError("pcr_synth_counts failed")
+    if counts_only:
+        return ctr, cte
     u0, u1 = (0, d1) if users is None else users
     index = np.concatenate([[0], np.cumsum(ctr[u0:u1])]).astype(np.int64)
     tindex = np.concatenate([[0], np.cumsum(cte[u0:u1])]).astype(np.int64)

@@ -223,6 +223,27 @@ def test_user_sharding_on_one_gpu(oracle, nranks):
     assert abs(obj_sum / obj_full - 1) < 1e-12
     assert rel(g_sum, g_full) < 1e-12 and rel(Ha_sum, Ha_full) < 1e-12
     assert rel(U_sh, U_full) < 1e-12
+    # pcr_solver_create_shard: a rank that holds ONLY its own users (renumbered from 0) is the same solver, bit for bit
+    idx, item, val = ds.csr(0)
+    tidx, titem, tval = ds.csr(1)
+    for q, s in enumerate(shards):
+        u0, u1 = int(bounds[q]), int(bounds[q + 1])
+        loc = pcr.Dataset.from_csr(u1 - u0, R.d2, idx[u0:u1 + 1] - idx[u0], item[idx[u0]:idx[u1]], val[idx[u0]:idx[u1]],
+                                   tidx[u0:u1 + 1] - tidx[u0], titem[tidx[u0]:tidx[u1]], tval[tidx[u0]:tidx[u1]])
+        t = pcr.Solver(loc, pcr.Parameter(**par), rank=q, nranks=nranks, shard=(u0, R.d1))
+        assert (t.first_user, t.n_users, t.nnz_local, t.d1) == (u0, u1 - u0, s.nnz_local, R.d1)
+        t.set_local_only(True)
+        t.set_factors_local(U0[u0:u1], V0)
+        assert np.array_equal(t.comp_m(), m_parts[q])
+        s.set_factors(U0, V0); s.comp_m()
+        assert t.objective() == s.objective()
+        assert np.array_equal(t.obtain_g(), s.obtain_g())
+        t.update_U(); s.update_U()
+        assert np.array_equal(t.get_factors_local()[0], s.get_factors()[0][u0:u1])
+        assert t.evaluate(1, 10) == s.evaluate(1, 10)
+        t.close()
+    with pytest.raises(pcr.PcrError):
+        pcr.Solver(ds, pcr.Parameter(**par), rank=0, nranks=2, shard=(10, R.d1))      # the shard does not fit the job's user range
 
 
 def test_fp32_training_matches_reference_quality(oracle):
@@ -271,6 +292,8 @@ VARIANTS = [
     {"window_cache": "0"}, {"prepare_merged": "0"}, {"ustep_seq": "1"}, {"pipeline": "0"},   # searching sweeps, per-class prepare, serial classes
     {"sddmm_csc": "1"}, {"sddmm_csc": "1", "spmm_tiles": "16"},   # the CG's SDDMM over the tile-major CSC (wide item tables)
     {"allreduce_chunks": "3"}, {"allreduce_chunks": "5", "spmm_tiles": "16"}, {"allreduce_chunks": "4", "sddmm_csc": "1"},   # SpMM item range by item range (the N > 1 overlap form)
+    {"allreduce_chunks": "3", "spmm_tiles": "8"},            # ... with exactly one tile per XCD (the tile <-> XCD affinity inside every range's plan)
+    {"cluster_fence": "0"},                                  # cluster hand-off without the agent-scope release / acquire
 ]
 
 
