@@ -72,6 +72,19 @@ def gather_level(table_bytes):
     return "hbm-gather"
 
 
+def gather_ceiling(table_bytes):
+    """(level, ceiling GB/s, L2 share) for uniformly random row gathers from a table of that size.  MI355X_MICROARCH.md,
+    Indexed rows: "an XCD's 4 MiB L2 holds 4 MiB / T of a uniformly gathered table of T bytes; the time scales with the reads
+    that go beyond L2" -- so a table a little larger than one L2 (the Netflix shape's 7.1 MB) is served partly at the L2 rate
+    and partly at the next level's: ceiling = 1 / (h / L2 rate + (1 - h) / next level's rate), h = min(1, 4 MiB / T)."""
+    lv = gather_level(table_bytes)
+    h = min(1.0, (4 << 20) / max(table_bytes, 1))
+    if lv == "l2-gather":
+        return lv, GATHER_CEILING_GBS[lv], 1.0
+    c = 1.0 / (h / GATHER_CEILING_GBS["l2-gather"] + (1.0 - h) / GATHER_CEILING_GBS[lv])
+    return lv, round(c, 1), round(h, 3)
+
+
 def algorithmic_bytes(slot, nnz_b, nu_b, d2, r, esz):
     """Compulsory HBM bytes of ONE launch of a per-user kernel over a length bin holding nnz_b
     ratings of nu_b users (ideal caching: every operand crosses HBM once).  DESIGN.md section 3.5."""
@@ -313,8 +326,12 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False):
     # item table V (d2 x ld x esz); k_spmm (and k_sddmm in its tile-major form, item tables beyond the L2s) gathers rows of U
     # from a user tile cut to fit one XCD's L2 (<= 1.25 MB)
     v_table = d2 * ld * esz
-    lvl_v = gather_level(v_table)
-    lvl_slot = lambda cls: "l2-gather" if cls == "spmm" or (cls == "sddmm" and v_table > (32 << 20)) else lvl_v
+    lvl_v, ceil_v, l2share_v = gather_ceiling(v_table)
+    tiled = lambda cls: cls == "spmm" or (cls == "sddmm" and v_table > (32 << 20))         # gathers from an L2-sized user tile
+
+    def binding(cls, gb):
+        lv, ce, h = ("l2-gather", GATHER_CEILING_GBS["l2-gather"], 1.0) if tiled(cls) else (lvl_v, ceil_v, l2share_v)
+        return {"level": lv, "l2_share": h, "ceiling_GBs": ce, "achieved_GBs": round(gb, 1), "frac": round(gb / ce, 4)}
     u_rows = (rows_run or {}).get("u_rows", 0)
     rows_by_class = (rows_run or {}).get("rows_by_class", {})
     roof, roof_phase, kernels = None, {}, {}
@@ -355,10 +372,7 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False):
                              "frac_hbm_peak": round(ab / avg_s / 1e9 / HBM_PEAK_GBS, 5), "traffic_bytes": tr,
                              "traffic_over_algorithmic": round(tr / ab, 2) if tr else None}
             if g_rows:
-                lv = lvl_slot(cls)
-                gb = g_rows * r * esz / avg_s / 1e9
-                kernels[name]["binding"] = {"level": lv, "gathered_row_bytes": int(g_rows * r * esz), "achieved_GBs": round(gb, 1),
-                                            "ceiling_GBs": GATHER_CEILING_GBS[lv], "frac": round(gb / GATHER_CEILING_GBS[lv], 4)}
+                kernels[name]["binding"] = dict(binding(cls, g_rows * r * esz / avg_s / 1e9), gathered_row_bytes=int(g_rows * r * esz))
         if verbose:
             for k, (ms, n) in sorted(prof.items(), key=lambda kv: -est[kv[0]]):
                 extra = f"  alg {kernels[k]['achieved_GBs']:8.1f} GB/s  gpu-time share {100 * kernels[k]['gpu_time_share']:5.1f} %" if k in kernels else ""
@@ -383,21 +397,19 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False):
                         "slots in 'kernels', phases in 'roofline_phase' (DESIGN.md 3.5, 4)"}
 
         # phases: algorithmic bytes of everything a phase launches per step / its wall time per step
-        def phase(names, wall_ms_per_step, gather_bytes, level):
+        def phase(names, wall_ms_per_step, gather_bytes, cls):
             ab = sum(kernels[k]["algorithmic_bytes"] * run["launches"][k] / steps for k in names)
             gb = gather_bytes / (wall_ms_per_step / 1e3) / 1e9
             return {"bound": "hbm", "algorithmic_bytes_per_step": int(ab), "wall_us_per_step": round(1e3 * wall_ms_per_step, 1),
                     "achieved": round(ab / (wall_ms_per_step / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ab / (wall_ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
                     "share_of_step": round(wall_ms_per_step / (1e3 * secs / steps), 4),
-                    "gathered_row_bytes_per_step": int(gather_bytes), "gather_GBs": round(gb, 1),
-                    "binding": {"level": level, "ceiling_GBs": GATHER_CEILING_GBS[level], "achieved_GBs": round(gb, 1),
-                                "frac": round(gb / GATHER_CEILING_GBS[level], 4)}}
+                    "gathered_row_bytes_per_step": int(gather_bytes), "gather_GBs": round(gb, 1), "binding": binding(cls, gb)}
         un = [k for k in kernels if k.startswith("ustep/")]
         if un and prof.get("wall:ustep", (0, 0))[1]:
             wm, wn = prof["wall:ustep"]
             u_gather = u_rows / steps / N * r * esz           # this rank's share (the counter is the all-rank total)
-            roof_phase["u_step"] = dict(phase(un, wm / wn, u_gather, lvl_v), kernels=un,
+            roof_phase["u_step"] = dict(phase(un, wm / wn, u_gather, "ustep"), kernels=un,
                                         note="all length classes of k_ustep, launched side by side: sum of their algorithmic bytes / fork..join wall "
                                              "time on the solver's stream; gather_GBs = rows of V actually gathered (counted in the kernel: per user "
                                              "1 + 2 per CG iteration + 1 per line-search try, x its ratings) x row bytes / that wall time, against "
@@ -407,7 +419,7 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False):
             u_wall = roof_phase.get("u_step", {}).get("wall_us_per_step", 0.0) / 1e3
             v_ms = 1e3 * secs / steps - u_wall               # the two half steps alternate on one stream: the rest of a step is the V step
             v_gather = (inner["ls_v"] / steps + 2 * (inner["cg_v"] / steps) + 1) * esz * r * nnz_loc
-            roof_phase["v_step"] = dict(phase(vn, v_ms, v_gather, "l2-gather" if v_table > (32 << 20) else lvl_v), kernels=vn,
+            roof_phase["v_step"] = dict(phase(vn, v_ms, v_gather, "sddmm"), kernels=vn,
                                         note="gradient + CG (SDDMM, sweep, SpMM, finish, vector update) + line search, back to back on the "
                                              "solver's stream: step time minus the U step's wall time; gather_GBs = (1 SpMM + n_cg x (SDDMM + "
                                              "SpMM) + n_ls SDDMM) x ratings x row bytes / that time (the SpMM's user tiles are cut to one "
@@ -436,8 +448,8 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False):
     gg = gather_passes * G / (secs / steps) / 1e9
     gather = {"bytes_per_half_pass": int(G), "half_passes_per_iteration": round(gather_passes, 2),
               "u_side_half_passes": round(u_half_passes, 2), "u_side_user_average": round(1 + 2 * n_cg_u + n_ls_u, 2),
-              "achieved_GBs": round(gg, 1), "item_table_bytes": int(v_table), "level": lvl_v,
-              "ceiling_GBs": GATHER_CEILING_GBS[lvl_v] * N, "frac": round(gg / (GATHER_CEILING_GBS[lvl_v] * N), 4),
+              "achieved_GBs": round(gg, 1), "item_table_bytes": int(v_table), "level": lvl_v, "l2_share": l2share_v,
+              "ceiling_GBs": ceil_v * N, "frac": round(gg / (ceil_v * N), 4),
               "note": "row gathers (one esz*r-byte factor row per rating and half-pass) sustained over the WHOLE iteration, all "
                       "ranks, against the ceiling of the level the item table of this shape lives in (U side: rows counted by the "
                       "kernel -- long users run more CG iterations than the user average, so the rating-weighted pass count is the "
@@ -473,9 +485,11 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
         runs[pn] = timed_run(job, ds, shard, R.d2, r, lam, prec, steps, warmup, profile, shm)
         # diagnostic replay of the same iterations with the U-step kernels counting the rows of V they gather (an extra atomic
         # per user, so it is kept out of the timed run): the rating-weighted pass count of the U step, per length class
-        rr = timed_run(job, ds, shard, R.d2, r, lam, prec, steps, warmup, False, shm, count_rows=True)
-        runs[pn]["rows"] = dict(u_rows=rr["u_rows"], rows_by_class=rr["rows_by_class"],
-                                launches_counted={k: (warmup + steps) for k in rr["rows_by_class"]})
+        runs[pn]["rows"] = None
+        if not args.no_rows:
+            rr = timed_run(job, ds, shard, R.d2, r, lam, prec, steps, warmup, False, shm, count_rows=True)
+            runs[pn]["rows"] = dict(u_rows=rr["u_rows"], rows_by_class=rr["rows_by_class"],
+                                    launches_counted={k: (warmup + steps) for k in rr["rows_by_class"]})
     bounds = None
     if N > 1:
         import torch
@@ -571,6 +585,7 @@ def main():
     ap.add_argument("--no-f64", action="store_true", help="skip the second timed run in the reference's arithmetic type")
     ap.add_argument("--no-netflix", action="store_true", help="skip the Netflix-shaped sub-record of the default N = 1 run")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-rows", action="store_true", help="skip the diagnostic replay that counts the rows the U step gathers (profiler passes)")
     ap.add_argument("--profile-period", type=int, default=0,
                     help="event-time every n-th launch of each kernel (the first one included); 0 = as sparse as leaves a dozen "
                          "samples of the most frequent kernel (11 launches per step): min(16, 11 * steps / 12)")

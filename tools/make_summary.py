@@ -1,48 +1,50 @@
 #!/usr/bin/env python3
-"""Dev tool: profiles/<tag>_* from gpurun_out/<tag>/ (tools/collect_profiles.sh): copies the small artefacts and writes
-profiles/<tag>_summary.md.   make_summary.py <tag> "<title line>" """
+"""Dev tool: gpurun_out/<tag>/<shape>_<prec>/ (tools/collect_profiles.sh) -> profiles/<tag>_<shape>_<prec>_kernel_stats.csv,
+profiles/<tag>_<shape>_<prec>_counters.md, and the PMC traffic figures bench.py reads, merged into profiles/r03_traffic.json
+under the key "<shape>:<prec>".      make_summary.py <tag> <shape> <prec> "<source note>"
+Units per MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half
+their bytes (doubled in the traffic column); SQ_* cycle counters are quad-cycles summed over waves."""
 import csv, json, os, shutil, sys
-tag, title = sys.argv[1], sys.argv[2]
-src, dst = f"gpurun_out/{tag}", "profiles"
-for a, b in [("kernel_stats.csv", f"{tag}_kernel_stats.csv"), ("pmc_traffic_table.txt", f"{tag}_pmc_traffic_table.txt"),
-             ("bench.json", f"{tag}_bench.json"), ("bench_noprofile.json", f"{tag}_bench_noprofile.json"), ("traffic.json", "r02_traffic.json")]:
-    shutil.copy(os.path.join(src, a), os.path.join(dst, b))
-b = json.loads(open(f"{src}/bench.json").read().strip().split("\n")[-1])
-bn = json.loads(open(f"{src}/bench_noprofile.json").read().strip().split("\n")[-1])
-cpu = b.get("cpu_baseline") or {}
-out = [f"# {title}", "",
-       "Commands (GPU box, 1x MI355X, ml1m-shaped synthetic, PrimalCR++ k=100 lambda=5000, fp32 storage / fp64 accumulation; `tools/collect_profiles.sh`):", "",
-       f"* `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu` -> `{tag}_kernel_stats.csv`",
-       f"* `rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --no-cpu --no-profile --steps 10` and the same with `--pmc WRITE_SIZE` (separate passes) -> `r02_traffic.json`, `{tag}_pmc_traffic_table.txt` (tools/pmc_traffic.py; counters in KiB, FETCH_SIZE also given x2 per MI355X_MICROARCH.md)",
-       f"* `python3 bench.py --verbose` -> `{tag}_bench.json`; `python3 bench.py --no-profile --no-cpu` -> `{tag}_bench_noprofile.json`", "",
-       f"bench: {b['ms_per_step']:.2f} ms per outer iteration with sampled event timing ({bn['ms_per_step']:.2f} ms without = {bn['value']:.3e} pairs/s), "
-       f"test NDCG@10 {b['ndcg10_test']:.4f}, pairwise error {b['pairwise_error_test']:.4f}; "
-       + (f"reference OpenMP -n {cpu.get('cores')}: {cpu.get('s_per_iter', 0):.2f} s per iteration ({b.get('speedup_vs_cpu_baseline', 0):.0f}x)." if cpu else ""), "",
-       (f"fp64 storage (the reference's arithmetic type), same run: {b['f64']['ms_per_step']:.2f} ms per outer iteration, test NDCG@10 {b['f64']['ndcg10_test']:.4f}. " if b.get("f64") else "")
-       + (f"reference -n 1: {cpu['single_thread']['s_per_iter']:.2f} s per iteration." if cpu.get("single_thread") else ""), "",
-       "roofline (dominant kernel = most GPU time): " + json.dumps(b["roofline"]), "",
-       "roofline_phase: " + json.dumps(b.get("roofline_phase")), "",
-       "| kernel (rocprofv3 --kernel-trace --stats) | calls | total us | avg us | % |", "|---|---|---|---|---|"]
-rows = list(csv.DictReader(open(f"{src}/kernel_stats.csv")))
-for r in rows[:28]:
-    out.append(f"| `{r['Name'][:64]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
-out += ["", "HIP-event averages from the same build inside bench.py (sampled launches timed, see the roofline note; share = share of the summed GPU time, concurrent length classes not discounted):", "",
-        "| slot | avg us | launches | GPU-time share | algorithmic MB | algorithmic GB/s | frac of 8 TB/s | PMC bytes/launch (2 x FETCH + WRITE) |", "|---|---|---|---|---|---|---|---|"]
-for k, v in sorted(b["kernels"].items(), key=lambda kv: -kv[1]["gpu_time_share"]):
-    out.append(f"| {k} | {v['avg_us']} | {v['launches']} | {v['gpu_time_share']} | {v['algorithmic_bytes']/1e6:.2f} | {v['achieved_GBs']} | {v['frac_hbm_peak']} | {v['traffic_bytes']} |")
-occ = os.path.join(src, "pmc_occupancy_table.txt")
-if os.path.exists(occ):
-    shutil.copy(occ, os.path.join(dst, f"{tag}_pmc_occupancy_table.txt"))
-    out += ["", "Achieved occupancy (`rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`, its own pass; PMC runs "
-            "serialise the kernels, so the concurrent U-step classes are shown alone):", "", open(occ).read().rstrip()]
-mix = os.path.join(src, "pmc_mix_table.txt")
-if os.path.exists(mix):
-    shutil.copy(mix, os.path.join(dst, f"{tag}_pmc_mix_table.txt"))
-    out += ["", "Where the wave cycles go (`rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY "
-            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD`, its own pass): every kernel waits on memory for 43-87 % of its wave cycles",
-            "", open(mix).read().rstrip()]
-extra = f"{dst}/{tag}_extra.md"          # hand-written notes on runs outside bench.py (kept across regenerations)
-if os.path.exists(extra):
-    out += ["", open(extra).read().rstrip()]
-open(f"{dst}/{tag}_summary.md", "w").write("\n".join(out) + "\n")
-print("\n".join(out[:12]))
+tag, shape, prec, note = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else ""
+src, dst = f"gpurun_out/{tag}/{shape}_{prec}", "profiles"
+base = f"{dst}/{tag}_{shape}_{prec}"
+load = lambda n: json.load(open(f"{src}/pmc_{n}.json")) if os.path.exists(f"{src}/pmc_{n}.json") else {}
+fe, wr, l2, lds, occ, mix = (load(n) for n in ("fetch", "write", "l2", "lds", "occ", "mix"))
+out = [f"# {tag} / {shape} / {prec}: rocprofv3 counters per kernel ({note})", "",
+       f"Command of every pass: `rocprofv3 --pmc <counters> -- python3 bench.py --shape {shape} --precision {prec} --no-cpu --no-f64 --no-netflix --no-rows --no-profile [...]` "
+       "(one pass per counter group; `--kernel-trace --stats` in a pass of its own -> the kernel_stats.csv beside this file). "
+       "PMC passes serialise the kernels: concurrent U-step classes are seen alone.", ""]
+if os.path.exists(f"{src}/kernel_stats.csv"):
+    shutil.copy(f"{src}/kernel_stats.csv", base + "_kernel_stats.csv")
+    out += ["| kernel (rocprofv3 --kernel-trace --stats) | calls | total us | avg us | % |", "|---|---|---|---|---|"]
+    for r in list(csv.DictReader(open(f"{src}/kernel_stats.csv")))[:24]:
+        out.append(f"| `{r['Name'][:78]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
+    out.append("")
+names = sorted(set(fe) | set(wr) | set(l2) | set(lds), key=lambda k: -(fe.get(k, {}).get("FETCH_SIZE", 0) + wr.get(k, {}).get("WRITE_SIZE", 0)))
+traffic = {}
+out += ["| kernel | launches | FETCH raw MB/launch | WRITE MB/launch | traffic = 2 x FETCH + WRITE MB/launch | L2 hit rate (TCC_HIT / (HIT + MISS)) | LDS bank-conflict cycles / LDS active cycles | LDS instructions per wave-kcycle |",
+        "|---|---|---|---|---|---|---|---|"]
+for k in names:
+    if k.startswith("__amd") or k.startswith("k_spin") or k.startswith("k_nop"):
+        continue
+    f, w = fe.get(k, {}), wr.get(k, {})
+    n = max(f.get("launches", 0), w.get("launches", 0), 1)
+    fb = 1024 * f.get("FETCH_SIZE", 0) / max(f.get("launches", 1), 1); wb = 1024 * w.get("WRITE_SIZE", 0) / max(w.get("launches", 1), 1)
+    if f or w:
+        traffic[k] = {"launches": int(n), "fetch_bytes_per_launch_raw": fb, "write_bytes_per_launch": wb}
+    h = l2.get(k, {}); hit = h.get("TCC_HIT_sum", 0); miss = h.get("TCC_MISS_sum", 0)
+    ld = lds.get(k, {}); bc = ld.get("SQ_LDS_BANK_CONFLICT", 0); act = ld.get("SQ_LDS_IDX_ACTIVE", 0); wc = ld.get("SQ_WAVE_CYCLES", 0)
+    out.append(f"| `{k[:78]}` | {int(n)} | {fb/1e6:.2f} | {wb/1e6:.2f} | {(2*fb+wb)/1e6:.2f} | "
+               + (f"{100*hit/(hit+miss):.1f} %" if hit + miss else "-") + " | "
+               + (f"{100*bc/act:.1f} %" if act else "-") + " | " + (f"{1000*ld.get('SQ_INSTS_LDS', 0)/(4*wc):.1f}" if wc else "-") + " |")
+open(base + "_counters.md", "w").write("\n".join(out) + "\n")
+tpath = f"{dst}/r03_traffic.json"
+tj = json.load(open(tpath)) if os.path.exists(tpath) else {"workloads": {}}
+tj["workloads"][f"{shape}:{prec}"] = {"source": f"profiles/r03_traffic.json [{shape}:{prec}] ({tag}, {note})", "kernels": traffic}
+json.dump(tj, open(tpath, "w"), indent=0)
+for tbl, title in (("pmc_occupancy_table.txt", "Achieved occupancy (SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE, its own pass)"),
+                   ("pmc_mix_table.txt", "Where the wave cycles go (SQ_WAVE_CYCLES SQ_ACTIVE_INST_* SQ_WAIT_* SQ_INSTS_*, its own pass)")):
+    if os.path.exists(f"{src}/{tbl}"):
+        with open(base + "_counters.md", "a") as fo:
+            fo.write(f"\n{title}:\n\n" + open(f"{src}/{tbl}").read().rstrip() + "\n")
+print("\n".join(out[:40]))
