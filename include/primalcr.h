@@ -143,21 +143,27 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
 /* ------------------------------------------------------------------------- */
 
 /* Launch knobs.  The reference has none (its only scheduling choice is `#pragma omp ... schedule(dynamic,500)`,
- * pcrpp.cpp:825); the device solver chooses its launch configuration from the shape of the shard, and these process-wide
+ * pcrpp.cpp:825); the device solver chooses its launch configuration from the shape of the shard, and these
  * key/value pairs override single choices -- for the parity tests (every configuration must give the same trajectory)
- * and for A/B measurements.  Read once by pcr_solver_create; value NULL removes a key; unknown keys are PCR_ERR_ARG.
- * No environment variable is read anywhere on the product path.
+ * and for A/B measurements.  The table belongs to the CALLING THREAD: pcr_solver_create snapshots the creating thread's
+ * pairs into the solver (nothing is read later, nothing is shared between threads, so solver handles stay re-entrant);
+ * value NULL removes a key; unknown keys are PCR_ERR_ARG.
+ * No environment variable is read anywhere on the product path.  (The ROCm runtime has one prerequisite of its own for
+ * pcr_solver_comm_init_p2p / RCCL across processes on hosts whose driver only supports dmabuf IPC:
+ * HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment of every rank.)
  *   ustep_mode      1 = latency form of k_ustep for every long class, 2 = throughput form (default: by user count)
  *   ustep_many      user count above which a long class counts as throughput-bound (default CUs/4)
  *   allreduce_chunks N = item ranges of the SpMM whose all-reduces overlap the next range's SpMM (default 1: one all-reduce per
  *                   vector on the solver's stream; opt-in, meant for vectors of 16 MB and more -- about one range per 4 MB)
+ *   resort_window   half-width D of the nearly-sorted fast path of the per-user sorts (k_prepare, k_ustep's line search): a user
+ *                   whose ratings moved by at most D positions since the previous sorted state is re-sorted by windowed rank
+ *                   counting (verified; else the full bitonic network); default 8, 0 = always the full network, at most 64
  *   cluster_fence   0 = the hand-off between the workgroups of a cluster without the agent-scope release / acquire (its payload
  *                   is sc1 both ways; measured valid on gfx950, not an architectural guarantee; default 1: fenced)
  *   ustep_small_unr 8 = eight rows in flight per lane group in the one-wave and 256-thread classes of k_ustep (default 4)
  *   ustep_ls_recur  0 = k_ustep's first line-search try gathers the rows for its scores (default 1: m - s sum alpha_k b_k from the
  *                   CG's own b_k = V_I p_k, no pass)
  *   ustep_seq       1 = the U step's length classes back to back on one stream
- *   ustep_lockstep  1 = U step as rating-parallel lock-step passes over all users (default 0: per-user kernels)
  *   ustep_gram      dual (Gram-matrix on MFMA) U step for users with at most that many ratings (<= 128; default 0 = off)
  *   cluster_k       4 (default) or 1: workgroups per clustered long user;  cluster_users: how many users get clusters
  *   ubins           "cap:block:resident,..." length classes of the U step below 1024 ratings

@@ -180,26 +180,23 @@ extern "C" int pcr_dataset_from_csr(int64_t d1, int64_t d2, const int64_t* index
 }
 
 // ------------------------------------------------------------------------------------------
-// launch knobs (pcr_tune): a process-wide key/value table the solver consults when it is created
+// launch knobs (pcr_tune): a key/value table PER CALLING THREAD, which pcr_solver_create (on that thread) snapshots into the
+// solver -- no process-global mutable state: two threads that create solvers with different knobs do not see each other's
 // ------------------------------------------------------------------------------------------
 #include <map>
-#include <mutex>
-static std::mutex g_tune_mu;
-static std::map<std::string, std::string>& tune_table() { static std::map<std::string, std::string> t; return t; }
+static std::map<std::string, std::string>& tune_table() { static thread_local std::map<std::string, std::string> t; return t; }
 static const char* const TUNE_KEYS[] = {"ustep_mode", "ustep_many", "cluster_k", "cluster_users", "ubins", "spmm_tiles", "spmm_chunk", "sddmm_tile",
                                         "sddmm_csc", "lanes", "window_cache", "prepare_merged", "sweep_wave_cap", "eval_brute", "pipeline",
-                                        "ustep_seq", "ustep_lockstep", "ustep_gram", "count_rows", "wide_teams", "ustep_win_lds", "win16", "sweep_prefetch", "ustep_small_unr", "ustep_ls_recur", "allreduce_chunks", "cluster_fence", "debug", "fault_cluster_member", nullptr};
+                                        "ustep_seq", "ustep_gram", "count_rows", "wide_teams", "ustep_win_lds", "win16", "sweep_prefetch", "ustep_small_unr", "ustep_ls_recur", "allreduce_chunks", "cluster_fence", "resort_window", "debug", "fault_cluster_member", nullptr};
 extern "C" int pcr_tune(const char* key, const char* value) {
     if (!key) { pcr_set_error("pcr_tune: null key"); return PCR_ERR_ARG; }
     bool known = false;
     for (const char* const* k = TUNE_KEYS; *k; ++k) known = known || !strcmp(*k, key);
     if (!known) { pcr_set_error(std::string("pcr_tune: unknown key '") + key + "'"); return PCR_ERR_ARG; }
-    std::lock_guard<std::mutex> lk(g_tune_mu);
     if (value) tune_table()[key] = value; else tune_table().erase(key);
     return PCR_OK;
 }
 bool pcr_tune_get(const char* key, std::string* out) {
-    std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = tune_table().find(key);
     if (it == tune_table().end()) return false;
     if (out) *out = it->second;

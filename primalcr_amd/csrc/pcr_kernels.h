@@ -75,6 +75,9 @@ struct Shard {
     // else 32 -- half the bytes of what is the largest per-rating array of the state (4 slots x 5 levels).
     void* win;                 // nnz * ws entries of uint16_t (w16) or uint32_t
     int ws, w16;
+    // nearly-sorted fast path of the sorts (resort_window): half-width of the window a rating may have moved by (0 = always
+    // the full bitonic network); prev_valid: sidx / slvl hold a valid permutation of every user (any earlier sorted state)
+    int resort_d, prev_valid;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -251,6 +254,84 @@ __device__ __forceinline__ void bitonic_sort(T* key, LI* li, int npad) {
             if (INLDS && !last && j <= 64 && jnext <= 64) wave_sync(); else bsync<BLOCK>();
         }
     }
+}
+
+// Nearly-sorted fast path.  From the third outer iteration on, a user's (level, m) order barely moves between two sorted
+// states (tools/exp_resort.py, ml1m shape: the largest displacement of any rating of a user is <= 8 positions for 70 % of the
+// rating mass at iteration 5, 90 % at 14, 98 % at 25 -- while the full bitonic network costs 45-78 stages of LDS round trip +
+// ordering point whatever the input).  key[0, n) / li[0, n) hold the NEW scores in the PREVIOUS order (levels are static, so
+// every level is already one contiguous run): the new rank of position p follows from the inversions inside a window of +-D
+// positions of its run,   rank = p - #{q in [p - D, p): key_q > key_p} + #{q in (p, p + D]: key_q < key_p}   (stable),
+// a scatter of p to tmp[rank], and a gather through a second array: 2 D + 14 LDS operations per rating and 7 ordering points.
+// The windowed count is exact only if nothing moved further than D; that is VERIFIED, not assumed: the result is accepted
+// only if every slot of tmp was filled (n writes into n slots: a bijection) and the permuted keys ascend inside every run --
+// then it IS a (level, m)-sorted order, and any such order gives the same sums (tie order is irrelevant, see bitonic_sort).
+// Otherwise key / li are untouched and the caller runs the bitonic network.  tmp: n ints, key2: n T's (both LDS, distinct from
+// key / li; key2 == nullptr: no room, no fast path).  No per-thread arrays: the kernels around it are register-bound.
+#ifdef PCR_RESORT_STAT
+__device__ unsigned long long g_resort_stat[4];      // users (fast path taken, fallen back), their ratings
+#endif
+template <typename T, typename LI, int BLOCK, class LevF>
+__device__ __forceinline__ bool resort_window_d(T* key, LI* li, LevF levf, const int* rs, int n, int* tmp, T* key2, int D, int* flag) {
+    static_assert(sizeof(LI) <= sizeof(T) || sizeof(LI) == 4, "li is permuted through key2's bytes");
+    const int tid = btid<BLOCK>();
+#pragma unroll 1
+    for (int p = tid; p < n; p += BLOCK) tmp[p] = -1;
+    if (BLOCK > PCR_WAVE && tid == 0) *flag = 0;               // (flag: one LDS word for the team's verdict; __syncthreads_or would
+    bsync<BLOCK>();                                             // add static LDS to kernels that ask for all 160 KB dynamically)
+#pragma unroll 1
+    for (int p = tid; p < n; p += BLOCK) {
+        const int lev = levf(p);
+        const int lo = max(rs[lev], p - D), hi = min(rs[lev + 1], p + D + 1);
+        const T kp = key[p];
+        int r = p;
+#pragma unroll 2
+        for (int q = lo; q < p; ++q) r -= (key[q] > kp) ? 1 : 0;
+#pragma unroll 2
+        for (int q = p + 1; q < hi; ++q) r += (key[q] < kp) ? 1 : 0;
+        tmp[r] = p;
+    }
+    bsync<BLOCK>();
+    int bad = 0;
+#pragma unroll 1
+    for (int p = tid; p < n; p += BLOCK) {
+        const int src = tmp[p];
+        bad |= (src < 0) ? 1 : 0;
+        key2[p] = key[src < 0 ? 0 : src];
+    }
+    bsync<BLOCK>();
+#pragma unroll 1
+    for (int p = tid; p < n; p += BLOCK)
+        if (p + 1 < rs[levf(p) + 1]) bad |= (key2[p + 1] < key2[p]) ? 1 : 0;          // the next position belongs to the same run
+    if (BLOCK == PCR_WAVE) bad = __any(bad);
+    else { if (bad) *flag = 1; __syncthreads(); bad = *flag; }
+#ifdef PCR_RESORT_STAT
+    if (tid == 0) { atomicAdd(&g_resort_stat[bad ? 1 : 0], 1ull); atomicAdd(&g_resort_stat[bad ? 3 : 2], (unsigned long long)n); }
+#endif
+    if (bad) return false;
+#pragma unroll 1
+    for (int p = tid; p < n; p += BLOCK) key[p] = key2[p];
+    bsync<BLOCK>();
+    LI* li2 = reinterpret_cast<LI*>(key2);
+#pragma unroll 1
+    for (int p = tid; p < n; p += BLOCK) li2[p] = li[tmp[p]];
+    bsync<BLOCK>();
+#pragma unroll 1
+    for (int p = tid; p < n; p += BLOCK) li[p] = li2[p];
+    bsync<BLOCK>();
+    return true;
+}
+
+// two tiers: a narrow window first (most users, most iterations), four times as wide for the users that fail it; then the network
+template <typename T, typename LI, int BLOCK, class LevF>
+__device__ __forceinline__ bool resort_window(T* key, LI* li, LevF levf, const int* rs, int n, int* tmp, T* key2, int D, int* flag) {
+    if (D <= 0 || !key2) return false;
+#pragma unroll 1
+    for (int tier = 0; tier < 2; ++tier) {                     // (one copy of the body: the kernels around it are register-bound)
+        if (tier) { bsync<BLOCK>(); D *= 4; if (D >= n) break; }   // (the verdict word and tmp are reused)
+        if (resort_window_d<T, LI, BLOCK>(key, li, levf, rs, n, tmp, key2, D, flag)) return true;
+    }
+    return false;
 }
 
 // first index in [s,e) with a[q] > x   (= s + #{a[q] <= x})
@@ -674,7 +755,7 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(const T* __restrict__ U, const 
                                                  const int32_t* __restrict__ ruser, const int32_t* __restrict__ rows,
                                                  int64_t nnz, T* __restrict__ out, Geo geo, int tile, const int* skip,
                                                  const int32_t* __restrict__ perm, const int2* __restrict__ blk_map,
-                                                 const int32_t* __restrict__ chunk_ptr, const uint8_t* __restrict__ only = nullptr) {
+                                                 const int32_t* __restrict__ chunk_ptr) {
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -698,13 +779,7 @@ __global__ __launch_bounds__(BLOCK) void k_sddmm(const T* __restrict__ U, const 
     for (int t = threadIdx.x; t < nb; t += BLOCK) { s_row[t] = rows[b0 + t]; s_usr[t] = ruser[b0 + t]; }
     __syncthreads();
     const int l0 = grp * tile;
-    int l1 = (l0 + tile < nb) ? l0 + tile : nb;
-    if (only) {     // lock-step U step: `only[user]` = the user still takes part; a lane group none of whose ratings do skips its tile
-        int any = 0;
-        for (int q = l0 + g; q < l1; q += G) any |= (int)only[s_usr[q]];
-        for (int off = G >> 1; off > 0; off >>= 1) any |= __shfl_xor(any, off);
-        if (!any) l1 = l0;
-    }
+    const int l1 = (l0 + tile < nb) ? l0 + tile : nb;
     const int rho = 4 * (g & 1) + (g & 2) + ((g >> 2) & 1);
     for (int k = 0; k * G < geo.nchunk; ++k) {
         const int ch = g + k * G;
@@ -806,7 +881,7 @@ __device__ unsigned long long g_prep_prof[4 * 8];
 template <typename T, int BLOCK, bool BIG>
 __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, const int32_t* __restrict__ users, int nusers,
                                              const T* __restrict__ m_in, int cap, int cap_pad, int rs_cap, char* scratch,
-                                             size_t stride, int strict, int first, int step, const uint8_t* __restrict__ only = nullptr) {
+                                             size_t stride, int strict, int first, int step) {
     typedef typename LiSel<T, BIG>::type LI;
     Carver small(smem);
     double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
@@ -822,7 +897,6 @@ __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, cons
 
     for (int ui = first; ui < nusers; ui += step) {
         const int u = users[ui];
-        if (only && !only[u]) continue;                       // lock-step U step: users whose line search is over keep their state
         const int64_t s0 = S.uptr[u];
         const int n = (int)(S.uptr[u + 1] - s0);
         const int nlev = (int)(S.runofs[u + 1] - S.runofs[u]) - 1;
@@ -832,14 +906,25 @@ __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, cons
         }
         for (int l = tid; l <= nlev; l += BLOCK) rs[l] = S.runstart[S.runofs[u] + l];
         const int npad = next_pow2(n);
+        // start from the user's PREVIOUS order when there is one (any earlier sorted state: levels are static, so it is level-
+        // grouped already, and from the third iteration on nearly (level, m)-sorted for the new scores too: resort_window)
+        const bool from_prev = !BIG && S.resort_d > 0 && S.prev_valid;
 #pragma unroll 4
         for (int p = tid; p < npad; p += BLOCK) {
-            if (p < n) { li[p] = LiOps<LI>::pack(S.lvl[s0 + p], (unsigned)p); key[p] = m_in[s0 + p]; }
-            else { li[p] = LiOps<LI>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
+            if (p < n) {
+                if (from_prev) { const unsigned idx = (unsigned)S.sidx[s0 + p]; li[p] = LiOps<LI>::pack(S.slvl[s0 + p], idx); key[p] = m_in[s0 + idx]; }
+                else { li[p] = LiOps<LI>::pack(S.lvl[s0 + p], (unsigned)p); key[p] = m_in[s0 + p]; }
+            } else { li[p] = LiOps<LI>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
         }
         bsync<BLOCK>();
         PPROF(0);
-        bitonic_sort<T, LI, BLOCK, false, !BIG>(key, li, npad);
+        // (tmp and the second key array share the prefix-sum array, idle until the loss: 4-byte scores only -- fp64 sorts fully)
+        bool resorted = false;
+        if constexpr (!BIG)
+            if (from_prev)
+                resorted = resort_window<T, LI, BLOCK>(key, li, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, n, reinterpret_cast<int*>(Sx),
+                                                       sizeof(T) == 4 ? reinterpret_cast<T*>(reinterpret_cast<int*>(Sx) + n) : (T*)nullptr, S.resort_d, reinterpret_cast<int*>(red));
+        if (!resorted) bitonic_sort<T, LI, BLOCK, false, !BIG>(key, li, npad);
         PPROF(1);
         for (int p = tid; p < n; p += BLOCK) {
             const LI x = li[p];
@@ -876,10 +961,9 @@ __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, cons
 template <typename T, int BLOCK, bool BIG>
 __global__ __launch_bounds__(BLOCK) void k_prepare(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                    const T* __restrict__ m_in,
-                                                   int cap, int cap_pad, int rs_cap, char* scratch, size_t stride, int strict,
-                                                   const uint8_t* __restrict__ only) {
+                                                   int cap, int cap_pad, int rs_cap, char* scratch, size_t stride, int strict) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    prepare_body<T, BLOCK, BIG>(smem, S, users, nusers, m_in, cap, cap_pad, rs_cap, scratch, stride, strict, (int)blockIdx.x, (int)gridDim.x, only);
+    prepare_body<T, BLOCK, BIG>(smem, S, users, nusers, m_in, cap, cap_pad, rs_cap, scratch, stride, strict, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Both LDS-resident classes in ONE launch of 512-thread workgroups: workgroups [0, nblk_b) take the long users of list B
@@ -889,17 +973,15 @@ template <typename T, int WB>
 __global__ __launch_bounds__(WB) void k_prepare_all(Shard<T> S, const int32_t* __restrict__ users_a, int nusers_a, int cap_a,
                                                      int cap_pad_a, int rs_cap_a, size_t wave_bytes,
                                                      const int32_t* __restrict__ users_b, int nusers_b, int cap_b, int cap_pad_b,
-                                                     int rs_cap_b, int nblk_b, const T* __restrict__ m_in, int strict,
-                                                     const uint8_t* __restrict__ only) {
+                                                     int rs_cap_b, int nblk_b, const T* __restrict__ m_in, int strict) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < nblk_b)
         prepare_body<T, WB, false>(smem, S, users_b, nusers_b, m_in, cap_b, cap_pad_b, rs_cap_b, nullptr, 0, strict,
-                                   (int)blockIdx.x, nblk_b, only);
+                                   (int)blockIdx.x, nblk_b);
     else
         prepare_body<T, 64, false>(smem + (size_t)(threadIdx.x >> 6) * wave_bytes, S, users_a, nusers_a, m_in, cap_a, cap_pad_a,
                                    rs_cap_a, nullptr, 0, strict, ((int)blockIdx.x - nblk_b) * (WB / 64) + (int)(threadIdx.x >> 6),
-                                   ((int)gridDim.x - nblk_b) * (WB / 64), only);
-
+                                   ((int)gridDim.x - nblk_b) * (WB / 64));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -916,8 +998,7 @@ static inline size_t vsweep_bytes(int cap, int rs_cap, bool two) {      // two: 
 template <typename T, int BLOCK, bool BIG, bool HV>
 __device__ __forceinline__ void vsweep_block_body(char* smem, const Shard<T>& S, const int32_t* __restrict__ users, int nusers,
                                                   const T* __restrict__ bsrc, T* __restrict__ c_out, int cap, int rs_cap,
-                                                  char* scratch, size_t stride, int strict, int blk, int nblk,
-                                                  const uint8_t* __restrict__ only = nullptr, int flags = 0) {
+                                                  char* scratch, size_t stride, int strict, int blk, int nblk, int flags = 0) {
     const int b_csr = flags & 1, pf4 = flags & 2;       // b in CSR order; four rounds of per-rating loads in flight
     Carver small(smem);
     double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
@@ -930,7 +1011,6 @@ __device__ __forceinline__ void vsweep_block_body(char* smem, const Shard<T>& S,
 
     for (int ui = blk; ui < nusers; ui += nblk) {
         const int u = users[ui];
-        if (only && !only[u]) continue;
         const int64_t s0 = S.uptr[u];
         const int n = (int)(S.uptr[u + 1] - s0);
         const int nlev = (int)(S.runofs[u + 1] - S.runofs[u]) - 1;
@@ -966,11 +1046,11 @@ template <typename T, int BLOCK, bool BIG, bool HV>
 __global__ __launch_bounds__(BLOCK) void k_vsweep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                   const T* __restrict__ bsrc, T* __restrict__ c_out,
                                                   int cap, int rs_cap, char* scratch, size_t stride, int strict, const int* skip,
-                                                  const uint8_t* __restrict__ only, int b_csr) {
+                                                  int b_csr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (skip && *skip) return;
     vsweep_block_body<T, BLOCK, BIG, HV>(smem, S, users, nusers, bsrc, c_out, cap, rs_cap, scratch, stride, strict,
-                                         (int)blockIdx.x, (int)gridDim.x, only, b_csr);
+                                         (int)blockIdx.x, (int)gridDim.x, b_csr);
 }
 
 // k_vsweep for short users (<= 256 ratings), ONE WAVE PER USER, four users per 256-thread
@@ -984,12 +1064,10 @@ static inline size_t vsweep_wave_bytes(int cap, int rs_cap, bool two) {      // 
 template <typename T, bool HV>
 __device__ __forceinline__ void vsweep_wave_body(char* smem, const Shard<T>& S, const int32_t* __restrict__ users, int nusers,
                                                  const T* __restrict__ bsrc, T* __restrict__ c_out,
-                                                 int cap, int rs_cap, size_t wave_bytes, int strict, int ui,
-                                                 const uint8_t* __restrict__ only = nullptr, int flags = 0) {
+                                                 int cap, int rs_cap, size_t wave_bytes, int strict, int ui, int flags = 0) {
     const int b_csr = flags & 1, pf4 = flags & 2;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (ui >= nusers) return;
-    if (only && !only[users[ui]]) return;
     Carver big(smem + (size_t)wid * wave_bytes);
     T* ms = big.take<T>(cap);                           // scores (thresholds) -- not loaded when the window cache replaces them
     T* x = (HV && !S.ws) ? big.take<T>(cap) : ms;       // sweep values b; they share the array unless both are needed
@@ -1034,12 +1112,11 @@ __device__ __forceinline__ void vsweep_wave_body(char* smem, const Shard<T>& S, 
 template <typename T, bool HV>
 __global__ __launch_bounds__(256) void k_vsweep_wave(Shard<T> S, const int32_t* __restrict__ users, int nusers,
                                                      const T* __restrict__ bsrc, T* __restrict__ c_out,
-                                                     int cap, int rs_cap, size_t wave_bytes, int strict, const int* skip,
-                                                     const uint8_t* __restrict__ only, int b_csr) {
+                                                     int cap, int rs_cap, size_t wave_bytes, int strict, const int* skip, int b_csr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (skip && *skip) return;
     vsweep_wave_body<T, HV>(smem, S, users, nusers, bsrc, c_out, cap, rs_cap, wave_bytes, strict,
-                            (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), only, b_csr);
+                            (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), b_csr);
 }
 
 // Both LDS-resident classes in ONE launch of 512-thread workgroups (the two sweeps are each shorter than a launch
@@ -1049,16 +1126,15 @@ template <typename T, bool HV, int WB>
 __global__ __launch_bounds__(WB) void k_vsweep_all(Shard<T> S, const int32_t* __restrict__ users_a, int nusers_a, int cap_a,
                                                     int rs_cap_a, size_t wave_bytes, const int32_t* __restrict__ users_b,
                                                     int nusers_b, int cap_b, int rs_cap_b, int nblk_b,
-                                                    const T* __restrict__ bsrc, T* __restrict__ c_out, int strict, const int* skip,
-                                                    const uint8_t* __restrict__ only, int b_csr) {
+                                                    const T* __restrict__ bsrc, T* __restrict__ c_out, int strict, const int* skip, int b_csr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (skip && *skip) return;
     if ((int)blockIdx.x < nblk_b)
         vsweep_block_body<T, WB, false, HV>(smem, S, users_b, nusers_b, bsrc, c_out, cap_b, rs_cap_b, nullptr, 0, strict,
-                                            (int)blockIdx.x, nblk_b, only, b_csr);
+                                            (int)blockIdx.x, nblk_b, b_csr);
     else
         vsweep_wave_body<T, HV>(smem, S, users_a, nusers_a, bsrc, c_out, cap_a, rs_cap_a, wave_bytes, strict,
-                                ((int)blockIdx.x - nblk_b) * (WB / 64) + (int)(threadIdx.x >> 6), only, b_csr);
+                                ((int)blockIdx.x - nblk_b) * (WB / 64) + (int)(threadIdx.x >> 6), b_csr);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1081,8 +1157,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const i
                                                 const int32_t* __restrict__ cuf,
                                                 const int32_t* __restrict__ chunk_ptr, const int32_t* __restrict__ inc_base,
                                                 const int32_t* __restrict__ slot_id, const int2* __restrict__ blk_chunks,
-                                                const T* __restrict__ U, T* __restrict__ slab, Geo geo, const int* skip,
-                                                const uint8_t* __restrict__ only = nullptr, const int32_t* __restrict__ inc_row = nullptr) {
+                                                const T* __restrict__ U, T* __restrict__ slab, Geo geo, const int* skip) {
     typedef typename VecOf<T>::type V;
     constexpr int VEC = VecOf<T>::N;
     if (skip && *skip) return;
@@ -1091,12 +1166,6 @@ __global__ __launch_bounds__(BLOCK) void k_spmm(const T* __restrict__ c, const i
     if ((int)threadIdx.x / G >= bc.y) return;
     const int gid = bc.x + (int)threadIdx.x / G;
     const int64_t z0 = chunk_ptr[gid], z1 = chunk_ptr[gid + 1];
-    if (only) {     // lock-step U step (output rows = users): a chunk none of whose users still takes part is skipped
-        int any = 0;
-        for (int i = inc_base[gid] + g; i < inc_base[gid + 1]; i += G) any |= (int)only[inc_row[i]];
-        for (int off = G >> 1; off > 0; off >>= 1) any |= __shfl_xor(any, off);
-        if (!any) return;
-    }
     for (int k = 0; k * G < geo.nchunk; ++k) {
         const int ch = g + k * G;
         const bool act = ch < geo.nchunk;
@@ -1505,8 +1574,12 @@ static inline size_t ustep_xch_bytes(int cap_pad, int ld, int K) {
 // workgroups share a CU in the throughput-bound classes with many users).
 // CLS: nothing but a distinct kernel SYMBOL for two length classes that run the same workgroup form, so that a profiler's
 // per-symbol figures (rocprofv3 --stats, --pmc) belong to one class each.
+// The 512-thread throughput form (4 rows in flight, no LDS image, no cluster) must stay within 128 VGPRs = 4 waves per SIMD, so
+// that two workgroups share a CU: its CLS = 0 symbol is compiled under HIP's minimum-waves-per-SIMD bound (the second
+// __launch_bounds__ argument), which also caps the dynamic LDS a launch may ask for at half a CU's -- a class whose
+// per-rating arrays need more than that runs one workgroup per CU whatever its registers and takes the CLS = 1 symbol.
 template <typename T, int BLOCK, bool BIG, int K, bool RES, int UNR, int CLS = 0>
-__global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
+__global__ __launch_bounds__(BLOCK, (BLOCK == 512 && UNR == 4 && !RES && K == 1 && !BIG && CLS == 0 && sizeof(T) == 4) ? 4 : 1) void k_ustep(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                  T* __restrict__ U, const T* __restrict__ Vm, double lambda, double stepsize0,
                                                  int cg_max, double cg_tol, int strict, int solver1, int cap, int cap_pad, int rs_cap, int rcap, int nchp,
                                                  char* scratch, size_t stride, unsigned long long* counters, ClusterBufs cb, int fault,
@@ -1750,7 +1823,12 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
                     else { li[p] = LiOps<LI>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
                 }
                 __syncthreads();
-                bitonic_sort<T, LI, BLOCK, false, !BIG>(key, li, npad);         // update_infor_ui (:684-726)
+                // update_infor_ui (:684-726): key holds the new scores in the order of the gradient point -- nearly sorted from the
+                // third outer iteration on (resort_window), else the full network
+                // (tmp lives in the prefix-sum array, the second key array in ms0: the gradient point's scores are not needed again)
+                bool resorted = false;
+                if constexpr (!BIG) resorted = resort_window<T, LI, BLOCK>(key, li, [&](int p) { return (int)lv0[p]; }, rs, n, reinterpret_cast<int*>(Sx), ms0, S.resort_d, reinterpret_cast<int*>(red));
+                if (!resorted) bitonic_sort<T, LI, BLOCK, false, !BIG>(key, li, npad);
                 UPROF(8);
                 loss_new = block_objective<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, Sx, red, strict);
                 obj_new = lambda / 2.0 * nn + loss_new;
@@ -1804,245 +1882,6 @@ __global__ __launch_bounds__(BLOCK) void k_ustep(Shard<T> S, Geo geo, const int3
         atomicAdd(counters + 4 + cls * 16 + 12, 1ull);
     }
 #endif
-}
-
-// ---------------------------------------------------------------------------------------
-// Lock-step U step (large shards): update_U_new (pcrpp.cpp:818-838) as RATING-PARALLEL passes over all users at once
-// instead of one workgroup per user.  Users are independent given V, so their Newton steps can advance together:
-//     gradient    k_vsweep<GRAD> -> k_spmm over the CSR (rows of V gathered, one partial row per (chunk, user)) -> k_ufin_grad
-//     CG, k = 1.. k_sddmm(P, V) -> k_vsweep<HV> -> k_spmm -> k_ufin_cg     (users whose residual has met the tolerance drop
-//                 out: lane groups / chunks / workgroups holding only finished users return at once)
-//     line search k_uls_apply -> k_sddmm(U_new, V) -> k_prepare (sort, windows, loss) -> k_uls_decide, repeated for the users
-//                 that found no decrease (pcrpp.cpp:794-813)
-// The gathers then run at the rate of k_sddmm / k_spmm (perfectly balanced, 13-15 TB/s out of the L2s) instead of the
-// 2.3x lower rate of the per-user teams of k_ustep, which stay the choice for small shards (one launch, no 10 x 4 kernel
-// latencies).  Arithmetic per user is that of k_ustep: r-vectors in fp64, the same alpha / beta / stop formulas
-// (pcrpp.cpp:628-647), the same skip rules (:787-790, pcr.cpp:552), the last tried u returned (:794-814).
-// ---------------------------------------------------------------------------------------
-template <typename T>
-struct ULock {
-    double *D, *RR, *P, *HP;        // nu x ld: delta, residual, direction, H p (fp64, as the LDS r-vectors of k_ustep)
-    T *PT, *Unew;                   // nu x ld: the direction rounded to T (what the SDDMM multiplies), the tried u
-    double *prev_obj, *err, *nn, *step;     // per user
-    uint8_t *active, *ls;           // CG still running / line search still running
-    int* tries;
-    int* nact;                      // [0] users with a running CG, [1] users in the line search, [2] "CG all done" flag
-};
-
-template <typename X>
-__device__ __forceinline__ X group_sum(X v, int G) {
-    for (int off = G >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-
-// sum of the slab rows [s0, s1) of one chunk column, added to acc[] (fp64), eight loads in flight
-template <typename T>
-__device__ __forceinline__ void slab_sum(const T* __restrict__ slab, int s0, int s1, int ch, const Geo& geo, double* acc) {
-    typedef typename VecOf<T>::type V;
-    constexpr int VEC = VecOf<T>::N;
-    for (int sl = s0; sl < s1; sl += 8) {
-        V pv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (sl + q < s1) pv[q] = *reinterpret_cast<const V*>(slab + row_off(sl + q, geo) + ch * VEC);
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (sl + q < s1) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[e] += (double)velem(pv[q], e);
-            }
-    }
-}
-
-// g_u = lambda u + sum_j c_j v_j (obtain_g_u_new, pcrpp.cpp:493-539; zeros for a user without ratings, :496-498), the skip
-// rules, prev_obj (pcrpp.cpp:786), and the CG start (:629-631): delta = 0, rr = -g, p = g.  G lanes per user.
-template <typename T, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_ufin_grad(const T* __restrict__ slab, const int32_t* __restrict__ uslot,
-                                                     const T* __restrict__ U, const int64_t* __restrict__ uptr,
-                                                     const int64_t* __restrict__ runofs, const double* __restrict__ objp,
-                                                     double* __restrict__ objr, double lambda, double stepsize0, double cg_tol,
-                                                     int solver1, int nu, Geo geo, ULock<T> L) {
-    typedef typename VecOf<T>::type V;
-    constexpr int VEC = VecOf<T>::N;
-    __shared__ int cnt_s;
-    if (threadIdx.x == 0) cnt_s = 0;
-    __syncthreads();
-    const int G = geo.G, g = threadIdx.x & (G - 1), ipb = BLOCK / G;
-    int mine = 0;
-    for (int u = (int)blockIdx.x * ipb + (int)threadIdx.x / G; u < nu; u += (int)gridDim.x * ipb) {
-        const int s0 = uslot[u], s1 = uslot[u + 1];
-        const bool empty = uptr[u + 1] == uptr[u];
-        double un2 = 0.0, gn2 = 0.0;
-        for (int ch = g; ch < geo.nchunk; ch += G) {
-            const size_t o = row_off(u, geo) + (size_t)ch * VEC;
-            const V uv = *reinterpret_cast<const V*>(U + o);
-            double acc[VEC];
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] = empty ? 0.0 : (double)velem(uv, e) * lambda;
-            slab_sum<T>(slab, s0, s1, ch, geo, acc);
-            V pt;
-            T* ptp = reinterpret_cast<T*>(&pt);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const double ue = (double)velem(uv, e);
-                un2 += ue * ue; gn2 += acc[e] * acc[e];
-                L.D[o + e] = 0.0; L.RR[o + e] = acc[e] * -1.0; L.P[o + e] = acc[e];
-                ptp[e] = (T)acc[e];
-            }
-            *reinterpret_cast<V*>(L.PT + o) = pt;
-        }
-        un2 = group_sum(un2, G); gn2 = group_sum(gn2, G);
-        if (g == 0) {
-            const double prev = lambda / 2.0 * un2 + objp[u];
-            const int nlev = (int)(runofs[u + 1] - runofs[u]) - 1;
-            const bool skip = (gn2 < 0.0001) || (solver1 && nlev <= 1);          // pcrpp.cpp:787-790; pcr.cpp:552
-            L.prev_obj[u] = prev; L.err[u] = sqrt(gn2) * cg_tol; L.step[u] = stepsize0; L.tries[u] = 0;
-            L.active[u] = skip ? 0 : 1; L.ls[u] = skip ? 0 : 1;
-            objr[u] = prev;                                                      // a skipped user keeps u_i and its objective
-            mine += skip ? 0 : 1;
-        }
-    }
-    if (mine) atomicAdd(&cnt_s, mine);
-    __syncthreads();
-    if (threadIdx.x == 0 && cnt_s) { atomicAdd(L.nact, cnt_s); atomicAdd(L.nact + 1, cnt_s); }
-}
-
-// one CG iteration of every user still running (solve_delta_u_new, pcrpp.cpp:636-645): H p = lambda p + sum_j c_j v_j from the
-// slab, alpha = -(rr.p)/(p.Hp), delta += alpha p, rr += alpha Hp, stop if |rr| < err, else beta = (rr.Hp)/(p.Hp), p = -rr + beta p
-template <typename T, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_ufin_cg(const T* __restrict__ slab, const int32_t* __restrict__ uslot, double lambda,
-                                                   int nu, Geo geo, ULock<T> L, unsigned long long* __restrict__ counters) {
-    typedef typename VecOf<T>::type V;
-    constexpr int VEC = VecOf<T>::N;
-    __shared__ int cnt_s[2];
-    if (L.nact[2]) return;
-    if (threadIdx.x < 2) cnt_s[threadIdx.x] = 0;
-    __syncthreads();
-    const int G = geo.G, g = threadIdx.x & (G - 1), ipb = BLOCK / G;
-    int ran = 0, done = 0;
-    for (int u = (int)blockIdx.x * ipb + (int)threadIdx.x / G; u < nu; u += (int)gridDim.x * ipb) {
-        if (!L.active[u]) continue;                                   // (uniform inside a lane group)
-        const int s0 = uslot[u], s1 = uslot[u + 1];
-        double a = 0.0, b = 0.0;
-        for (int ch = g; ch < geo.nchunk; ch += G) {
-            const size_t o = row_off(u, geo) + (size_t)ch * VEC;
-            double hp[VEC];
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) hp[e] = L.P[o + e] * lambda;
-            slab_sum<T>(slab, s0, s1, ch, geo, hp);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) { L.HP[o + e] = hp[e]; a += L.P[o + e] * hp[e]; b += L.RR[o + e] * L.P[o + e]; }
-        }
-        const double pHp = group_sum(a, G), rp = group_sum(b, G);
-        const double alpha = -1.0 * rp / pHp;
-        a = 0.0; b = 0.0;
-        for (int ch = g; ch < geo.nchunk; ch += G) {
-            const size_t o = row_off(u, geo) + (size_t)ch * VEC;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const double hv = L.HP[o + e];                         // (this lane's own stores: program order)
-                L.D[o + e] = L.D[o + e] + L.P[o + e] * alpha;
-                const double rn = L.RR[o + e] + hv * alpha;
-                L.RR[o + e] = rn;
-                a += rn * rn; b += rn * hv;
-            }
-        }
-        const double rr2 = group_sum(a, G), rHp = group_sum(b, G);
-        ran += (g == 0);
-        if (sqrt(rr2) < L.err[u]) {
-            if (g == 0) { L.active[u] = 0; done += 1; }
-            continue;
-        }
-        const double beta = rHp / pHp;
-        for (int ch = g; ch < geo.nchunk; ch += G) {
-            const size_t o = row_off(u, geo) + (size_t)ch * VEC;
-            V pt;
-            T* ptp = reinterpret_cast<T*>(&pt);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const double pn = L.RR[o + e] * -1.0 + L.P[o + e] * beta;
-                L.P[o + e] = pn;
-                ptp[e] = (T)pn;
-            }
-            *reinterpret_cast<V*>(L.PT + o) = pt;
-        }
-    }
-    if (ran) atomicAdd(&cnt_s[0], ran);
-    if (done) atomicAdd(&cnt_s[1], done);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (cnt_s[0]) atomicAdd(counters + 0, (unsigned long long)cnt_s[0]);
-        if (cnt_s[1]) atomicSub(L.nact, cnt_s[1]);
-    }
-}
-// after an iteration: nobody left -> the remaining (already queued) kernels of the solve return at once
-__global__ void k_ucg_check(int* nact) { if (threadIdx.x == 0 && nact[0] <= 0) nact[2] = 1; }
-
-// line search, one try of every user still searching: u_new = u - step * delta (pcrpp.cpp:795-797), rounded to T as it will be
-// stored; nn = |u_new|^2
-template <typename T, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_uls_apply(const T* __restrict__ U, int nu, Geo geo, ULock<T> L) {
-    typedef typename VecOf<T>::type V;
-    constexpr int VEC = VecOf<T>::N;
-    const int G = geo.G, g = threadIdx.x & (G - 1), ipb = BLOCK / G;
-    for (int u = (int)blockIdx.x * ipb + (int)threadIdx.x / G; u < nu; u += (int)gridDim.x * ipb) {
-        if (!L.ls[u]) continue;
-        const double step = L.step[u];
-        double nn = 0.0;
-        for (int ch = g; ch < geo.nchunk; ch += G) {
-            const size_t o = row_off(u, geo) + (size_t)ch * VEC;
-            const V uv = *reinterpret_cast<const V*>(U + o);
-            V nv;
-            T* np = reinterpret_cast<T*>(&nv);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const double v = (double)velem(uv, e) + L.D[o + e] * -step;
-                np[e] = (T)v;
-                nn += (double)np[e] * (double)np[e];
-            }
-            *reinterpret_cast<V*>(L.Unew + o) = nv;
-        }
-        nn = group_sum(nn, G);
-        if (g == 0) L.nn[u] = nn;
-    }
-}
-// ... and its verdict (pcrpp.cpp:806-812): accept on a strict decrease, else halve the step, at most 20 tries; the LAST tried
-// u_new is what the user gets either way (:813), with its objective
-template <typename T, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_uls_decide(T* __restrict__ U, const double* __restrict__ objp, double* __restrict__ objr,
-                                                      double lambda, int nu, Geo geo, ULock<T> L,
-                                                      unsigned long long* __restrict__ counters) {
-    typedef typename VecOf<T>::type V;
-    constexpr int VEC = VecOf<T>::N;
-    __shared__ int cnt_s[2];
-    if (threadIdx.x < 2) cnt_s[threadIdx.x] = 0;
-    __syncthreads();
-    const int G = geo.G, g = threadIdx.x & (G - 1), ipb = BLOCK / G;
-    int tried = 0, fin = 0;
-    for (int u = (int)blockIdx.x * ipb + (int)threadIdx.x / G; u < nu; u += (int)gridDim.x * ipb) {
-        if (!L.ls[u]) continue;
-        const double obj_new = lambda / 2.0 * L.nn[u] + objp[u];
-        const int tries = L.tries[u] + 1;
-        const bool stop = (obj_new < L.prev_obj[u]) || tries >= 20;
-        if (stop) {
-            for (int ch = g; ch < geo.nchunk; ch += G) {
-                const size_t o = row_off(u, geo) + (size_t)ch * VEC;
-                *reinterpret_cast<V*>(U + o) = *reinterpret_cast<const V*>(L.Unew + o);
-            }
-        }
-        if (g == 0) {
-            tried += 1;
-            L.tries[u] = tries;
-            if (stop) { objr[u] = obj_new; L.ls[u] = 0; fin += 1; } else L.step[u] = L.step[u] / 2.0;
-        }
-    }
-    if (tried) atomicAdd(&cnt_s[0], tried);
-    if (fin) atomicAdd(&cnt_s[1], fin);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (cnt_s[0]) atomicAdd(counters + 1, (unsigned long long)cnt_s[0]);
-        if (cnt_s[1]) atomicSub(L.nact + 1, cnt_s[1]);
-    }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -142,7 +142,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = -1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
-        fault_cluster_member = 0, ustep_lockstep = -1, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_small_unr = 0, ustep_ls_recur = 1, allreduce_chunks = 0, cluster_fence = 1;
+        fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_small_unr = 0, ustep_ls_recur = 1, allreduce_chunks = 0, cluster_fence = 1, resort_window = 8;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -151,11 +151,11 @@ struct Tune {
         cluster_users = pcr_tune_int("cluster_users", 0); window_cache = pcr_tune_int("window_cache", 1);
         prepare_merged = pcr_tune_int("prepare_merged", -1); ustep_seq = pcr_tune_int("ustep_seq", 0); eval_brute = pcr_tune_int("eval_brute", 0);
         pipeline = pcr_tune_int("pipeline", 1); debug = pcr_tune_int("debug", 0); fault_cluster_member = pcr_tune_int("fault_cluster_member", 0);
-        ustep_lockstep = pcr_tune_int("ustep_lockstep", -1);
         ustep_gram = pcr_tune_int("ustep_gram", -1); count_rows = pcr_tune_int("count_rows", 0);
         wide_teams = pcr_tune_int("wide_teams", -1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); win16 = pcr_tune_int("win16", 1); sweep_prefetch = pcr_tune_int("sweep_prefetch", -1);
         ustep_small_unr = pcr_tune_int("ustep_small_unr", 0); ustep_ls_recur = pcr_tune_int("ustep_ls_recur", 1);
         allreduce_chunks = pcr_tune_int("allreduce_chunks", 0); cluster_fence = pcr_tune_int("cluster_fence", 1);
+        resort_window = pcr_tune_int("resort_window", 8);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -224,17 +224,6 @@ struct Solver final : pcr_solver {
     DBuf<unsigned long long> d_rowcnt;            // per U-step class: rows of V gathered since the solver was created (count_rows)
     size_t xch_stride = 0;
     int max_clusters = 1;
-    // ---- lock-step U step (pcr_kernels.h, "Lock-step U step"): user-major slab SpMM over the CSR + per-user CG state
-    bool lockstep = false;
-    DBuf<int32_t> du_cuf, du_chunk_ptr, du_inc_base, du_slot_id, du_inc_row, du_uslot;
-    DBuf<int2> du_blk_chunks;
-    int u_spmm_blocks = 0;
-    DBuf<T> du_slab, du_PT, du_Unew;
-    DBuf<double> du_D, du_RR, du_P, du_HP, du_prev, du_err, du_nn, du_step;
-    DBuf<uint8_t> du_active, du_ls;
-    DBuf<int> du_tries, du_nact;
-    int* h_nact = nullptr;                                        // pinned
-    ULock<T> ul;
     // ---- eval data (0 = train, 1 = test)
     struct EvalSet {
         int64_t nnz = 0;
@@ -277,6 +266,14 @@ struct Solver final : pcr_solver {
 
     ~Solver() override {
         if (st) (void)hipStreamSynchronize(st);
+#ifdef PCR_RESORT_STAT
+        {   // developer build: how often the nearly-sorted fast path of the per-user sorts was taken
+            unsigned long long h[4];
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_resort_stat), sizeof(h)) == hipSuccess && h[0] + h[1])
+                fprintf(stderr, "resort-stat: fast path %llu sorts (%.1f %%), %.1f %% of the sorted ratings; full network %llu sorts\n", h[0],
+                        100.0 * h[0] / (h[0] + h[1]), 100.0 * h[2] / (double)(h[2] + h[3]), h[1]);
+        }
+#endif
 #ifdef PCR_PREP_PROF
         {   // developer build: per-phase shader clocks of thread 0 of every k_prepare workgroup, by class
             unsigned long long h[32];
@@ -303,7 +300,6 @@ struct Solver final : pcr_solver {
         if (h_scal) (void)hipHostFree(h_scal);
         if (h_uobj) (void)hipHostFree(h_uobj);
         if (h_counters) (void)hipHostFree(h_counters);
-        if (h_nact) (void)hipHostFree(h_nact);
         for (int i = 0; i < NSIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (int i = 0; i < MAXLANE; ++i) if (ev_lane[i]) (void)hipEventDestroy(ev_lane[i]);
@@ -819,6 +815,10 @@ struct Solver final : pcr_solver {
                 const std::string key = std::to_string(b.block) + (b.big ? "g" : "") + "k" + std::to_string(b.K) + (b.rcap > 0 ? "r" : "") + "u" + std::to_string(b.unr);
                 const bool two = !b.big && b.K == 1 && b.rcap == 0 && b.unr == 4;       // the forms instantiated twice (set_lds_limits)
                 b.sym = two ? (seen[key]++ & 1) : 0;
+                // the 512-thread throughput form: symbol 0 is the register-capped one (two workgroups per CU), compiled for at most
+                // half a CU's LDS; a class that needs more LDS than that takes symbol 1 (pcr_kernels.h, k_ustep)
+                if (two && b.block == 512 && sizeof(T) == 4)
+                    b.sym = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + carve_bytes(b.wcap, 2) + ustep_big_bytes<T>(b.cap, host_pow2(b.cap), b.max_lev + 2, 4) > (size_t)80 * 1024 ? 1 : 0;
             }
         }
 
@@ -839,6 +839,8 @@ struct Solver final : pcr_solver {
         RC(d_sidx.alloc(nnz_local)); RC(d_objr.alloc(nu));
         sh.sidx = d_sidx.p; sh.objr = d_objr.p;
         sh.ws = sh_ws_for_bins;
+        sh.resort_d = std::max(0, std::min(tune.resort_window, 64));
+        sh.prev_valid = 0;                                  // set once the first k_prepare of the solver's life has been queued
         {
             int64_t longest = 0;
             for (int64_t u = 0; u < nu; ++u) longest = std::max(longest, uptr[u + 1] - uptr[u]);
@@ -917,45 +919,6 @@ struct Solver final : pcr_solver {
             scratch_blocks = std::max((int)std::min<size_t>(std::max<size_t>(nbig, 1), (size_t)ncu * 2), u_big_blocks);
             RC(d_scratch.alloc(scratch_stride * (size_t)scratch_blocks));
         }
-        // Lock-step U step: built and measured -- on every shape tried the per-user k_ustep stays ahead (full
-        // Netflix shape: U step 52 ms per-user, 63 ms lock-step; the long users, which hold most ratings, are also the ones
-        // whose CG runs longest, so few ratings ever drop out, and b / c / the r-vectors now cross global memory).  It stays
-        // available behind pcr_tune("ustep_lockstep", "1") and is held to the same parity tests.
-        lockstep = tune.ustep_lockstep > 0;
-        if (lockstep && nnz_local > 0) {
-            const int chunk = 128, gpb = 256 / geo.G;
-            std::vector<int32_t> chunk_ptr, cuf(item), inc_base, inc_row, uslot(nu + 1, 0);
-            for (int64_t a = 0; a < nnz_local; a += chunk) chunk_ptr.push_back((int32_t)a);
-            const int64_t nchunks = (int64_t)chunk_ptr.size();
-            chunk_ptr.push_back((int32_t)nnz_local);
-            for (int64_t c = 0; c < nchunks; ++c) {
-                inc_base.push_back((int32_t)inc_row.size());
-                for (int64_t z = chunk_ptr[c]; z < chunk_ptr[c + 1]; ++z) {
-                    if (z == chunk_ptr[c] || ruser[z] != ruser[z - 1]) inc_row.push_back(ruser[z]);
-                    if (z != chunk_ptr[c] && ruser[z] != ruser[z - 1]) cuf[z] |= (int32_t)0x80000000;      // "a new user starts here"
-                }
-            }
-            inc_base.push_back((int32_t)inc_row.size());
-            for (int32_t u : inc_row) uslot[u + 1]++;                  // incidences enumerated in CSR order are user-major already
-            for (int64_t u = 0; u < nu; ++u) uslot[u + 1] += uslot[u];
-            std::vector<int32_t> slot_id(inc_row.size());
-            for (size_t i = 0; i < slot_id.size(); ++i) slot_id[i] = (int32_t)i;
-            std::vector<int2> blk;
-            for (int64_t c = 0; c < nchunks; c += gpb) blk.push_back(make_int2((int)c, (int)std::min<int64_t>(gpb, nchunks - c)));
-            u_spmm_blocks = (int)blk.size();
-            RC(du_cuf.upload(cuf, st)); RC(du_chunk_ptr.upload(chunk_ptr, st)); RC(du_inc_base.upload(inc_base, st));
-            RC(du_slot_id.upload(slot_id, st)); RC(du_inc_row.upload(inc_row, st)); RC(du_uslot.upload(uslot, st));
-            RC(du_blk_chunks.upload(blk, st));
-            RC(du_slab.alloc(std::max<size_t>(inc_row.size(), 1) * geo.ld));
-            const size_t nUl = (size_t)nu * geo.ld;
-            RC(du_PT.alloc(nUl)); RC(du_Unew.alloc(nUl)); RC(du_D.alloc(nUl)); RC(du_RR.alloc(nUl)); RC(du_P.alloc(nUl)); RC(du_HP.alloc(nUl));
-            RC(du_prev.alloc(nu)); RC(du_err.alloc(nu)); RC(du_nn.alloc(nu)); RC(du_step.alloc(nu));
-            RC(du_active.alloc(nu)); RC(du_ls.alloc(nu)); RC(du_tries.alloc(nu)); RC(du_nact.alloc(4));
-            HIPCHK(hipHostMalloc((void**)&h_nact, 4 * sizeof(int)));
-            ul.D = du_D.p; ul.RR = du_RR.p; ul.P = du_P.p; ul.HP = du_HP.p; ul.PT = du_PT.p; ul.Unew = du_Unew.p;
-            ul.prev_obj = du_prev.p; ul.err = du_err.p; ul.nn = du_nn.p; ul.step = du_step.p;
-            ul.active = du_active.p; ul.ls = du_ls.p; ul.tries = du_tries.p; ul.nact = du_nact.p;
-        } else lockstep = false;
         RC(set_lds_limits());
         HIPCHK(hipStreamSynchronize(st));
         RC(pick_lanes());
@@ -980,7 +943,9 @@ struct Solver final : pcr_solver {
         UL1(64); UL1(256); UL1(512);
 #undef UL1
         UL(64, false, 1, true, 8); UL(64, false, 1, false, 8); UL(256, false, 1, false, 8);
-        UL(512, false, 1, true, 8); UL(512, false, 1, false, 4); UL(512, false, 4, true, 8);
+        UL(512, false, 1, true, 8); UL(512, false, 4, true, 8);
+        if (sizeof(T) == 4) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 1, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        else UL(512, false, 1, false, 4);
         UL(512, true, 1, true, 8); UL(512, true, 1, false, 4); UL(512, true, 4, true, 8);
 #undef UL
         HIPCHK(hipFuncSetAttribute((const void*)k_ustep_gram<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -1118,11 +1083,10 @@ struct Solver final : pcr_solver {
     // ------------------------------------------------------------------------------ launches
     // m = V_I u, sort, per-user loss -> objp.  Vm = matrix the scores are taken against.
     // out[z] = U[user(z)] . M[rows[z]] for all local ratings (rating-parallel, balanced)
-    int launch_sddmm(const T* M, const int32_t* rows, T* out, const int* skip = nullptr, const T* Umat = nullptr,
-                     const uint8_t* only = nullptr, const char* slot = "sddmm") {
+    int launch_sddmm(const T* M, const int32_t* rows, T* out, const int* skip = nullptr) {
         if (nnz_local == 0) return PCR_OK;
-        ProfScope ps(this, slot);
-        if (!Umat) Umat = d_U.p;
+        ProfScope ps(this, "sddmm");
+        const T* Umat = d_U.p;
         // tile = consecutive ratings one lane group walks.  64 by default; a shard that needs between one and two rounds of
         // workgroups at 64 gets the smallest tile (a multiple of the 8-row batch) with which ONE round holds it all
         // (ml1m: 96 -- 1224 workgroups on 1280 slots instead of 1836; 1.66 -> 1.64 ms per iteration; 80: 1.68, 128: 1.67)
@@ -1140,7 +1104,7 @@ struct Solver final : pcr_solver {
         const int ngrp = 256 / geo.G, span = ngrp * tile;
         const int grid = cdiv(nnz_local, span);
         hipLaunchKernelGGL((k_sddmm<T, 256>), dim3(grid), dim3(256), (size_t)span * 8, st, Umat, M, d_ruser.p, rows, nnz_local, out, geo, tile, skip,
-                           (const int32_t*)nullptr, (const int2*)nullptr, (const int32_t*)nullptr, only);
+                           (const int32_t*)nullptr, (const int2*)nullptr, (const int32_t*)nullptr);
         HIPCHK(hipGetLastError());
         return PCR_OK;
     }
@@ -1152,7 +1116,7 @@ struct Solver final : pcr_solver {
         ProfScope ps(this, "sddmm");
         const int span = (256 / geo.G) * spmm_chunk;
         hipLaunchKernelGGL((k_sddmm<T, 256>), dim3(spmm_blocks), dim3(256), (size_t)span * 8, st, A, d_U.p, d_crow.p, d_cuser.p, nnz_local, out, geo,
-                           spmm_chunk, skip, d_c2r.p, d_blk_chunks.p, d_chunk_ptr.p, (const uint8_t*)nullptr);
+                           spmm_chunk, skip, d_c2r.p, d_blk_chunks.p, d_chunk_ptr.p);
         HIPCHK(hipGetLastError());
         return PCR_OK;
     }
@@ -1163,15 +1127,15 @@ struct Solver final : pcr_solver {
         const bool merged = tune.prepare_merged >= 0 ? tune.prepare_merged != 0 : nnz_local < (int64_t)4000000;
         return merged && !pbins[0].users.empty() && !pbins[1].users.empty();
     }
-    int launch_prepare(const T* Vm, const T* Umat = nullptr, const uint8_t* only = nullptr) {
-        RC(launch_sddmm(Vm, d_item.p, d_mcsr.p, nullptr, Umat, only, only ? "u:sddmm" : "sddmm"));
+    int launch_prepare(const T* Vm) {
+        RC(launch_sddmm(Vm, d_item.p, d_mcsr.p));
         auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
             const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
             const size_t bigb = prepare_bytes<T>(b.cap, cap_pad, rsc, b.big ? 8 : 4);
             const size_t lds = small_common(b.block) + (b.big ? 0 : bigb);
             const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
-#define LP(BL, BG) hipLaunchKernelGGL((k_prepare<T, BL, BG>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_mcsr.p, b.cap, cap_pad, rsc, d_scratch.p, scratch_stride, strict(), only)
+#define LP(BL, BG) hipLaunchKernelGGL((k_prepare<T, BL, BG>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_mcsr.p, b.cap, cap_pad, rsc, d_scratch.p, scratch_stride, strict())
             if (b.big) LP(512, true);
             else if (b.block == 64) LP(64, false);
             else if (b.block == 256) LP(256, false);
@@ -1189,21 +1153,23 @@ struct Solver final : pcr_solver {
             const int wbs = wide_teams ? 1024 : 512, wpb = wbs / 64;
             const size_t lds = std::max(wb * wpb, small_common(wbs) + prepare_bytes<T>(bb.cap, cpb, rsb, 4));
             {
-                ProfScope ps(this, only ? "u:prepare" : "prepare/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
+                ProfScope ps(this, "prepare/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
                 if (wide_teams)
                     hipLaunchKernelGGL((k_prepare_all<T, 1024>), dim3(nb + cdiv(na, wpb)), dim3(1024), lds, st, sh, ba.d_users.p, na, ba.cap, cpa, rsa, wb,
-                                       bb.d_users.p, nb, bb.cap, cpb, rsb, nb, d_mcsr.p, strict(), only);
+                                       bb.d_users.p, nb, bb.cap, cpb, rsb, nb, d_mcsr.p, strict());
                 else
                     hipLaunchKernelGGL((k_prepare_all<T, 512>), dim3(nb + cdiv(na, wpb)), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, cpa, rsa, wb,
-                                       bb.d_users.p, nb, bb.cap, cpb, rsb, nb, d_mcsr.p, strict(), only);
+                                       bb.d_users.p, nb, bb.cap, cpb, rsb, nb, d_mcsr.p, strict());
             }
             if (!pbins[2].users.empty()) { ProfScope ps(this, pname("prepare", pbins[2]), st, pbins[2].nnz, (int64_t)pbins[2].users.size()); fn(pbins[2], st); }
             HIPCHK(hipGetLastError());
             have_sorted = true;
+            sh.prev_valid = 1;
             return PCR_OK;
         }
         RC(for_bins(bins, "prepare", fn));
         have_sorted = true;
+        sh.prev_valid = 1;
         return PCR_OK;
     }
 
@@ -1211,10 +1177,10 @@ struct Solver final : pcr_solver {
         // b = u_user . A_item per rating: walking the sorted state's item ids leaves it in sorted order (what the sweep reads);
         // the CSC walk (item tables beyond the L2s) leaves it in CSR order and the sweep picks it up through sidx
         if (hv) { if (sddmm_by_tiles()) RC(launch_sddmm_csc(A, d_b.p, skip)); else RC(launch_sddmm(A, d_sitem.p, d_b.p, skip)); }
-        return launch_sweeps(hv, skip, nullptr, hv && sddmm_by_tiles());
+        return launch_sweeps(hv, skip, hv && sddmm_by_tiles());
     }
-    // the per-user sweeps alone: b (d_b) -> c (CSR order, d_c); only: lock-step U step, users still taking part
-    int launch_sweeps(bool hv, const int* skip, const uint8_t* only, bool b_csr = false) {
+    // the per-user sweeps alone: b (d_b) -> c (CSR order, d_c)
+    int launch_sweeps(bool hv, const int* skip, bool b_csr = false) {
         const int bc = (b_csr ? 1 : 0) | (sweep_pf4 ? 2 : 0);
         const bool two = hv && !sh.ws;                      // scores and sweep values both live in LDS (no window cache)
         auto fn = [&](Bin& b, hipStream_t q) {
@@ -1222,14 +1188,14 @@ struct Solver final : pcr_solver {
             const int rsc = b.max_lev + 2;
             if (b.block == 64) {                         // short users: one wave each, four per workgroup
                 const size_t wb = (vsweep_wave_bytes<T>(b.cap, rsc, two) + 15) & ~(size_t)15;
-                if (hv) hipLaunchKernelGGL((k_vsweep_wave<T, true>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip, only, bc);
-                else hipLaunchKernelGGL((k_vsweep_wave<T, false>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip, only, bc);
+                if (hv) hipLaunchKernelGGL((k_vsweep_wave<T, true>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip, bc);
+                else hipLaunchKernelGGL((k_vsweep_wave<T, false>), dim3(cdiv(nus, 4)), dim3(256), wb * 4, q, sh, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, wb, strict(), skip, bc);
                 return;
             }
             const size_t bigb = vsweep_bytes<T>(b.cap, rsc, two);
             const size_t lds = small_common(b.block) + (b.big ? 0 : bigb);
             const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
-#define LV(BL, BG, HV) hipLaunchKernelGGL((k_vsweep<T, BL, BG, HV>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, d_scratch.p, scratch_stride, strict(), skip, only, bc)
+#define LV(BL, BG, HV) hipLaunchKernelGGL((k_vsweep<T, BL, BG, HV>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_b.p, d_c.p, b.cap, rsc, d_scratch.p, scratch_stride, strict(), skip, bc)
             if (hv) { if (b.big) LV(512, true, true); else LV(512, false, true); }
             else { if (b.big) LV(512, true, false); else LV(512, false, false); }
 #undef LV
@@ -1244,9 +1210,9 @@ struct Solver final : pcr_solver {
             const size_t lds = std::max(wb * wpb, small_common(wbs) + vsweep_bytes<T>(bb.cap, rsb, two));
             const int grid = nb + cdiv(na, wpb);
             {
-                ProfScope ps(this, only ? std::string("u:sweep") : std::string(hv ? "vhv" : "vgrad") + "/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
+                ProfScope ps(this, std::string(hv ? "vhv" : "vgrad") + "/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
 #define LVA(HV, WBS) hipLaunchKernelGGL((k_vsweep_all<T, HV, WBS>), dim3(grid), dim3(WBS), lds, st, sh, ba.d_users.p, na, ba.cap, rsa, wb, \
-                                        bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip, only, bc)
+                                        bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip, bc)
                 if (hv) { if (wide_teams) LVA(true, 1024); else LVA(true, 512); }
                 else { if (wide_teams) LVA(false, 1024); else LVA(false, 512); }
 #undef LVA
@@ -1572,60 +1538,7 @@ struct Solver final : pcr_solver {
         counters_zeroed = true;
         return PCR_OK;
     }
-    // update_U_new as rating-parallel passes over all users (pcr_kernels.h, "Lock-step U step")
-    int launch_ustep_lockstep() {
-        RC(zero_counters());
-        counters_zeroed = false;
-        ProfScope wall(this, "wall:ustep", st);
-        const int nu = (int)n_users;
-        const int fin_grid = (int)std::min<int64_t>(4096, cdiv(std::max(nu, 1), 256 / geo.G));
-        auto spmm_u = [&](const int* skip, const uint8_t* only) {
-            ProfScope ps(this, "u:spmm");
-            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(u_spmm_blocks), dim3(256), 0, st, d_c.p, (const int32_t*)nullptr, du_cuf.p, du_chunk_ptr.p,
-                               du_inc_base.p, du_slot_id.p, du_blk_chunks.p, d_V.p, du_slab.p, geo, skip, only, du_inc_row.p);
-        };
-        HIPCHK(hipMemsetAsync(du_nact.p, 0, 4 * sizeof(int), st));
-        // ---- gradient (obtain_g_u_new) at the sorted state of (U, V), skip rules, CG start
-        RC(launch_sweeps(false, nullptr, nullptr));
-        spmm_u(nullptr, nullptr);
-        {
-            ProfScope ps(this, "u:fin");
-            hipLaunchKernelGGL((k_ufin_grad<T, 256>), dim3(fin_grid), dim3(256), 0, st, du_slab.p, du_uslot.p, d_U.p, d_uptr.p, d_runofs.p, d_objp.p,
-                               d_objr.p, prm.lambda, prm.stepsize, prm.cg_tol, strict(), nu, geo, ul);
-            hipLaunchKernelGGL(k_ucg_check, dim3(1), dim3(64), 0, st, du_nact.p);
-        }
-        // ---- CG (solve_delta_u_new): all iterations queued; once every user has stopped the rest return at once
-        const int* done = du_nact.p + 2;
-        for (int k = 1; k <= prm.cg_max_iter; ++k) {
-            RC(launch_sddmm(d_V.p, d_sitem.p, d_b.p, done, du_PT.p, du_active.p, "u:sddmm"));     // b = p_user . v_item, sorted order
-            RC(launch_sweeps(true, done, du_active.p));
-            spmm_u(done, du_active.p);
-            ProfScope ps(this, "u:fin");
-            hipLaunchKernelGGL((k_ufin_cg<T, 256>), dim3(fin_grid), dim3(256), 0, st, du_slab.p, du_uslot.p, prm.lambda, nu, geo, ul, d_counters.p);
-            hipLaunchKernelGGL(k_ucg_check, dim3(1), dim3(64), 0, st, du_nact.p);
-        }
-        HIPCHK(hipGetLastError());
-        // ---- line search (pcrpp.cpp:794-813): every user that moved tries step 1; the few that found no decrease halve
-        for (int round = 0; round < 20; ++round) {
-            {
-                ProfScope ps(this, "u:ls");
-                hipLaunchKernelGGL((k_uls_apply<T, 256>), dim3(fin_grid), dim3(256), 0, st, d_U.p, nu, geo, ul);
-            }
-            RC(launch_prepare(d_V.p, du_Unew.p, du_ls.p));              // scores, sort, windows and loss of the tried u, those users only
-            {
-                ProfScope ps(this, "u:ls");
-                hipLaunchKernelGGL((k_uls_decide<T, 256>), dim3(fin_grid), dim3(256), 0, st, d_U.p, d_objp.p, d_objr.p, prm.lambda, nu, geo, ul, d_counters.p);
-            }
-            HIPCHK(hipMemcpyAsync(h_nact, du_nact.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            if (h_nact[1] <= 0) break;
-        }
-        HIPCHK(hipGetLastError());
-        return PCR_OK;
-    }
-
     int launch_ustep() {
-        if (lockstep) return launch_ustep_lockstep();
         RC(zero_counters());
         counters_zeroed = false;
         auto fn = [&](Bin& b, hipStream_t q) {

@@ -288,7 +288,6 @@ VARIANTS = [
     {"lanes": "1"},                                          # every class on the solver's stream
     {"wide_teams": "1"}, {"wide_teams": "0"}, {"ustep_win_lds": "0"}, {"win16": "0"}, {"win16": "0", "ustep_win_lds": "0"}, {"sweep_prefetch": "1"}, {"sweep_prefetch": "0"}, {"ustep_ls_recur": "0"},                # 1024- / 512-thread teams in the merged prepare / sweep launches
     {"ustep_gram": "128"}, {"ustep_gram": "40"}, {"ustep_gram": "64", "window_cache": "0"},   # dual (Gram matrix on MFMA) form for short users
-    {"ustep_lockstep": "1"}, {"ustep_lockstep": "1", "window_cache": "0"},   # the U step as rating-parallel lock-step passes (large-shard form)
     {"window_cache": "0"}, {"prepare_merged": "0"}, {"ustep_seq": "1"}, {"pipeline": "0"},   # searching sweeps, per-class prepare, serial classes
     {"sddmm_csc": "1"}, {"sddmm_csc": "1", "spmm_tiles": "16"},   # the CG's SDDMM over the tile-major CSC (wide item tables)
     {"allreduce_chunks": "3"}, {"allreduce_chunks": "5", "spmm_tiles": "16"}, {"allreduce_chunks": "4", "sddmm_csc": "1"},   # SpMM item range by item range (the N > 1 overlap form)
@@ -384,7 +383,7 @@ def test_pipelined_iterations_equal_the_step_by_step_loop(oracle):
         assert np.array_equal(Ua, Ub) and np.array_equal(Va, Vb)
 
 
-@pytest.mark.parametrize("knobs", [{}, {"ustep_gram": 128}, {"ustep_lockstep": 1}], ids=["default", "gram", "lockstep"])
+@pytest.mark.parametrize("knobs", [{}, {"ustep_gram": 128}], ids=["default", "gram"])
 def test_line_search_failure_quirks(oracle, knobs):
     """(Every form of the U step: the dual form must take its gradient coefficients from the STALE scores of the rejected V_new
     but every b = V_I s and every line-search score from the V that was kept -- a fuzz case caught it using the stale ones.)
@@ -413,8 +412,8 @@ def test_line_search_failure_quirks(oracle, knobs):
         U, V = Un, Vn
 
 
-@pytest.mark.parametrize("knobs", [{}, {"ustep_gram": 128}, {"ustep_lockstep": 1}, {"win16": 0, "ustep_win_lds": 0}],
-                         ids=["default", "gram", "lockstep", "win32"])
+@pytest.mark.parametrize("knobs", [{}, {"ustep_gram": 128}, {"win16": 0, "ustep_win_lds": 0}],
+                         ids=["default", "gram", "win32"])
 def test_fuzz_small_shapes_against_oracle(oracle, knobs):
     """Seeded random shapes around the corners of the launch logic: ranks that are not multiples of 4, 1..12 rating
     levels (window cache on and off), real-valued ratings, users of 0..700 ratings, both solvers; two outer iterations in
@@ -709,68 +708,6 @@ def test_tight_cg_tolerance_uses_the_summed_residual(oracle):
         assert rel(s.compute_Ha(delta), g) < 1e-8                                  # H delta = g to the tolerance asked for
     finally:
         oracle.set_cg()
-
-
-@pytest.mark.parametrize("precision", [pcr.PCR_F64, pcr.PCR_F32])
-@pytest.mark.parametrize("solver", [2, 1])
-def test_lockstep_u_step_against_oracle(oracle, precision, solver):
-    """The large-shard form of the U step (rating-parallel lock-step passes over all users, pcr_kernels.h) on sets that
-    exercise its corners: users without ratings, with one rating, with all-equal ratings (skip rules q6), users in every
-    sweep / prepare class incl. global scratch, users whose CG runs to the cap while others stop after one iteration.
-    Two outer iterations against the oracle, counts included in fp64."""
-    rng = np.random.default_rng(77)
-    d2, r, lam = 6000, 10, 25.0
-    lens = np.concatenate([[0, 1, 2, 5000, 4097, 4096, 1500, 1025, 300, 257, 256, 65, 64, 33], rng.integers(3, 400, 150)])
-    d1 = len(lens)
-    user = np.repeat(np.arange(d1), lens)
-    item = np.concatenate([np.sort(rng.choice(d2, n, replace=False)) for n in lens])
-    val = rng.integers(1, 6, user.shape[0]).astype(np.float64)
-    val[user == 8] = 3.0                                                       # a user with all-equal ratings
-    X = oracle.build_csr(d1, d2, user, item, val)
-    U0 = oracle.initial(d1, r) * 0.3; V0 = oracle.initial(d2, r) * 0.3
-    Uo, Vo, ro = oracle.train(X, U0, V0, lam, 2, solver=solver, do_predict=0)
-    ds = pcr.Dataset.from_triplets(d1, d2, user, item, val)
-    with pcr.tuned(ustep_lockstep=1):
-        s = pcr.Solver(ds, pcr.Parameter(k=r, precision=precision, solver_type=solver, maxiter=2, do_predict=0, **{"lambda": lam}))
-    s.set_factors(U0, V0)
-    recs, _ = s.train()
-    Ug, Vg = s.get_factors()
-    t = TOL[precision]
-    for a, b in zip(recs, ro):
-        assert abs(a["obj"] / b["obj"] - 1) < max(t["obj"], t["fac"] * 1e-2), (a["obj"], b["obj"])
-    assert rel(Vg, Vo) < t["fac"] and rel(Ug, Uo) < t["fac"]
-    if precision == pcr.PCR_F64:
-        for a, b in zip(recs[1:], ro[1:]):
-            assert (a["cg_v"], a["ls_v"], a["cg_u"], a["ls_u"]) == (b["cg_v"], b["ls_v"], b["cg_u"], b["ls_u"])
-
-
-@pytest.mark.parametrize("step", [3.0, 50.0, 1e9])
-def test_lockstep_u_step_line_search_retries(oracle, step):
-    """Initial step sizes beyond 1 (the reference's `stepsize`, pmf.h:28): the first try overshoots for many
-    users, whose line search halves the step -- the lock-step form then re-runs scores / sort / loss for those users alone,
-    round after round (step 3: 2.2 tries per user; 50: 6.3; 1e9: every user exhausts its 20 tries and gets the last tried
-    u, q5).  Counts, objective and factors as the oracle's, and as the per-user kernel's."""
-    R = synth.generate("small", seed=12, d1=300, d2=200, nnz=20000, mu=3.8, sigma=0.8)
-    r, lam = 6, 1e-3
-    X = oracle.build_csr(R.d1, R.d2, R.user, R.item, R.val)
-    U0 = oracle.initial(R.d1, r); V0 = oracle.initial(R.d2, r)
-    m0 = oracle.comp_m(U0, V0, X)
-    U1, objUo, iu = oracle.update_U_new(X, m0, lam, step, V0, U0)
-    assert iu["ls"] > 2 * R.d1
-    ds = pcr.Dataset.from_ratings(R)
-    for ls in (1, 0):
-        with pcr.tuned(ustep_lockstep=ls):
-            s = pcr.Solver(ds, pcr.Parameter(k=r, precision=pcr.PCR_F64, stepsize=step, **{"lambda": lam}))
-        s.set_factors(U0, V0)
-        s.comp_m(want=False)
-        objU, info = s.update_U()
-        Ug, _ = s.get_factors()
-        assert (info["cg"], info["ls"]) == (iu["cg"], iu["ls"]), ls
-        assert abs(objU / objUo - 1) < 1e-9 and rel(Ug, U1) < 1e-7, ls
-        # the state the U step leaves is the sorted state of (U_new, V): the next V step starts from it
-        oV, iv = s.update_V()
-        V2, m2, objVo, ivo = oracle.update_V_new(X, lam, step, U1, V0)
-        assert (iv["cg"], iv["ls"]) == (ivo["cg"], ivo["ls"]) and abs(oV / objVo - 1) < 1e-9, ls
 
 
 @pytest.mark.parametrize("precision", [pcr.PCR_F64, pcr.PCR_F32])
