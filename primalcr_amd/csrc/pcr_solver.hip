@@ -495,12 +495,23 @@ struct Solver final : pcr_solver {
             if (tune.spmm_chunk > 0) spmm_chunk = std::max(8, tune.spmm_chunk);
             const size_t row_bytes = (size_t)geo.ld * sizeof(T);
             int64_t tile_users_max = std::max<int64_t>(64, (int64_t)((5u << 18) / row_bytes));
-            int64_t ntiles = std::max<int64_t>(cdiv(nu, tile_users_max), std::min<int64_t>(8, nu / 256));
+            // Small shards: what a tile re-reads is its rows of U and its slice of c (4-byte gathers through the static map); 2, 4 or 8
+            // tiles -- each bound to 4, 2 or 1 XCDs -- whichever is the fewest that keeps that under 2 MB per tile.  Every (tile, item)
+            // pair costs a slab row, so fewer tiles is less slab: ml1m 4 tiles, 25 k rows = 10 MB written by k_spmm and read back by
+            // k_spmm_fin instead of 41 k rows = 16 MB at 8 tiles (k_spmm_fin 9.6 -> 8.3 us, k_spmm unchanged; 2 tiles: 7.8 / +0.7 us).
+            int64_t small_tiles = std::min<int64_t>(8, nu / 256);
+            if (small_tiles >= 2) {
+                const double reread = (double)nu * row_bytes + (double)nnz_local * sizeof(T);
+                small_tiles = reread / 2 <= 2e6 ? 2 : reread / 4 <= 2e6 ? 4 : 8;
+                small_tiles = std::min<int64_t>(small_tiles, nu / 256 >= 8 ? 8 : nu / 256 >= 4 ? 4 : 2);
+            }
+            int64_t ntiles = std::max<int64_t>(cdiv(nu, tile_users_max), small_tiles);
             // ... but every (tile, item) pair with a rating costs a partial row in the slab: on a very wide, sparse item side
             // (Yahoo-shaped: 136 k items) 1.25 MB tiles would hold ~5 ratings per pair and the slab would outweigh the
             // gather.  Keep at least 16 ratings per pair on average (ml1m 32, Netflix shape 37: unaffected).
             ntiles = std::min<int64_t>(ntiles, std::max<int64_t>(8, nnz_local / (16 * std::max<int64_t>(d2, 1))));
-            if (ntiles > 1) ntiles = (ntiles + 7) / 8 * 8;             // every XCD the same number of tiles
+            if (ntiles > 4) ntiles = (ntiles + 7) / 8 * 8;             // every XCD the same number of tiles (2 and 4 tiles: XCD groups)
+            else if (ntiles == 3) ntiles = 4;
             if (tune.spmm_tiles > 0) ntiles = tune.spmm_tiles;
             ntiles = std::max<int64_t>(1, std::min<int64_t>(ntiles, std::max<int64_t>(nu, 1)));
             tile_users_max = std::max<int64_t>(tile_users_max, 2 * (int64_t)cdiv(nu, ntiles));       // (the density bound may ask for larger tiles)
@@ -589,8 +600,13 @@ struct Solver final : pcr_solver {
                 size_t rr8 = 0;
                 for (int64_t t = 0; t < ntiles; ++t) {
                     const int32_t c0 = trc0[(size_t)t * n_rng + r], c1 = trc0[(size_t)t * n_rng + r + 1];
-                    for (int32_t c = c0; c < c1; c += gpb)                                // fewer than 8 tiles: no affinity, use every XCD
-                        per_xcd[ntiles >= 8 ? t % 8 : rr8++ % 8].push_back(make_int2(c, std::min<int32_t>(gpb, c1 - c)));
+                    // tile t -> XCD t mod 8; 2 or 4 tiles: tile t -> the XCDs {t, t + ntiles, ..} in turn (each of them then caches only
+                    // that tile's rows of U and slice of c); any other count below 8: no affinity, use every XCD
+                    size_t turn = 0;
+                    for (int32_t c = c0; c < c1; c += gpb) {
+                        const size_t x = ntiles >= 8 ? (size_t)(t % 8) : (ntiles == 2 || ntiles == 4) ? (size_t)t + (size_t)ntiles * (turn++ % (8 / ntiles)) : rr8++ % 8;
+                        per_xcd[x].push_back(make_int2(c, std::min<int32_t>(gpb, c1 - c)));
+                    }
                 }
                 size_t deepest = 0;
                 for (auto& v : per_xcd) deepest = std::max(deepest, v.size());
@@ -746,6 +762,8 @@ struct Solver final : pcr_solver {
             const bool lds_bound = !b.big && ustep_big_bytes<T>(b.cap, host_pow2(b.cap), b.max_lev + 2, 4) > 72 * 1024;
             if (b.K > 1 || lds_bound || !many((int64_t)b.users.size())) { b.unr = 8; continue; }
             b.unr = 4;
+            // (re-checked in round 3 for a 513..1024 class of 200 users, one round of workgroups: 256 threads at 8 rows in flight
+            // 1.49 -> 1.69 ms per ml1m step, 512 threads at 4 rows: no change)
             if (b.limit == 1024 && !b.big) b.block = 256;
         }
         // A class whose per-rating arrays + r-vectors do not fit the 160 KB of LDS (fp64 at wide ranks with users near 4096
