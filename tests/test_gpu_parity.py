@@ -293,6 +293,8 @@ VARIANTS = [
     {"allreduce_chunks": "3"}, {"allreduce_chunks": "5", "spmm_tiles": "16"}, {"allreduce_chunks": "4", "sddmm_csc": "1"},   # SpMM item range by item range (the N > 1 overlap form)
     {"allreduce_chunks": "3", "spmm_tiles": "8"},            # ... with exactly one tile per XCD (the tile <-> XCD affinity inside every range's plan)
     {"cluster_fence": "0"},                                  # cluster hand-off without the agent-scope release / acquire
+    {"resort_window": "0"}, {"resort_window": "2"}, {"resort_window": "64"},   # the sorts' nearly-sorted fast path: off, narrow, widest
+    {"spmm_tiles": "2"}, {"spmm_tiles": "4"},                # tiles bound to groups of 4 / 2 XCDs
 ]
 
 
@@ -331,6 +333,38 @@ def test_launch_variants_agree(oracle):
     assert abs(oV / objV - 1) < 1e-9 and abs(oU / objU - 1) < 1e-9
     assert rel(Vg, V1) < 1e-7 and rel(Ug, U1) < 1e-7
     assert iu["cg"] == info_u["cg"] and iu["ls"] == info_u["ls"]
+
+
+@pytest.mark.parametrize("precision", [pcr.PCR_F64, pcr.PCR_F32])
+def test_nearly_sorted_fast_path_walks_the_same_trajectory(oracle, precision):
+    """From the third outer iteration on most users are re-sorted by windowed rank counting instead of the bitonic network
+    (resort_window; verified per user, falls back otherwise).  Any (level, m)-sorted order gives the same sums, so eight outer
+    iterations with the fast path (default, and a narrow window that falls back often) must equal the run that always sorts
+    fully -- to summation-order rounding in fp64 with identical inner counts, and the fp64 run must match the oracle."""
+    d1, d2, user, item, val = _mixed_set(seed=21, d1=500, d2=5200)
+    r, lam, iters = 12, 30.0, 8
+    ds = pcr.Dataset.from_triplets(d1, d2, user, item, val)
+    U0 = oracle.initial(d1, r) * 0.3; V0 = oracle.initial(d2, r) * 0.3
+    runs = {}
+    for w in (0, 8, 3):
+        with pcr.tuned(resort_window=w):
+            s = pcr.Solver(ds, pcr.Parameter(k=r, precision=precision, do_predict=0, **{"lambda": lam}))
+        s.set_factors(U0, V0)
+        recs = s.iterate(iters)
+        runs[w] = (recs, s.get_factors())
+        s.close()
+    tol = 1e-9 if precision == pcr.PCR_F64 else 2e-3
+    for w in (8, 3):
+        for a, b in zip(runs[0][0], runs[w][0]):
+            assert abs(a["obj"] / b["obj"] - 1) < tol, (w, a, b)
+            if precision == pcr.PCR_F64:
+                assert (a["cg_v"], a["ls_v"], a["cg_u"], a["ls_u"]) == (b["cg_v"], b["ls_v"], b["cg_u"], b["ls_u"]), w
+        assert rel(runs[w][1][0], runs[0][1][0]) < tol * 10 and rel(runs[w][1][1], runs[0][1][1]) < tol * 10
+    if precision == pcr.PCR_F64:
+        X = oracle.build_csr(d1, d2, user, item, val)
+        _, _, ref = oracle.train(X, U0, V0, lam, iters, do_predict=0)
+        for a, b in zip(runs[8][0], ref[1:]):
+            assert abs(a["obj"] / b["obj"] - 1) < 1e-8
 
 
 def test_state_left_by_u_step_equals_a_fresh_prepare(oracle):
