@@ -344,7 +344,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && UNR == 4 && !RES && K == 1 
                 if constexpr (!BIG) resorted = resort_window<T, LI, BLOCK>(key, li, [&](int p) { return (int)lv0[p]; }, rs, n, reinterpret_cast<int*>(Sx), ms0, S.resort_d, reinterpret_cast<int*>(red));
                 if (!resorted) bitonic_sort<T, LI, BLOCK, false, !BIG>(key, li, npad);
                 UPROF(8);
-                loss_new = block_objective<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, Sx, red, strict);
+                // objective_u_new (:542-573) of the tried point.  With the LDS window copy (free again: the CG is over) its windows
+                // are searched ONCE, into that copy: the loss reads them (block_objective_win) and the state store below copies
+                // them out -- one search pass per rating and level instead of three.  (Not in the one-wave classes: short users, and
+                // the extra code costs them a wave per SIMD of registers.)
+                if (BLOCK > PCR_WAVE && wl) {
+#pragma unroll 1
+                    for (int p = tid; p < n; p += BLOCK)
+                        find_windows<T, uint16_t>(key, rs, nlev, (int)LiOps<LI>::lev(li[p]), key[p], strict, winL + (size_t)p * S.ws);
+                    __syncthreads();
+                    loss_new = block_objective_win<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, winL, S.ws, Sx, red);
+                } else
+                    loss_new = block_objective<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, Sx, red, strict);
                 obj_new = lambda / 2.0 * nn + loss_new;
                 ++n_ls;
                 UPROF(9);
@@ -368,7 +379,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && UNR == 4 && !RES && K == 1 
                 S.slvl[s0 + p] = (uint16_t)lev;
                 S.sitem[s0 + p] = itm[LiOps<LI>::idx(x)];
                 S.sidx[s0 + p] = stage[p];
-                if (S.ws) store_windows<T>(S, (size_t)s0 + p, key, rs, nlev, lev, key[p], strict);
+                if (S.ws && !(BLOCK > PCR_WAVE && wl)) store_windows<T>(S, (size_t)s0 + p, key, rs, nlev, lev, key[p], strict);
+            }
+            if (BLOCK > PCR_WAVE && wl) {     // the windows of the last tried point are in the LDS copy (found for its objective)
+                if (S.w16) {
+                    uint16_t* wg = reinterpret_cast<uint16_t*>(S.win) + (size_t)s0 * S.ws;
+#pragma unroll 1
+                    for (int i = tid; i < n * S.ws; i += BLOCK) wg[i] = winL[i];
+                } else {
+                    uint32_t* wg = reinterpret_cast<uint32_t*>(S.win) + (size_t)s0 * S.ws;
+#pragma unroll 1
+                    for (int i = tid; i < n * S.ws; i += BLOCK) wg[i] = winL[i];
+                }
             }
         }
         if (mem == 0) for (int t = tid; t < ld; t += BLOCK) U[(size_t)u * ld + t] = (T)unew[t];
