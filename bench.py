@@ -144,7 +144,11 @@ def slot_kernel_match(slot, kernel_name, prec):
     if cls in ("vgrad", "vhv"):
         return (args[3] == "true") == (cls == "vhv")
     if cls == "ustep":
-        return (args[3] != "1") == clu and (len(args) < 7 or args[6] == (sym or "0"))
+        if clu or args[3] != "1":
+            return clu and args[3] != "1"
+        # l = latency form (8 rows in flight), r = one-wave class with LDS-resident rows, #n = symbol id: one symbol per class
+        return (args[5] == "8") == ("l" in flags) and (block != "64" or (args[4] == "true") == ("r" in flags)) and \
+               (len(args) < 7 or args[6] == (sym or "0"))
     return True
 
 

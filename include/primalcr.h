@@ -287,8 +287,9 @@ int pcr_predict(const double *U, int64_t d1, const double *V, int64_t d2, int64_
                 int device);                                               /* [device] */
 
 /* per-kernel device timing (HIP events on the solver's stream, one pair per launch).
- * slot names: "<class>/<workgroup size>[.<length bound>][g][c][#n]" for the per-user kernels (classes
- * prepare, vgrad, vhv, ustep; g = global-scratch variant, c = workgroup clusters, #n = the n-th kernel symbol
+ * slot names: "<class>/<workgroup size>[.<length bound>][g][c][l][r][#n]" for the per-user kernels (classes
+ * prepare, vgrad, vhv, ustep; g = global-scratch variant, c = workgroup clusters, l = k_ustep's latency form (8 rows
+ * in flight), r = one-wave k_ustep class with LDS-resident rows, #n = the n-th kernel symbol
  * of a workgroup form that two length classes of the U step share -- every class is its own symbol in a
  * profiler's per-kernel tables; "vgrad/all", "vhv/all" = both LDS classes in one launch), "wall:<class>" for
  * the fork..join wall time of a class whose length classes run concurrently, and "sddmm", "spmm",

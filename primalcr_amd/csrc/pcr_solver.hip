@@ -1076,7 +1076,11 @@ struct Solver final : pcr_solver {
         if (b.gram) return std::string(cls) + "/gram" + std::to_string(b.block) + "." + std::to_string(b.limit);
         std::string s = std::string(cls) + "/" + std::to_string(b.block);
         if (!strcmp(cls, "ustep") && b.limit) s += "." + std::to_string(b.limit);
-        return s + (b.big ? "g" : "") + (b.K > 1 ? "c" : "") + (b.sym ? "#" + std::to_string(b.sym) : "");
+        // (k_ustep: l = the latency form, 8 rows in flight; r = one-wave class with its rows LDS-resident; #n = symbol id -- together
+        // with the workgroup size they name ONE kernel symbol, so a profiler's per-symbol rows can be matched to a class)
+        const bool us = !strcmp(cls, "ustep");
+        return s + (b.big ? "g" : "") + (b.K > 1 ? "c" : "") + (us && b.K == 1 && b.unr == 8 ? "l" : "") + (us && b.block == 64 && b.rcap > 0 ? "r" : "") +
+               (b.sym ? "#" + std::to_string(b.sym) : "");
     }
     std::string ustep_classes() override {
         std::string all;

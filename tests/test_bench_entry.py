@@ -124,3 +124,27 @@ def test_two_physical_gpus_equal_one_rank(comm, chunks):
     recs = s.iterate(warmup + steps)
     assert recs[-1]["obj"] == pytest.approx(a["objective"], rel=1e-10)
     assert s.evaluate(1, 10)[1] == pytest.approx(a["ndcg10_test"], abs=1e-9)
+
+
+def test_every_ustep_class_is_one_kernel_symbol_in_the_committed_profiles():
+    """bench.py prices a HIP-event slot with the PMC bytes of 'its' kernel symbol (profiles/r03_traffic.json): every U-step length
+    class of the committed bench line (ml1m and the Netflix-shaped sub-record) must match exactly one k_ustep symbol of the
+    rocprofv3 kernel stats of the same shape, and no symbol may serve two classes."""
+    import csv
+    sys.path.insert(0, ROOT)
+    import bench
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r03_b_bench.json")).read().strip().split("\n")[-1])
+    for shape, rec in (("ml1m", line), ("netflix", line["netflix"])):
+        names = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r03_b_{shape}_f32_kernel_stats.csv")))
+                 if r["Name"].startswith("void k_ustep<float")]
+        slots = [k for k in rec["kernels"] if k.startswith("ustep/")]
+        assert len(slots) >= 6 and len(names) >= len(slots)
+        owner = {}
+        for sl in slots:
+            hit = [n for n in names if bench.slot_kernel_match(sl, n, "f32")]
+            assert len(hit) == 1, (shape, sl, hit)
+            assert hit[0] not in owner, (shape, sl, owner[hit[0]])
+            owner[hit[0]] = sl
+        dom = rec["roofline"]["kernel"]
+        if dom.startswith("ustep/"):
+            assert rec["roofline"]["traffic"] and rec["roofline"]["traffic_over_algorithmic"] > 1, (shape, rec["roofline"])
