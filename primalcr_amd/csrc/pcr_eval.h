@@ -116,22 +116,29 @@ template <typename T>
 static inline size_t eval2_bytes(int cap, int cap_pad, int rs_cap) {
     return carve_bytes(cap_pad, sizeof(T)) + carve_bytes(cap_pad, 4) + carve_bytes(cap, 4) + carve_bytes(rs_cap, 4);
 }
-template <typename T, int BLOCK>
+// BIG (users beyond 4096 ratings): the n-sized arrays live in a per-workgroup global scratch slice, (level, index) packs into 64 bits
+template <typename T>
+static inline size_t eval2_big_bytes(int cap, int cap_pad) {
+    return carve_bytes(cap_pad, sizeof(T)) + carve_bytes(cap_pad, 8) + carve_bytes(cap, 4);
+}
+template <typename T, int BLOCK, bool BIG = false>
 __global__ __launch_bounds__(BLOCK) void k_eval2(const int64_t* __restrict__ uptr, const int32_t* __restrict__ item,
                                                  const uint16_t* __restrict__ elvl, const int64_t* __restrict__ erunofs,
                                                  const int32_t* __restrict__ erunstart, const double* __restrict__ gain,
                                                  const double* __restrict__ idcg, const double* __restrict__ disc, int ndcg_k,
                                                  const int32_t* __restrict__ users, int nusers, const T* __restrict__ U,
                                                  const T* __restrict__ Vm, Geo geo, double* __restrict__ out4, int cap, int cap_pad,
-                                                 int rs_cap) {
+                                                 int rs_cap, char* scratch = nullptr, size_t stride = 0) {
+    typedef typename LiSel<T, BIG>::type LI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Carver small(smem);
     T* vecT = small.take<T>(geo.ld);
     double* red = small.take<double>(BLOCK / PCR_WAVE + 1);
-    T* key = small.take<T>(cap_pad);
-    uint32_t* li = small.take<uint32_t>(cap_pad);
-    int32_t* itm = small.take<int32_t>(cap);
     int* rs = small.take<int>(rs_cap);
+    Carver big(BIG ? scratch + (size_t)blockIdx.x * stride : small.p);
+    T* key = big.take<T>(cap_pad);
+    LI* li = big.take<LI>(cap_pad);
+    int32_t* itm = big.take<int32_t>(cap);
     const int tid = threadIdx.x;
     for (int ui = blockIdx.x; ui < nusers; ui += gridDim.x) {
         const int u = users[ui];
@@ -149,18 +156,18 @@ __global__ __launch_bounds__(BLOCK) void k_eval2(const int64_t* __restrict__ upt
         block_sddmm<T, BLOCK>(Vm, vecT, itm, n, key, geo);
         const int npad = next_pow2(n);
         for (int p = tid; p < npad; p += BLOCK) {
-            if (p < n) li[p] = LiOps<uint32_t>::pack(elvl[s0 + p], (unsigned)p);
-            else { li[p] = LiOps<uint32_t>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
+            if (p < n) li[p] = LiOps<LI>::pack(elvl[s0 + p], (unsigned)p);
+            else { li[p] = LiOps<LI>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
         }
         __syncthreads();
-        bitonic_sort<T, uint32_t, BLOCK, true>(key, li, npad);
+        bitonic_sort<T, LI, BLOCK, true, !BIG>(key, li, npad);
         // ---- mis-ordered pairs
         double bad = 0.0;
         for (int p = tid; p < n; p += BLOCK) {
-            const int lev = (int)LiOps<uint32_t>::lev(li[p]);
+            const int lev = (int)LiOps<LI>::lev(li[p]);
             const T sa = key[p];
-            unsigned cnt = 0;
-            for (int l = lev + 1; l < nlev; ++l) cnt += (unsigned)(ubound(key, rs[l], rs[l + 1], sa) - rs[l]);
+            unsigned long long cnt = 0;
+            for (int l = lev + 1; l < nlev; ++l) cnt += (unsigned long long)(ubound(key, rs[l], rs[l + 1], sa) - rs[l]);
             bad += (double)cnt;
         }
         const double badsum = block_sum<BLOCK>(bad, red);               // exact below 2^53
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval2(const int64_t* __restrict__ upt
             for (int k = 0; k < nowk; ++k) {
                 const bool have = (lane < nlev) && cur >= lo;
                 T best = have ? key[cur] : (T)0;
-                int bi = have ? (int)LiOps<uint32_t>::idx(li[cur]) : -1;
+                int bi = have ? (int)LiOps<LI>::idx(li[cur]) : -1;
                 int owner = lane;
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) {

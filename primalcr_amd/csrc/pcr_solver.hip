@@ -931,7 +931,10 @@ struct Solver final : pcr_solver {
         for (auto& b : ubins)
             if (b.big && !b.users.empty()) need = std::max(need, ustep_big_bytes<T>(b.cap, host_pow2(b.cap), b.max_lev + 2, 8));
         for (int w = 0; w < 2; ++w)
-            if (!ev[w].bins[3].users.empty()) { need = std::max(need, eval_bytes<T>(ev[w].bins[3].cap)); nbig = std::max(nbig, ev[w].bins[3].users.size()); }
+            if (!ev[w].bins[3].users.empty()) {
+                need = std::max(need, std::max(eval_bytes<T>(ev[w].bins[3].cap), eval2_big_bytes<T>(ev[w].bins[3].cap, host_pow2(ev[w].bins[3].cap))));
+                nbig = std::max(nbig, ev[w].bins[3].users.size());
+            }
         if (need) {
             scratch_stride = (need + 255) & ~(size_t)255;
             scratch_blocks = std::max((int)std::min<size_t>(std::max<size_t>(nbig, 1), (size_t)ncu * 2), u_big_blocks);
@@ -1686,6 +1689,14 @@ struct Solver final : pcr_solver {
             const int32_t* it = which == 0 ? d_item.p : es.item.p;
             auto fn = [&](Bin& b, hipStream_t q) {
                 const int nus = (int)b.users.size();
+                if (fast_eval && b.big) {                // ... users beyond 4096 ratings: the same in a global-scratch slice
+                    const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
+                    const size_t lds2 = small_common(512) + carve_bytes(rsc, 4);
+                    hipLaunchKernelGGL((k_eval2<T, 512, true>), dim3(std::min(nus, scratch_blocks)), dim3(512), lds2, q, up, it, es.elvl.p, es.erunofs.p,
+                                       es.erunstart.p, es.gain.p, es.idcg.p, es.disc.p, ndcg_k, b.d_users.p, nus, d_U.p, d_V.p, geo, d_out4.p, b.cap, cap_pad,
+                                       rsc, d_scratch.p, scratch_stride);
+                    return;
+                }
                 if (fast_eval && !b.big) {               // O(len T log len): sort by (raw level, score)
                     const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
                     const size_t lds2 = small_common(b.block) + eval2_bytes<T>(b.cap, cap_pad, rsc);
