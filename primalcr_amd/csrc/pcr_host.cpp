@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <numeric>
 #include <random>
@@ -484,35 +485,75 @@ extern "C" int pcr_dataset_csr(const pcr_dataset* ds, int which, int64_t* index,
 // levels
 // ------------------------------------------------------------------------------------------
 
+// run fn(t, lo, hi) for nthreads contiguous pieces of [0, n) (host set-up work: levels, tile-major CSC)
+void pcr_parallel_ranges(int64_t n, int nthreads, const std::function<void(int, int64_t, int64_t)>& fn) {
+    nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, n / 4096 + 1));
+    if (nthreads == 1) { fn(0, 0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back([&, t]() { fn(t, n * t / nthreads, n * (t + 1) / nthreads); });
+    for (auto& x : th) x.join();
+}
+int pcr_host_threads() {
+    // (the cgroup quota of a container is not visible through hardware_concurrency: cap at 16, the loader's default too)
+    return (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+}
+
+// Three passes, the outer two over user ranges in parallel: (1) per user the sorted distinct keys -- collected by insertion into a
+// small vector (rating sets have a handful of levels; a user with more than 64 distinct values falls back to sort + unique) --
+// and each rating's level; (2) prefix sums of the per-user level counts; (3) the cumulative per-level counts.
 int pcr_build_levels(const PcrCsr& X, int64_t u0, int64_t u1, int solver_type, PcrLevels& out, std::string& err) {
-    int64_t z0 = X.index[u0], z1 = X.index[u1];
+    const int64_t z0 = X.index[u0], z1 = X.index[u1], nu = u1 - u0;
     out.level.assign((size_t)(z1 - z0), 0);
-    out.run_ofs.assign((size_t)(u1 - u0 + 1), 0);
+    out.run_ofs.assign((size_t)(nu + 1), 0);
     out.run_start.clear();
     out.max_levels = 0;
-    std::vector<double> keys, uniq;
-    for (int64_t u = u0; u < u1; ++u) {
-        int64_t a = X.index[u], b = X.index[u + 1];
-        keys.resize((size_t)(b - a));
-        for (int64_t z = a; z < b; ++z)
-            keys[z - a] = (solver_type == PCR_SOLVER_PCRPP) ? (double)lround(X.val[z]) : X.val[z];
-        uniq = keys;
-        std::sort(uniq.begin(), uniq.end());
-        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-        int T = (int)uniq.size();
-        if (T > 65535) { err = "user " + std::to_string(u) + " has more than 65535 distinct rating levels"; return PCR_ERR_UNSUPPORTED; }
-        out.max_levels = std::max(out.max_levels, T);
-        out.run_ofs[u - u0] = (int64_t)out.run_start.size();
-        size_t base = out.run_start.size();
-        out.run_start.resize(base + T + 1, 0);
-        for (int64_t z = a; z < b; ++z) {
-            int l = (int)(std::lower_bound(uniq.begin(), uniq.end(), keys[z - a]) - uniq.begin());
-            out.level[z - z0] = (uint16_t)l;
-            out.run_start[base + l + 1]++;
+    const int nth = pcr_host_threads();
+    std::vector<int64_t> bad(nth, -1);
+    std::vector<int> maxlev(nth, 0);
+    const bool pp = solver_type == PCR_SOLVER_PCRPP;
+    pcr_parallel_ranges(nu, nth, [&](int t, int64_t lo, int64_t hi) {
+        std::vector<double> uniq, keys;
+        for (int64_t ui = lo; ui < hi; ++ui) {
+            const int64_t a = X.index[u0 + ui], b = X.index[u0 + ui + 1];
+            uniq.clear();
+            bool small = true;
+            for (int64_t z = a; z < b && small; ++z) {
+                const double k = pp ? (double)lround(X.val[z]) : X.val[z];
+                auto it = std::lower_bound(uniq.begin(), uniq.end(), k);
+                if (it == uniq.end() || *it != k) { if (uniq.size() >= 64) small = false; else uniq.insert(it, k); }
+            }
+            if (!small) {
+                keys.resize((size_t)(b - a));
+                for (int64_t z = a; z < b; ++z) keys[z - a] = pp ? (double)lround(X.val[z]) : X.val[z];
+                uniq = keys;
+                std::sort(uniq.begin(), uniq.end());
+                uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+            }
+            const int T = (int)uniq.size();
+            if (T > 65535) { if (bad[t] < 0) bad[t] = u0 + ui; continue; }
+            maxlev[t] = std::max(maxlev[t], T);
+            out.run_ofs[ui + 1] = T + 1;
+            for (int64_t z = a; z < b; ++z) {
+                const double k = pp ? (double)lround(X.val[z]) : X.val[z];
+                out.level[z - z0] = (uint16_t)(std::lower_bound(uniq.begin(), uniq.end(), k) - uniq.begin());
+            }
         }
-        for (int l = 0; l < T; ++l) out.run_start[base + l + 1] += out.run_start[base + l];
+    });
+    for (int t = 0; t < nth; ++t) {
+        if (bad[t] >= 0) { err = "user " + std::to_string(bad[t]) + " has more than 65535 distinct rating levels"; return PCR_ERR_UNSUPPORTED; }
+        out.max_levels = std::max(out.max_levels, maxlev[t]);
     }
-    out.run_ofs[u1 - u0] = (int64_t)out.run_start.size();
+    for (int64_t ui = 0; ui < nu; ++ui) out.run_ofs[ui + 1] += out.run_ofs[ui];
+    out.run_start.assign((size_t)out.run_ofs[nu], 0);
+    pcr_parallel_ranges(nu, nth, [&](int, int64_t lo, int64_t hi) {
+        for (int64_t ui = lo; ui < hi; ++ui) {
+            const int64_t a = X.index[u0 + ui], b = X.index[u0 + ui + 1];
+            int32_t* rs = out.run_start.data() + out.run_ofs[ui];
+            const int T = (int)(out.run_ofs[ui + 1] - out.run_ofs[ui]) - 1;
+            for (int64_t z = a; z < b; ++z) rs[out.level[z - z0] + 1]++;
+            for (int l = 0; l < T; ++l) rs[l + 1] += rs[l];
+        }
+    });
     return PCR_OK;
 }
 

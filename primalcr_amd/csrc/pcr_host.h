@@ -1,6 +1,7 @@
 // pcr_host.h -- host-side data structures shared by the loader, the solver and the CLIs.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,10 @@ struct PcrLevels {
     int max_levels = 0;
 };
 int pcr_build_levels(const PcrCsr& X, int64_t u0, int64_t u1, int solver_type, PcrLevels& out, std::string& err);
+
+// host set-up helpers: fn(thread, lo, hi) over contiguous pieces of [0, n); the thread count set-up work uses
+void pcr_parallel_ranges(int64_t n, int nthreads, const std::function<void(int, int64_t, int64_t)>& fn);
+int pcr_host_threads();
 
 void pcr_set_error(const std::string& msg);
 

@@ -467,21 +467,33 @@ struct Solver final : pcr_solver {
         if (nnz_local >= ((int64_t)1 << 31) - 1) { pcr_set_error("more than 2^31 ratings on one GPU"); return PCR_ERR_UNSUPPORTED; }
         const int64_t nu = n_users;
 
+        // (pcr_tune("debug"): wall time of the set-up phases)
+        auto t_phase = std::chrono::steady_clock::now();
+        auto phase = [&](const char* what) {
+            if (!tune.debug) return;
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "[pcr] set-up: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_phase).count());
+            t_phase = now;
+        };
         // ---- host-side shard preparation
         std::vector<int64_t> uptr(nu + 1);
         for (int64_t u = 0; u <= nu; ++u) uptr[u] = X.index[ds_u0 + u] - z0;
         std::vector<int32_t> item(X.item.begin() + z0, X.item.begin() + z1);
         PcrLevels lv;
         std::string err;
+        phase("copy CSR");
         int rc = pcr_build_levels(X, ds_u0, ds_u0 + nu, prm.solver_type, lv, err);
         if (rc != PCR_OK) { pcr_set_error(err); return rc; }
+        phase("levels");
         // Tile-major CSC of the shard (pcr_kernels.h, k_spmm): users are cut into tiles of about equal rating count whose
         // rows of U take at most 1.25 MB (measured on a 48 k x 17.8 k, 10 M shape: 1.2 MB tiles 379 us, 2.4 MB tiles 595 us =
         // untiled, 0.6 MB tiles 411 us: the tile shares the XCD's 4 MB L2 with the streamed ids, c and the slab stores);
         // inside a tile the entries are ordered by item, then user.
         std::vector<int32_t> cpos(nnz_local), cuser(nnz_local), crow(nnz_local), ruser(nnz_local);
-        for (int64_t u = 0; u < nu; ++u)
-            for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) ruser[z] = (int32_t)u;
+        pcr_parallel_ranges(nu, pcr_host_threads(), [&](int, int64_t lo, int64_t hi) {
+            for (int64_t u = lo; u < hi; ++u)
+                for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) ruser[z] = (int32_t)u;
+        });
         {
             // chunk = ratings one lane group walks (one slab row per item it meets).  128 on large shards; a shard whose
             // workgroups all fit on the chip at once (6 per CU at 80 VGPRs) gets the smallest chunk that still fits in one
@@ -550,38 +562,60 @@ struct Solver final : pcr_solver {
                 }
             }
             std::vector<int32_t> chunk_ptr, trc0((size_t)ntiles * n_rng + 1, 0);      // first chunk of (tile, range)
-            std::vector<int64_t> cur(d2);
-            int64_t q = 0;
-            for (int64_t t = 0; t < ntiles; ++t) {
-                std::fill(cur.begin(), cur.end(), 0);
-                for (int64_t z = uptr[tile_u[t]]; z < uptr[tile_u[t + 1]]; ++z) cur[item[z]]++;
-                int64_t run = q;
-                for (int64_t j = 0; j < d2; ++j) { const int64_t n = cur[j]; cur[j] = run; run += n; }
-                std::vector<int64_t> cut(n_rng + 1);                       // where the tile's entries cross into each item range
-                for (int r = 0; r < n_rng; ++r) cut[r] = rng_item[r] < d2 ? cur[rng_item[r]] : run;
-                cut[n_rng] = run;
-                for (int64_t u = tile_u[t]; u < tile_u[t + 1]; ++u)
-                    for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) {
-                        const int64_t p = cur[item[z]]++;
-                        cpos[z] = (int32_t)p; cuser[p] = (int32_t)u; crow[p] = item[z];
+            {   // the tiles are independent (a tile's entries are the ratings of its users: [uptr[tile_u[t]], uptr[tile_u[t + 1]])):
+                // built by the host threads side by side, their chunk lists concatenated in tile order afterwards
+                std::vector<std::vector<int32_t>> tile_chunks((size_t)ntiles);
+                std::vector<std::vector<int32_t>> tile_rc((size_t)ntiles);                 // first chunk of every range inside the tile's list
+                pcr_parallel_ranges(ntiles, (int)std::min<int64_t>(pcr_host_threads(), ntiles), [&](int, int64_t t0, int64_t t1) {
+                    std::vector<int64_t> cur(d2), cut(n_rng + 1);
+                    for (int64_t t = t0; t < t1; ++t) {
+                        std::fill(cur.begin(), cur.end(), 0);
+                        for (int64_t z = uptr[tile_u[t]]; z < uptr[tile_u[t + 1]]; ++z) cur[item[z]]++;
+                        int64_t run = uptr[tile_u[t]];
+                        for (int64_t j = 0; j < d2; ++j) { const int64_t n = cur[j]; cur[j] = run; run += n; }
+                        for (int r = 0; r < n_rng; ++r) cut[r] = rng_item[r] < d2 ? cur[rng_item[r]] : run;      // where the tile's entries cross into each item range
+                        cut[n_rng] = run;
+                        for (int64_t u = tile_u[t]; u < tile_u[t + 1]; ++u)
+                            for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) {
+                                const int64_t p = cur[item[z]]++;
+                                cpos[z] = (int32_t)p; cuser[p] = (int32_t)u; crow[p] = item[z];
+                            }
+                        tile_rc[t].resize(n_rng);
+                        for (int r = 0; r < n_rng; ++r) {
+                            tile_rc[t][r] = (int32_t)tile_chunks[t].size();
+                            for (int64_t a = cut[r]; a < cut[r + 1]; a += spmm_chunk) tile_chunks[t].push_back((int32_t)a);   // chunks never straddle tiles or ranges
+                        }
                     }
-                for (int r = 0; r < n_rng; ++r) {
-                    trc0[(size_t)t * n_rng + r] = (int32_t)chunk_ptr.size();
-                    for (int64_t a = cut[r]; a < cut[r + 1]; a += spmm_chunk) chunk_ptr.push_back((int32_t)a);   // chunks never straddle tiles or ranges
+                });
+                for (int64_t t = 0; t < ntiles; ++t) {
+                    for (int r = 0; r < n_rng; ++r) trc0[(size_t)t * n_rng + r] = (int32_t)chunk_ptr.size() + tile_rc[t][r];
+                    chunk_ptr.insert(chunk_ptr.end(), tile_chunks[t].begin(), tile_chunks[t].end());
                 }
-                q = run;
             }
             trc0[(size_t)ntiles * n_rng] = (int32_t)chunk_ptr.size();
             const int64_t nchunks = (int64_t)chunk_ptr.size();
             chunk_ptr.push_back((int32_t)nnz_local);
             // (chunk, item) incidences in chunk order -> item-major slab rows: the slots of one item are consecutive
             std::vector<int32_t> inc_base(nchunks + 1, 0), inc_item, item_slot(d2 + 1, 0);
-            for (int64_t c = 0; c < nchunks; ++c) {
-                inc_base[c] = (int32_t)inc_item.size();
-                for (int64_t z = chunk_ptr[c]; z < chunk_ptr[c + 1]; ++z)
-                    if (z == chunk_ptr[c] || crow[z] != crow[z - 1]) inc_item.push_back(crow[z]);
-            }
-            inc_base[nchunks] = (int32_t)inc_item.size();
+            std::vector<int32_t> cuf(cuser);      // k_spmm's per-entry word: the user id, and in the sign bit "a new item starts here" (never at a chunk start)
+            const int nth = pcr_host_threads();
+            pcr_parallel_ranges(nchunks, nth, [&](int, int64_t c0, int64_t c1) {          // incidences per chunk, and the new-item flags
+                for (int64_t c = c0; c < c1; ++c) {
+                    int32_t n = 1;
+                    for (int64_t z = (int64_t)chunk_ptr[c] + 1; z < chunk_ptr[c + 1]; ++z)
+                        if (crow[z] != crow[z - 1]) { ++n; cuf[z] |= (int32_t)0x80000000; }
+                    inc_base[c + 1] = chunk_ptr[c + 1] > chunk_ptr[c] ? n : 0;
+                }
+            });
+            for (int64_t c = 0; c < nchunks; ++c) inc_base[c + 1] += inc_base[c];
+            inc_item.resize((size_t)inc_base[nchunks]);
+            pcr_parallel_ranges(nchunks, nth, [&](int, int64_t c0, int64_t c1) {
+                for (int64_t c = c0; c < c1; ++c) {
+                    int32_t o = inc_base[c];
+                    for (int64_t z = chunk_ptr[c]; z < chunk_ptr[c + 1]; ++z)
+                        if (z == chunk_ptr[c] || crow[z] != crow[z - 1]) inc_item[o++] = crow[z];
+                }
+            });
             for (int32_t j : inc_item) item_slot[j + 1]++;
             for (int64_t j = 0; j < d2; ++j) item_slot[j + 1] += item_slot[j];
             std::vector<int32_t> slot_id(inc_item.size());
@@ -618,13 +652,7 @@ struct Solver final : pcr_solver {
             }
             if (blk.empty()) blk.push_back(make_int2(0, 0));
             spmm_blocks = rng_blk[n_rng];
-            {   // k_spmm's per-entry word: the user id, and in the sign bit "a new item starts here" (never at a chunk start)
-                std::vector<int32_t> cuf(cuser);
-                for (int64_t c = 0; c < nchunks; ++c)
-                    for (int64_t z = (int64_t)chunk_ptr[c] + 1; z < chunk_ptr[c + 1]; ++z)
-                        if (crow[z] != crow[z - 1]) cuf[z] |= (int32_t)0x80000000;
-                RC(d_cuf.upload(cuf, st));
-            }
+            RC(d_cuf.upload(cuf, st));
             RC(d_chunk_ptr.upload(chunk_ptr, st)); RC(d_slot_base.upload(inc_base, st)); RC(d_slot_id.upload(slot_id, st));
             RC(d_blk_chunks.upload(blk, st)); RC(d_item_slot.upload(item_slot, st));
             RC(d_slab.alloc((size_t)std::max<size_t>(inc_item.size(), 1) * geo.ld));
@@ -632,6 +660,7 @@ struct Solver final : pcr_solver {
             sddmm_csc = (size_t)d2 * geo.ld * sizeof(T) > ((size_t)32 << 20) && spmm_tiles >= 8;     // item table larger than all L2s together
             if (tune.sddmm_csc >= 0) sddmm_csc = tune.sddmm_csc != 0;
         }
+        phase("tile-major CSC, slab plan");
         make_bins(uptr, nu, &lv.run_ofs, bins);
         for (auto& b : bins) RC(b.d_users.upload(b.users, st));
         // sweep / prepare classes: class 0 = one wave per user, class 1 = one 512-thread workgroup, class 2 = global scratch.
@@ -840,10 +869,11 @@ struct Solver final : pcr_solver {
             }
         }
 
+        phase("length classes");
         RC(d_uptr.upload(uptr, st)); RC(d_item.upload(item, st)); RC(d_lvl.upload(lv.level, st));
         {   // static CSC entry -> CSR position map (the inverse of cpos)
             std::vector<int32_t> c2r(nnz_local);
-            for (int64_t z = 0; z < nnz_local; ++z) c2r[cpos[z]] = (int32_t)z;
+            pcr_parallel_ranges(nnz_local, pcr_host_threads(), [&](int, int64_t lo, int64_t hi) { for (int64_t z = lo; z < hi; ++z) c2r[cpos[z]] = (int32_t)z; });
             RC(d_c2r.upload(c2r, st));
         }
         RC(d_cuser.upload(cuser, st)); RC(d_crow.upload(crow, st)); RC(d_ruser.upload(ruser, st));
@@ -867,6 +897,7 @@ struct Solver final : pcr_solver {
         RC(d_win.alloc((size_t)nnz_local * sh.ws * (sh.w16 ? 1 : 2)));
         sh.win = d_win.p;
 
+        phase("uploads, state arrays");
         // ---- eval sets (train shard, test shard)
         for (int w = 0; w < 2; ++w) {
             const PcrCsr& E = w == 0 ? ds->train : ds->test;
@@ -882,16 +913,34 @@ struct Solver final : pcr_solver {
             }
             RC(es.val.upload(es.h_val, st));
             std::vector<double> gain(es.nnz);
-            for (int64_t z = 0; z < es.nnz; ++z) gain[z] = pow(2.0, es.h_val[z]) - 1.0;     // util.cpp:519
+            {   // util.cpp:519: pow(2, v) - 1 -- through a table of the same expression for small integer ratings (bitwise the same value)
+                double tab[64];
+                for (int i = 0; i < 64; ++i) tab[i] = pow(2.0, (double)i) - 1.0;
+                pcr_parallel_ranges(es.nnz, pcr_host_threads(), [&](int, int64_t lo, int64_t hi) {
+                    for (int64_t z = lo; z < hi; ++z) {
+                        const double v = es.h_val[z];
+                        const int iv = (v >= 0.0 && v < 64.0) ? (int)v : -1;
+                        gain[z] = (iv >= 0 && (double)iv == v) ? tab[iv] : pow(2.0, v) - 1.0;
+                    }
+                });
+            }
             RC(es.gain.upload(gain, st));
             RC(es.idcg.alloc(nu));
             {
-                PcrLevels rl;
+                // levels of the RAW ratings (the evaluator compares doubles, util.cpp:471).  For the training set they are the
+                // solver's own levels when those are raw already (PrimalCR) or when every rating is an integer (lround changes nothing)
+                bool same = w == 0 && prm.solver_type == PCR_SOLVER_PCR;
+                if (w == 0 && !same) {
+                    same = true;
+                    for (int64_t z = 0; z < es.nnz && same; ++z) same = es.h_val[z] == (double)lround(es.h_val[z]);
+                }
+                PcrLevels rl_own;
                 std::string e2;
-                if (pcr_build_levels(E, ds_u0, ds_u0 + nu, PCR_SOLVER_PCR, rl, e2) == PCR_OK) {
-                    es.max_raw_levels = rl.max_levels;
-                    RC(es.elvl.upload(rl.level, st)); RC(es.erunofs.upload(rl.run_ofs, st)); RC(es.erunstart.upload(rl.run_start, st));
-                    make_bins(es.h_uptr, nu, &rl.run_ofs, es.bins);
+                const PcrLevels* rl = same ? &lv : &rl_own;
+                if (same || pcr_build_levels(E, ds_u0, ds_u0 + nu, PCR_SOLVER_PCR, rl_own, e2) == PCR_OK) {
+                    es.max_raw_levels = rl->max_levels;
+                    RC(es.elvl.upload(rl->level, st)); RC(es.erunofs.upload(rl->run_ofs, st)); RC(es.erunstart.upload(rl->run_start, st));
+                    make_bins(es.h_uptr, nu, &rl->run_ofs, es.bins);
                 } else {
                     es.max_raw_levels = 1 << 30;
                     make_bins(es.h_uptr, nu, nullptr, es.bins);
@@ -901,6 +950,7 @@ struct Solver final : pcr_solver {
         }
         RC(d_out4.alloc(4 * (size_t)std::max<int64_t>(nu, 1)));
 
+        phase("evaluation sets");
         // ---- factors / vectors
         const size_t nV = (size_t)d2 * geo.ld, nU = (size_t)nu * geo.ld;
         RC(d_U.alloc(nU)); RC(d_V.alloc(nV)); RC(d_Vnew.alloc(nV)); RC(d_g.alloc(nV)); RC(d_delta.alloc(nV));
@@ -942,7 +992,9 @@ struct Solver final : pcr_solver {
         }
         RC(set_lds_limits());
         HIPCHK(hipStreamSynchronize(st));
+        phase("factors, scratch");
         RC(pick_lanes());
+        phase("stream lanes");
         return PCR_OK;
     }
 
@@ -1667,16 +1719,20 @@ struct Solver final : pcr_solver {
         EvalSet& es = ev[which];
         if (es.idcg_k != ndcg_k) {
             // ideal DCG and discounts with the reference's arithmetic (util.cpp:505-524)
-            std::vector<double> idcg(n_users), disc(ndcg_k), tmp;
+            std::vector<double> idcg(n_users), disc(ndcg_k);
             for (int k = 1; k <= ndcg_k; ++k) disc[k - 1] = 1.0 / log2((double)k + 1.0);
-            for (int64_t u = 0; u < n_users; ++u) {
-                tmp.assign(es.h_val.begin() + es.h_uptr[u], es.h_val.begin() + es.h_uptr[u + 1]);
-                std::sort(tmp.begin(), tmp.end(), [](double a, double b) { return a > b; });
-                int64_t nowk = std::min<int64_t>(ndcg_k, (int64_t)tmp.size());
-                double m = 0.0;
-                for (int64_t k = 1; k <= nowk; ++k) m += (pow(2.0, tmp[k - 1]) - 1.0) / log2((double)k + 1.0);
-                idcg[u] = m;
-            }
+            // (only the ndcg_k largest ratings of a user enter: a partial sort, users side by side on the host threads)
+            pcr_parallel_ranges(n_users, pcr_host_threads(), [&](int, int64_t lo, int64_t hi) {
+                std::vector<double> tmp;
+                for (int64_t u = lo; u < hi; ++u) {
+                    tmp.assign(es.h_val.begin() + es.h_uptr[u], es.h_val.begin() + es.h_uptr[u + 1]);
+                    const int64_t nowk = std::min<int64_t>(ndcg_k, (int64_t)tmp.size());
+                    std::partial_sort(tmp.begin(), tmp.begin() + nowk, tmp.end(), [](double a, double b) { return a > b; });
+                    double m = 0.0;
+                    for (int64_t k = 1; k <= nowk; ++k) m += (pow(2.0, tmp[k - 1]) - 1.0) / log2((double)k + 1.0);
+                    idcg[u] = m;
+                }
+            });
             if (n_users) HIPCHK(hipMemcpy(es.idcg.p, idcg.data(), n_users * sizeof(double), hipMemcpyHostToDevice));
             RC(es.disc.upload(disc, st));
             HIPCHK(hipStreamSynchronize(st));
