@@ -45,6 +45,7 @@
 
 static inline int host_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+#include "pcr_plan.h"
 
 // device buffer with RAII
 template <typename X>
@@ -485,181 +486,22 @@ struct Solver final : pcr_solver {
         int rc = pcr_build_levels(X, ds_u0, ds_u0 + nu, prm.solver_type, lv, err);
         if (rc != PCR_OK) { pcr_set_error(err); return rc; }
         phase("levels");
-        // Tile-major CSC of the shard (pcr_kernels.h, k_spmm): users are cut into tiles of about equal rating count whose
-        // rows of U take at most 1.25 MB (measured on a 48 k x 17.8 k, 10 M shape: 1.2 MB tiles 379 us, 2.4 MB tiles 595 us =
-        // untiled, 0.6 MB tiles 411 us: the tile shares the XCD's 4 MB L2 with the streamed ids, c and the slab stores);
-        // inside a tile the entries are ordered by item, then user.
-        std::vector<int32_t> cpos(nnz_local), cuser(nnz_local), crow(nnz_local), ruser(nnz_local);
-        pcr_parallel_ranges(nu, pcr_host_threads(), [&](int, int64_t lo, int64_t hi) {
-            for (int64_t u = lo; u < hi; ++u)
-                for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) ruser[z] = (int32_t)u;
-        });
-        {
-            // chunk = ratings one lane group walks (one slab row per item it meets).  128 on large shards; a shard whose
-            // workgroups all fit on the chip at once (6 per CU at 80 VGPRs) gets the smallest chunk that still fits in one
-            // round -- more, shorter chains: ml1m 96 instead of 128, k_spmm 32.3 -> 30.3 us, 1.69 -> 1.66 ms per iteration
-            // (64: 33.3 us, a second round; 192: 40.3 us)
-            {
-                const int64_t groups_at_once = (int64_t)ncu * 6 * (256 / geo.G);
-                const int64_t fit = cdiv(std::max<int64_t>(nnz_local, 1), groups_at_once);
-                spmm_chunk = (int)std::min<int64_t>(128, std::max<int64_t>(64, (fit + 31) / 32 * 32));
-            }
-            if (tune.spmm_chunk > 0) spmm_chunk = std::max(8, tune.spmm_chunk);
-            const size_t row_bytes = (size_t)geo.ld * sizeof(T);
-            int64_t tile_users_max = std::max<int64_t>(64, (int64_t)((5u << 18) / row_bytes));
-            // Small shards: what a tile re-reads is its rows of U and its slice of c (4-byte gathers through the static map); 2, 4 or 8
-            // tiles -- each bound to 4, 2 or 1 XCDs -- whichever is the fewest that keeps that under 2 MB per tile.  Every (tile, item)
-            // pair costs a slab row, so fewer tiles is less slab: ml1m 4 tiles, 25 k rows = 10 MB written by k_spmm and read back by
-            // k_spmm_fin instead of 41 k rows = 16 MB at 8 tiles (k_spmm_fin 9.6 -> 8.3 us, k_spmm unchanged; 2 tiles: 7.8 / +0.7 us).
-            int64_t small_tiles = std::min<int64_t>(8, nu / 256);
-            if (small_tiles >= 2) {
-                const double reread = (double)nu * row_bytes + (double)nnz_local * sizeof(T);
-                small_tiles = reread / 2 <= 2e6 ? 2 : reread / 4 <= 2e6 ? 4 : 8;
-                small_tiles = std::min<int64_t>(small_tiles, nu / 256 >= 8 ? 8 : nu / 256 >= 4 ? 4 : 2);
-            }
-            int64_t ntiles = std::max<int64_t>(cdiv(nu, tile_users_max), small_tiles);
-            // ... but every (tile, item) pair with a rating costs a partial row in the slab: on a very wide, sparse item side
-            // (Yahoo-shaped: 136 k items) 1.25 MB tiles would hold ~5 ratings per pair and the slab would outweigh the
-            // gather.  Keep at least 16 ratings per pair on average (ml1m 32, Netflix shape 37: unaffected).
-            ntiles = std::min<int64_t>(ntiles, std::max<int64_t>(8, nnz_local / (16 * std::max<int64_t>(d2, 1))));
-            if (ntiles > 4) ntiles = (ntiles + 7) / 8 * 8;             // every XCD the same number of tiles (2 and 4 tiles: XCD groups)
-            else if (ntiles == 3) ntiles = 4;
-            if (tune.spmm_tiles > 0) ntiles = tune.spmm_tiles;
-            ntiles = std::max<int64_t>(1, std::min<int64_t>(ntiles, std::max<int64_t>(nu, 1)));
-            tile_users_max = std::max<int64_t>(tile_users_max, 2 * (int64_t)cdiv(nu, ntiles));       // (the density bound may ask for larger tiles)
-            std::vector<int64_t> tile_u(1, 0);                       // user boundaries: equal ratings, at most tile_users_max users
-            for (int64_t t = 1; t < ntiles; ++t) {
-                const int64_t want = nnz_local * t / ntiles;
-                int64_t u = std::lower_bound(uptr.begin(), uptr.end(), want) - uptr.begin();
-                u = std::min(u, tile_u.back() + tile_users_max);
-                u = std::max(u, tile_u.back());
-                u = std::min<int64_t>(u, nu);
-                tile_u.push_back(u);
-            }
-            tile_u.push_back(nu);
-            while ((int64_t)tile_u.size() >= 2 && nu - tile_u[tile_u.size() - 2] > tile_users_max) {     // the cap pushed users to the end
-                tile_u.back() = tile_u[tile_u.size() - 2] + tile_users_max;
-                tile_u.push_back(nu);
-            }
-            ntiles = (int64_t)tile_u.size() - 1;
-            // item ranges (see n_rng): OPT-IN through pcr_tune("allreduce_chunks", n) -- the overlap of one range's all-reduce with the
-            // next range's SpMM is equality-tested with several ranks on one device, but has never run across two physical GPUs
-            // (no multi-GPU node was available to this build), so the default exchange is the plain one: one all-reduce per vector
-            // on the solver's stream.  Where it should pay: vectors of 16 MB and more (the Yahoo!Music shape's 109 MB: one exchange
-            // ~ a third of a CG iteration at N = 8), about one range per 4 MB, at most 8; a range costs two more launches and its
-            // own ramp and tail, which an exchange of a few MB does not pay for.
-            {
-                n_rng = 1;
-                if (tune.allreduce_chunks > 0) n_rng = tune.allreduce_chunks;
-                n_rng = (int)std::max<int64_t>(1, std::min<int64_t>(n_rng, std::min<int64_t>(64, d2)));
-                rng_item.assign(n_rng + 1, 0);
-                for (int r = 0; r <= n_rng; ++r) rng_item[r] = d2 * r / n_rng;
-                if (n_rng > 1) {
-                    HIPCHK(hipStreamCreateWithFlags(&ar_st, hipStreamNonBlocking));
-                    HIPCHK(hipEventCreateWithFlags(&ev_ar, hipEventDisableTiming));
-                    ev_rng.resize(n_rng);
-                    for (auto& e : ev_rng) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                }
-            }
-            std::vector<int32_t> chunk_ptr, trc0((size_t)ntiles * n_rng + 1, 0);      // first chunk of (tile, range)
-            {   // the tiles are independent (a tile's entries are the ratings of its users: [uptr[tile_u[t]], uptr[tile_u[t + 1]])):
-                // built by the host threads side by side, their chunk lists concatenated in tile order afterwards
-                std::vector<std::vector<int32_t>> tile_chunks((size_t)ntiles);
-                std::vector<std::vector<int32_t>> tile_rc((size_t)ntiles);                 // first chunk of every range inside the tile's list
-                pcr_parallel_ranges(ntiles, (int)std::min<int64_t>(pcr_host_threads(), ntiles), [&](int, int64_t t0, int64_t t1) {
-                    std::vector<int64_t> cur(d2), cut(n_rng + 1);
-                    for (int64_t t = t0; t < t1; ++t) {
-                        std::fill(cur.begin(), cur.end(), 0);
-                        for (int64_t z = uptr[tile_u[t]]; z < uptr[tile_u[t + 1]]; ++z) cur[item[z]]++;
-                        int64_t run = uptr[tile_u[t]];
-                        for (int64_t j = 0; j < d2; ++j) { const int64_t n = cur[j]; cur[j] = run; run += n; }
-                        for (int r = 0; r < n_rng; ++r) cut[r] = rng_item[r] < d2 ? cur[rng_item[r]] : run;      // where the tile's entries cross into each item range
-                        cut[n_rng] = run;
-                        for (int64_t u = tile_u[t]; u < tile_u[t + 1]; ++u)
-                            for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) {
-                                const int64_t p = cur[item[z]]++;
-                                cpos[z] = (int32_t)p; cuser[p] = (int32_t)u; crow[p] = item[z];
-                            }
-                        tile_rc[t].resize(n_rng);
-                        for (int r = 0; r < n_rng; ++r) {
-                            tile_rc[t][r] = (int32_t)tile_chunks[t].size();
-                            for (int64_t a = cut[r]; a < cut[r + 1]; a += spmm_chunk) tile_chunks[t].push_back((int32_t)a);   // chunks never straddle tiles or ranges
-                        }
-                    }
-                });
-                for (int64_t t = 0; t < ntiles; ++t) {
-                    for (int r = 0; r < n_rng; ++r) trc0[(size_t)t * n_rng + r] = (int32_t)chunk_ptr.size() + tile_rc[t][r];
-                    chunk_ptr.insert(chunk_ptr.end(), tile_chunks[t].begin(), tile_chunks[t].end());
-                }
-            }
-            trc0[(size_t)ntiles * n_rng] = (int32_t)chunk_ptr.size();
-            const int64_t nchunks = (int64_t)chunk_ptr.size();
-            chunk_ptr.push_back((int32_t)nnz_local);
-            // (chunk, item) incidences in chunk order -> item-major slab rows: the slots of one item are consecutive
-            std::vector<int32_t> inc_base(nchunks + 1, 0), inc_item, item_slot(d2 + 1, 0);
-            std::vector<int32_t> cuf(cuser);      // k_spmm's per-entry word: the user id, and in the sign bit "a new item starts here" (never at a chunk start)
-            const int nth = pcr_host_threads();
-            pcr_parallel_ranges(nchunks, nth, [&](int, int64_t c0, int64_t c1) {          // incidences per chunk, and the new-item flags
-                for (int64_t c = c0; c < c1; ++c) {
-                    int32_t n = 1;
-                    for (int64_t z = (int64_t)chunk_ptr[c] + 1; z < chunk_ptr[c + 1]; ++z)
-                        if (crow[z] != crow[z - 1]) { ++n; cuf[z] |= (int32_t)0x80000000; }
-                    inc_base[c + 1] = chunk_ptr[c + 1] > chunk_ptr[c] ? n : 0;
-                }
-            });
-            for (int64_t c = 0; c < nchunks; ++c) inc_base[c + 1] += inc_base[c];
-            inc_item.resize((size_t)inc_base[nchunks]);
-            pcr_parallel_ranges(nchunks, nth, [&](int, int64_t c0, int64_t c1) {
-                for (int64_t c = c0; c < c1; ++c) {
-                    int32_t o = inc_base[c];
-                    for (int64_t z = chunk_ptr[c]; z < chunk_ptr[c + 1]; ++z)
-                        if (z == chunk_ptr[c] || crow[z] != crow[z - 1]) inc_item[o++] = crow[z];
-                }
-            });
-            for (int32_t j : inc_item) item_slot[j + 1]++;
-            for (int64_t j = 0; j < d2; ++j) item_slot[j + 1] += item_slot[j];
-            std::vector<int32_t> slot_id(inc_item.size());
-            {
-                std::vector<int32_t> nxt(item_slot.begin(), item_slot.end() - 1);
-                for (size_t i = 0; i < inc_item.size(); ++i) slot_id[i] = nxt[inc_item[i]]++;
-            }
-            // workgroup -> chunks: gpb chunks per workgroup, never across tiles; tile t is walked by workgroups b = t mod 8 (mod 8).
-            // One plan per item range, back to back (each a multiple of 8 workgroups, so the affinity holds in a launch of one range
-            // as in a launch of all of them).
-            const int gpb = 256 / geo.G;
-            std::vector<int2> blk;
-            rng_blk.assign(n_rng + 1, 0);
-            for (int r = 0; r < n_rng; ++r) {
-                std::vector<std::vector<int2>> per_xcd(8);
-                size_t rr8 = 0;
-                for (int64_t t = 0; t < ntiles; ++t) {
-                    const int32_t c0 = trc0[(size_t)t * n_rng + r], c1 = trc0[(size_t)t * n_rng + r + 1];
-                    // tile t -> XCD t mod 8; 2 or 4 tiles: tile t -> the XCDs {t, t + ntiles, ..} in turn (each of them then caches only
-                    // that tile's rows of U and slice of c); any other count below 8: no affinity, use every XCD
-                    size_t turn = 0;
-                    for (int32_t c = c0; c < c1; c += gpb) {
-                        const size_t x = ntiles >= 8 ? (size_t)(t % 8) : (ntiles == 2 || ntiles == 4) ? (size_t)t + (size_t)ntiles * (turn++ % (8 / ntiles)) : rr8++ % 8;
-                        per_xcd[x].push_back(make_int2(c, std::min<int32_t>(gpb, c1 - c)));
-                    }
-                }
-                size_t deepest = 0;
-                for (auto& v : per_xcd) deepest = std::max(deepest, v.size());
-                const size_t base = blk.size();
-                blk.resize(base + deepest * 8, make_int2(0, 0));
-                for (int x = 0; x < 8; ++x)
-                    for (size_t i = 0; i < per_xcd[x].size(); ++i) blk[base + i * 8 + x] = per_xcd[x][i];
-                rng_blk[r + 1] = (int)blk.size();
-            }
-            if (blk.empty()) blk.push_back(make_int2(0, 0));
-            spmm_blocks = rng_blk[n_rng];
-            RC(d_cuf.upload(cuf, st));
-            RC(d_chunk_ptr.upload(chunk_ptr, st)); RC(d_slot_base.upload(inc_base, st)); RC(d_slot_id.upload(slot_id, st));
-            RC(d_blk_chunks.upload(blk, st)); RC(d_item_slot.upload(item_slot, st));
-            RC(d_slab.alloc((size_t)std::max<size_t>(inc_item.size(), 1) * geo.ld));
-            spmm_tiles = (int)ntiles;
-            sddmm_csc = (size_t)d2 * geo.ld * sizeof(T) > ((size_t)32 << 20) && spmm_tiles >= 8;     // item table larger than all L2s together
-            if (tune.sddmm_csc >= 0) sddmm_csc = tune.sddmm_csc != 0;
+        SpmmPlan P;
+        build_spmm_plan(SpmmPlanIn{uptr, item, nu, nnz_local, d2, geo.ld, geo.G, ncu, sizeof(T), tune.spmm_chunk, tune.spmm_tiles, tune.allreduce_chunks}, P);
+        spmm_chunk = P.chunk; n_rng = P.n_rng; rng_item = P.rng_item; rng_blk = P.rng_blk; spmm_blocks = P.blocks; spmm_tiles = P.ntiles;
+        if (n_rng > 1) {          // the all-reduce of a finished item range runs on its own stream (launch_spmm)
+            HIPCHK(hipStreamCreateWithFlags(&ar_st, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ev_ar, hipEventDisableTiming));
+            ev_rng.resize(n_rng);
+            for (auto& e : ev_rng) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
+        RC(d_cuf.upload(P.cuf, st));
+        RC(d_chunk_ptr.upload(P.chunk_ptr, st)); RC(d_slot_base.upload(P.inc_base, st)); RC(d_slot_id.upload(P.slot_id, st));
+        RC(d_blk_chunks.upload(P.blk, st)); RC(d_item_slot.upload(P.item_slot, st));
+        RC(d_slab.alloc(std::max<size_t>(P.slab_rows, 1) * geo.ld));
+        sddmm_csc = (size_t)d2 * geo.ld * sizeof(T) > ((size_t)32 << 20) && spmm_tiles >= 8;     // item table larger than all L2s together
+        if (tune.sddmm_csc >= 0) sddmm_csc = tune.sddmm_csc != 0;
+        std::vector<int32_t>&cpos = P.cpos, &cuser = P.cuser, &crow = P.crow, &ruser = P.ruser;
         phase("tile-major CSC, slab plan");
         make_bins(uptr, nu, &lv.run_ofs, bins);
         for (auto& b : bins) RC(b.d_users.upload(b.users, st));

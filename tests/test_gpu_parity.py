@@ -293,6 +293,7 @@ VARIANTS = [
     {"allreduce_chunks": "3"}, {"allreduce_chunks": "5", "spmm_tiles": "16"}, {"allreduce_chunks": "4", "sddmm_csc": "1"},   # SpMM item range by item range (the N > 1 overlap form)
     {"allreduce_chunks": "3", "spmm_tiles": "8"},            # ... with exactly one tile per XCD (the tile <-> XCD affinity inside every range's plan)
     {"cluster_fence": "0"},                                  # cluster hand-off without the agent-scope release / acquire
+    {"cluster_users": "64"}, {"cluster_users": "64", "cluster_fence": "0"},   # as many clusters as the chip holds (members on every XCD)
     {"resort_window": "0"}, {"resort_window": "2"}, {"resort_window": "64"},   # the sorts' nearly-sorted fast path: off, narrow, widest
     {"spmm_tiles": "2"}, {"spmm_tiles": "4"},                # tiles bound to groups of 4 / 2 XCDs
 ]
