@@ -160,7 +160,6 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *                   counting (verified; else the full bitonic network); default 8, 0 = always the full network, at most 64
  *   cluster_fence   0 = the hand-off between the workgroups of a cluster without the agent-scope release / acquire (its payload
  *                   is sc1 both ways; measured valid on gfx950, not an architectural guarantee; default 1: fenced)
- *   ustep_small_unr 8 = eight rows in flight per lane group in the one-wave and 256-thread classes of k_ustep (default 4)
  *   ustep_ls_recur  0 = k_ustep's first line-search try gathers the rows for its scores (default 1: m - s sum alpha_k b_k from the
  *                   CG's own b_k = V_I p_k, no pass)
  *   ustep_seq       1 = the U step's length classes back to back on one stream
@@ -170,7 +169,6 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *   spmm_tiles, spmm_chunk, sddmm_tile, sddmm_csc   tiling of the rating-parallel kernels
  *   sweep_wave_cap  ratings up to which a sweep gives a user one wave
  *   sweep_prefetch  0 = the sweeps keep one round of per-rating loads in flight instead of four (default 1)
- *   wide_teams      1 = 1024-thread workgroups in the merged prepare and sweep launches (default 0: 512)
  *   window_cache    0 = sweeps search their hinge windows instead of caching them
  *   win16           0 = 32-bit window-cache entries even when every user has fewer than 65536 ratings (default 1: 16-bit)
  *   ustep_win_lds   0 = k_ustep reads the window cache from global memory in every sweep (default 1: LDS copy)

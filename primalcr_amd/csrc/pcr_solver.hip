@@ -143,7 +143,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = -1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
-        fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, wide_teams = -1, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_small_unr = 0, ustep_ls_recur = 1, allreduce_chunks = 0, cluster_fence = 1, resort_window = 8;
+        fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_ls_recur = 1, allreduce_chunks = 0, cluster_fence = 1, resort_window = 8;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -153,8 +153,8 @@ struct Tune {
         prepare_merged = pcr_tune_int("prepare_merged", -1); ustep_seq = pcr_tune_int("ustep_seq", 0); eval_brute = pcr_tune_int("eval_brute", 0);
         pipeline = pcr_tune_int("pipeline", 1); debug = pcr_tune_int("debug", 0); fault_cluster_member = pcr_tune_int("fault_cluster_member", 0);
         ustep_gram = pcr_tune_int("ustep_gram", -1); count_rows = pcr_tune_int("count_rows", 0);
-        wide_teams = pcr_tune_int("wide_teams", -1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); win16 = pcr_tune_int("win16", 1); sweep_prefetch = pcr_tune_int("sweep_prefetch", -1);
-        ustep_small_unr = pcr_tune_int("ustep_small_unr", 0); ustep_ls_recur = pcr_tune_int("ustep_ls_recur", 1);
+        ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); win16 = pcr_tune_int("win16", 1); sweep_prefetch = pcr_tune_int("sweep_prefetch", -1);
+        ustep_ls_recur = pcr_tune_int("ustep_ls_recur", 1);
         allreduce_chunks = pcr_tune_int("allreduce_chunks", 0); cluster_fence = pcr_tune_int("cluster_fence", 1);
         resort_window = pcr_tune_int("resort_window", 8);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
@@ -208,7 +208,6 @@ struct Solver final : pcr_solver {
     bool sddmm_csc = false;                       // the CG's SDDMM walks the SpMM's tile-major CSC (item table beyond the L2s)
     DBuf<T> d_slab;                               // k_spmm partial rows, one per (chunk, item) incidence
     bool sweep_pf4 = false;                       // sweeps keep four rounds of per-rating loads in flight (large shards)
-    bool wide_teams = false;                      // k_prepare_all / k_vsweep_all: 1024-thread teams for the long users (few of them)
     int spmm_chunk = 128;
     int sddmm_tile = 0;                           // ratings per lane group of k_sddmm (0 = not chosen yet)
     DBuf<uint16_t> d_lvl, d_slvl;
@@ -539,7 +538,6 @@ struct Solver final : pcr_solver {
         for (auto& b : pbins) RC(b.d_users.upload(b.users, st));
         // (measured, ml1m: 1024-thread teams make both launches slower -- k_vsweep_all 23 -> 31 us, k_prepare_all 99 -> 133 us:
         // sixteen one-wave users per workgroup cost more occupancy than the longest user's chain gains -- so 512 stays)
-        wide_teams = tune.wide_teams > 0;
         sweep_pf4 = tune.sweep_prefetch != 0;
         // U step: users with more than 1024 ratings are bound by one CU's gather bandwidth -> clusters of 4 workgroups
         // The U step keeps each user's rows of V in LDS (k_ustep, stage_rows), so its occupancy is set by LDS bytes, not
@@ -644,16 +642,11 @@ struct Solver final : pcr_solver {
             const size_t fixed = ustep_small_bytes(geo.ld, b.block, sizeof(T)) + ustep_big_bytes<T>(b.cap, host_pow2(b.cap), b.max_lev + 2, 4);
             if (fixed > (size_t)160 * 1024) { b.big = true; b.block = 512; }
         }
-        // the one-wave and 256-thread classes keep 4 rows in flight per lane group (8, pcr_tune("ustep_small_unr"), measured on ml1m:
-        // the one-wave classes alone 1.58 -> 1.67 ms per step, the 256-thread classes too 1.89 ms; Netflix shape U step 52 -> 68 ms:
-        // the registers cost more occupancy than the deeper gathers gain)
-        for (size_t q = 0; q < nsmall && q < ubins.size(); ++q) {
-            Bin& b = ubins[q];
-            if (b.gram || b.users.empty()) continue;
-            b.unr = tune.ustep_small_unr == 8 ? 8 : 4;
-        }
-        for (size_t q = nsmall; q < ubins.size(); ++q)
-            if (ubins[q].block == 256 && !ubins[q].big && tune.ustep_small_unr > 0) ubins[q].unr = tune.ustep_small_unr;
+        // the one-wave and 256-thread classes keep 4 rows in flight per lane group (8 measured on ml1m: the one-wave classes alone
+        // 1.58 -> 1.67 ms per step, the 256-thread classes too 1.89 ms; Netflix shape U step 52 -> 68 ms: the registers cost more
+        // occupancy than the deeper gathers gain)
+        for (size_t q = 0; q < nsmall && q < ubins.size(); ++q)
+            if (!ubins[q].gram && !ubins[q].users.empty()) ubins[q].unr = 4;
         u_big_blocks = 0;
         for (auto& b : ubins) {
             const int nus = (int)b.users.size();
@@ -845,9 +838,6 @@ struct Solver final : pcr_solver {
         const int lim = 160 * 1024;
         HIPCHK(hipFuncSetAttribute((const void*)k_prepare<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_prepare_all<T, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        HIPCHK(hipFuncSetAttribute((const void*)k_prepare_all<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 512, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 512, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -857,7 +847,6 @@ struct Solver final : pcr_solver {
 #define UL1(BL) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, BL, false, 1, false, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim))
         UL1(64); UL1(256); UL1(512);
 #undef UL1
-        UL(64, false, 1, true, 8); UL(64, false, 1, false, 8); UL(256, false, 1, false, 8);
         UL(512, false, 1, true, 8); UL(512, false, 4, true, 8);
         if (sizeof(T) == 4) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 1, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         else UL(512, false, 1, false, 4);
@@ -1068,17 +1057,13 @@ struct Solver final : pcr_solver {
             const int na = (int)ba.users.size(), nb = (int)bb.users.size();
             const int cpa = host_pow2(ba.cap), cpb = host_pow2(bb.cap), rsa = ba.max_lev + 2, rsb = bb.max_lev + 2;
             const size_t wb = (small_common(64) + prepare_bytes<T>(ba.cap, cpa, rsa, 4) + 15) & ~(size_t)15;
-            // workgroup size of the launch = the long users' teams: 512 threads (1024 behind pcr_tune("wide_teams"): measured slower)
-            const int wbs = wide_teams ? 1024 : 512, wpb = wbs / 64;
+            // workgroup size of the launch = the long users' teams: 512 threads (1024 measured slower: NOTES.md)
+            const int wbs = 512, wpb = wbs / 64;
             const size_t lds = std::max(wb * wpb, small_common(wbs) + prepare_bytes<T>(bb.cap, cpb, rsb, 4));
             {
                 ProfScope ps(this, "prepare/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
-                if (wide_teams)
-                    hipLaunchKernelGGL((k_prepare_all<T, 1024>), dim3(nb + cdiv(na, wpb)), dim3(1024), lds, st, sh, ba.d_users.p, na, ba.cap, cpa, rsa, wb,
-                                       bb.d_users.p, nb, bb.cap, cpb, rsb, nb, d_mcsr.p, strict());
-                else
-                    hipLaunchKernelGGL((k_prepare_all<T, 512>), dim3(nb + cdiv(na, wpb)), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, cpa, rsa, wb,
-                                       bb.d_users.p, nb, bb.cap, cpb, rsb, nb, d_mcsr.p, strict());
+                hipLaunchKernelGGL((k_prepare_all<T, 512>), dim3(nb + cdiv(na, wpb)), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, cpa, rsa, wb,
+                                   bb.d_users.p, nb, bb.cap, cpb, rsb, nb, d_mcsr.p, strict());
             }
             if (!pbins[2].users.empty()) { ProfScope ps(this, pname("prepare", pbins[2]), st, pbins[2].nnz, (int64_t)pbins[2].users.size()); fn(pbins[2], st); }
             HIPCHK(hipGetLastError());
@@ -1125,15 +1110,14 @@ struct Solver final : pcr_solver {
             const int na = (int)ba.users.size(), nb = (int)bb.users.size();
             const int rsa = ba.max_lev + 2, rsb = bb.max_lev + 2;
             const size_t wb = (vsweep_wave_bytes<T>(ba.cap, rsa, two) + 15) & ~(size_t)15;
-            const int wbs = wide_teams ? 1024 : 512, wpb = wbs / 64;
+            const int wbs = 512, wpb = wbs / 64;
             const size_t lds = std::max(wb * wpb, small_common(wbs) + vsweep_bytes<T>(bb.cap, rsb, two));
             const int grid = nb + cdiv(na, wpb);
             {
                 ProfScope ps(this, std::string(hv ? "vhv" : "vgrad") + "/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
 #define LVA(HV, WBS) hipLaunchKernelGGL((k_vsweep_all<T, HV, WBS>), dim3(grid), dim3(WBS), lds, st, sh, ba.d_users.p, na, ba.cap, rsa, wb, \
                                         bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip, bc)
-                if (hv) { if (wide_teams) LVA(true, 1024); else LVA(true, 512); }
-                else { if (wide_teams) LVA(false, 1024); else LVA(false, 512); }
+                if (hv) LVA(true, 512); else LVA(false, 512);
 #undef LVA
             }
             if (!sbins[2].users.empty()) { ProfScope ps(this, pname(hv ? "vhv" : "vgrad", sbins[2]), st, sbins[2].nnz, (int64_t)sbins[2].users.size()); fn(sbins[2], st); }
@@ -1485,9 +1469,7 @@ struct Solver final : pcr_solver {
                 return;
             }
             if (b.big) { if (b.K == 4) LU(512, true, 4, true, 8); else if (b.unr == 8) LU(512, true, 1, true, 8); else LU(512, true, 1, false, 4); }
-            else if (b.block == 64 && b.unr == 8) { if (b.rcap > 0) LU(64, false, 1, true, 8); else LU(64, false, 1, false, 8); }
             else if (b.block == 64) { if (b.rcap > 0) LU(64, false, 1, true, 4); else LU2(64); }
-            else if (b.block == 256 && b.unr == 8) LU(256, false, 1, false, 8);
             else if (b.block == 256) LU2(256);
             else if (b.K == 4) LU(512, false, 4, true, 8);
             else if (b.unr == 8) LU(512, false, 1, true, 8);

@@ -286,7 +286,7 @@ VARIANTS = [
     {"spmm_tiles": "5"}, {"spmm_tiles": "16"}, {"spmm_tiles": "64"},   # user tiles of the SpMM (incl. more tiles than XCDs)
     {"spmm_chunk": "32"}, {"spmm_chunk": "128"},         # ratings per SpMM lane group (the default adapts to the shard: 64 here)
     {"lanes": "1"},                                          # every class on the solver's stream
-    {"wide_teams": "1"}, {"wide_teams": "0"}, {"ustep_win_lds": "0"}, {"win16": "0"}, {"win16": "0", "ustep_win_lds": "0"}, {"sweep_prefetch": "1"}, {"sweep_prefetch": "0"}, {"ustep_ls_recur": "0"},                # 1024- / 512-thread teams in the merged prepare / sweep launches
+    {"ustep_win_lds": "0"}, {"win16": "0"}, {"win16": "0", "ustep_win_lds": "0"}, {"sweep_prefetch": "1"}, {"sweep_prefetch": "0"}, {"ustep_ls_recur": "0"},                # window-cache widths and copies, sweep load depth, line-search recurrence
     {"ustep_gram": "128"}, {"ustep_gram": "40"}, {"ustep_gram": "64", "window_cache": "0"},   # dual (Gram matrix on MFMA) form for short users
     {"window_cache": "0"}, {"prepare_merged": "0"}, {"ustep_seq": "1"}, {"pipeline": "0"},   # searching sweeps, per-class prepare, serial classes
     {"sddmm_csc": "1"}, {"sddmm_csc": "1", "spmm_tiles": "16"},   # the CG's SDDMM over the tile-major CSC (wide item tables)
