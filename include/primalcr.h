@@ -158,6 +158,9 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *   resort_window   half-width D of the nearly-sorted fast path of the per-user sorts (k_prepare, k_ustep's line search): a user
  *                   whose ratings moved by at most D positions since the previous sorted state is re-sorted by windowed rank
  *                   counting (verified; else the full bitonic network); default 8, 0 = always the full network, at most 64
+ *   p2p_ll          peer-to-peer communicator: vectors of at most this many MB (and the objective's scalars) take the device-driven
+ *                   exchange (one kernel per rank, flags inside the 8-byte words, no host barrier); larger ones the host-synchronised
+ *                   reduce-scatter / all-gather; default 16, 0 = host-synchronised always
  *   cluster_fence   0 = the hand-off between the workgroups of a cluster without the agent-scope release / acquire (its payload
  *                   is sc1 both ways; measured valid on gfx950, not an architectural guarantee; default 1: fenced)
  *   ustep_ls_recur  0 = k_ustep's first line-search try gathers the rows for its scores (default 1: m - s sum alpha_k b_k from the
@@ -204,9 +207,10 @@ int pcr_comm_unique_id(void *id128);                                       /* [d
 int pcr_solver_comm_init(pcr_solver *s, const void *id128);                /* [device] */
 /* The direct peer-to-peer alternative for the ranks of ONE node (replaces the omp atomics of
  * pcrpp.cpp:240-243, :323-327 across GPUs): every rank exposes an exchange buffer through HIP IPC; an all-reduce is a
- * reduce-scatter + all-gather in which each rank reads its peers' buffers over xGMI, sums in rank order (every rank
- * obtains the same bits) and meets the others in host barriers over a POSIX shared-memory control block, whose error flag
- * also releases the peers of a rank that failed.  Every rank calls this with the same name ("/something", shm_open);
+ * reduce-scatter + all-gather that sums in rank order (every rank obtains the same bits).  Vectors up to 16 MB and the
+ * scalars are exchanged by ONE kernel per rank with the flags inside the exchanged 8-byte words (no host involvement);
+ * larger vectors through reads of the peers' buffers over xGMI between host barriers over a POSIX shared-memory control
+ * block, whose error flag also releases the peers of a rank that failed.  Every rank calls this with the same name ("/something", shm_open);
  * no id exchange is needed.  Use either this or pcr_solver_comm_init. */
 int pcr_solver_comm_init_p2p(pcr_solver *s, const char *shm_name);         /* [device] */
 /* ranks the solver's communicator reports (ncclCommCount / the p2p control block); 1 without a communicator */

@@ -13,10 +13,22 @@
 // X and Y are double-buffered by call parity, so a rank that runs ahead never overwrites bytes a peer still reads (a rank
 // reaches its next barrier only after its own reads have completed).
 //
-// Why host barriers: xGMI peers see each other's plain stores reliably at kernel boundaries; the vectors are 1.6-109 MB, so
-// two ~10 us host round trips per all-reduce are noise on the shapes where N > 1 pays (Netflix-/Yahoo-shaped), and a rank
-// that dies or times out raises the shared error flag, which every peer polls in its barrier: no rank waits forever on a
-// lost peer (with RCCL the surviving ranks block inside the collective).
+// Why host barriers there: xGMI peers see each other's plain stores reliably at kernel boundaries; on 16-109 MB vectors two
+// ~10 us host round trips per all-reduce are noise, and a rank that dies or times out raises the shared error flag, which every
+// peer polls in its barrier: no rank waits forever on a lost peer (with RCCL the surviving ranks block inside the collective).
+//
+// Small vectors (at most ll_max bytes: the ml1m shape's 1.6 MB, the objective's scalars) take a DEVICE-DRIVEN exchange instead
+// -- no staging copy, no stream synchronisation, no host barrier -- in ONE kernel per rank (k_p2p_ll):
+//     scatter    rank r stores element i of its partial, packed with the call's sequence number into one 8-byte word (value,
+//                seq), straight into inbox[r] of the element's owner q = i / per            (remote 8-byte stores)
+//     reduce     the owner polls its inbox words until they carry this call's seq (its own memory: local polls), sums the ranks'
+//                values in rank order, and stores (sum, seq) into the outbox of every rank   (remote 8-byte stores)
+//     gather     every rank polls its own outbox and unpacks
+// Data and flag travel in the SAME 8-byte store (the hardware keeps an aligned 8-byte store whole), so no ordering between a
+// payload and its flag is ever assumed -- the scheme NCCL / RCCL call LL.  A slot is reused by the next call only after its
+// reader has consumed it (a rank leaves a call only when every owner has answered, and an owner answers only after it read
+// every rank's word), so single buffers suffice; seq makes a stale word unmistakable.  Polls are bounded: a rank whose peers
+// never arrive raises an error word in pinned host memory instead of hanging the GPU.  fp64 elements travel as two words.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -70,6 +82,58 @@ __global__ __launch_bounds__(256) void k_p2p_gather(X* __restrict__ out, P2PPtrs
     }
 }
 
+// ---- device-driven exchange for small vectors (see the header comment)
+struct P2PLLPtrs { unsigned long long* inbox[PCR_P2P_MAXR]; unsigned long long* outbox[PCR_P2P_MAXR]; };
+template <typename X> struct LLWords;
+template <> struct LLWords<float> { static constexpr int W = 1; };
+template <> struct LLWords<double> { static constexpr int W = 2; };
+__device__ __forceinline__ void ll_put(unsigned long long* dst, float v, unsigned seq) {
+    __hip_atomic_store(dst, ((unsigned long long)seq << 32) | (unsigned)__float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void ll_put(unsigned long long* dst, double v, unsigned seq) {
+    __hip_atomic_store(dst, ((unsigned long long)seq << 32) | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dst + 1, ((unsigned long long)seq << 32) | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// one word carrying this call's seq, or 0 with *err raised once the poll budget is spent (or another thread already failed)
+__device__ __forceinline__ unsigned ll_word(const unsigned long long* src, unsigned seq, int* err, long long& budget) {
+    for (;;) {
+        const unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(w >> 32) == seq) return (unsigned)w;
+        __builtin_amdgcn_s_sleep(1);
+        if ((--budget & 4095) == 0 && (budget <= 0 || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return 0u;
+        }
+    }
+}
+__device__ __forceinline__ float ll_get(const unsigned long long* src, unsigned seq, int* err, long long& budget, float) {
+    return __int_as_float((int)ll_word(src, seq, err, budget));
+}
+__device__ __forceinline__ double ll_get(const unsigned long long* src, unsigned seq, int* err, long long& budget, double) {
+    const unsigned lo = ll_word(src, seq, err, budget), hi = ll_word(src + 1, seq, err, budget);
+    return __hiloint2double((int)hi, (int)lo);
+}
+// buf[0, n) <- sum over the ranks, in rank order, the same bits on every rank.  The grid must be co-resident (the host keeps it
+// at <= 128 workgroups); inbox of rank q: [sender][per * W] words, outbox: [n_max * W] words.
+template <typename X>
+__global__ __launch_bounds__(256) void k_p2p_ll(X* __restrict__ buf, int64_t n, int64_t per, int64_t box_stride, int me, int nranks,
+                                                P2PLLPtrs ll, unsigned seq, int* err, long long budget0) {
+    constexpr int W = LLWords<X>::W;
+    const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x, dt = (int64_t)gridDim.x * 256;
+    long long budget = budget0;
+    for (int64_t i = t0; i < n; i += dt) {                                           // scatter
+        const int64_t q = i / per;
+        ll_put(ll.inbox[q] + ((int64_t)me * box_stride + (i - q * per)) * W, buf[i], seq);
+    }
+    const int64_t lo = per * me < n ? per * me : n, hi = lo + per < n ? lo + per : n;
+    for (int64_t j = lo + t0; j < hi; j += dt) {                                     // reduce my slice, answer everybody
+        X s = ll_get(ll.inbox[me] + (j - lo) * W, seq, err, budget, X());
+        for (int r = 1; r < nranks; ++r) s += ll_get(ll.inbox[me] + ((int64_t)r * box_stride + (j - lo)) * W, seq, err, budget, X());
+        for (int p = 0; p < nranks; ++p) ll_put(ll.outbox[p] + j * W, s, seq);
+    }
+    for (int64_t i = t0; i < n; i += dt) buf[i] = ll_get(ll.outbox[me] + i * W, seq, err, budget, X());      // gather
+}
+
 struct P2PComm {
     int rank = 0, nranks = 1;
     P2PCtl* ctl = nullptr;
@@ -80,9 +144,17 @@ struct P2PComm {
     uint64_t seq = 0;
     double timeout_s = 120.0;
     std::string err;
+    // device-driven exchange (k_p2p_ll): two box sets in this rank's buffer, one for vectors of at most ll_elems elements of elt
+    // bytes, one for the scalars; per-set sequence numbers; an error word the kernels raise, in pinned host memory
+    size_t ll_max_bytes = 0, ll_elems = 0, ll_per = 0, ll_elt = 4;
+    size_t ll_off[2] = {0, 0}, ll_outofs[2] = {0, 0};         // byte offsets of a set's inbox / its outbox inside a rank's buffer
+    unsigned ll_seq[2] = {0, 0};
+    int* ll_err = nullptr;
+    static constexpr size_t LL_SCAL = 64;                     // doubles in the scalar set
 
     static constexpr size_t SCAL_BYTES = 64 * sizeof(double);
-    size_t total_bytes() const { return 2 * cap_bytes + 2 * slice_bytes + 2 * SCAL_BYTES; }
+    size_t ll_bytes() const { return ll_outofs[1] ? ll_outofs[1] + LL_SCAL * 16 - ll_off[0] : 0; }
+    size_t total_bytes() const { return 2 * cap_bytes + 2 * slice_bytes + 2 * SCAL_BYTES + ll_bytes(); }
     char* X_of(char* base, int par) const { return base + (size_t)par * cap_bytes; }
     char* Y_of(char* base, int par) const { return base + 2 * cap_bytes + (size_t)par * slice_bytes; }
     char* S_of(char* base, int par) const { return base + 2 * cap_bytes + 2 * slice_bytes + (size_t)par * SCAL_BYTES; }
@@ -115,8 +187,8 @@ struct P2PComm {
     // maybe error = 1), creates the block with O_CREAT | O_EXCL, fills it and writes the magic word LAST; the other ranks open
     // the name until they find a block whose magic, rank count and age say it is THIS job's.  Callers should put something
     // unpredictable into the name (the CLI and bench.py do).
-    bool init(const char* name, int rank_, int nranks_, size_t elems_max, size_t elt) {
-        rank = rank_; nranks = nranks_;
+    bool init(const char* name, int rank_, int nranks_, size_t elems_max, size_t elt, size_t ll_max = 0) {
+        rank = rank_; nranks = nranks_; ll_max_bytes = ll_max; ll_elt = elt;
         if (nranks > PCR_P2P_MAXR) return fail("p2p communicator: at most 16 ranks");
         shm_name = name;
         const auto t_open = std::chrono::steady_clock::now();
@@ -156,6 +228,18 @@ struct P2PComm {
         cap_bytes = ((elems_max * elt) + 255) & ~(size_t)255;
         const size_t per = (elems_max + nranks - 1) / nranks;
         slice_bytes = ((per * elt) + 255) & ~(size_t)255;
+        if (ll_max_bytes) {       // box sets behind X | Y | S: [inbox: nranks x per x W words][outbox: n x W words], vectors then scalars
+            const size_t W = elt / 4;
+            ll_elems = std::min(elems_max, ll_max_bytes / elt);
+            ll_per = (ll_elems + nranks - 1) / nranks;
+            const size_t sper = (LL_SCAL + nranks - 1) / nranks;
+            ll_off[0] = 2 * cap_bytes + 2 * slice_bytes + 2 * SCAL_BYTES;
+            ll_outofs[0] = ll_off[0] + (size_t)nranks * ll_per * W * 8;
+            ll_off[1] = (ll_outofs[0] + ll_elems * W * 8 + 255) & ~(size_t)255;
+            ll_outofs[1] = ll_off[1] + (size_t)nranks * sper * 2 * 8;
+            if (hipHostMalloc((void**)&ll_err, sizeof(int)) != hipSuccess) return fail("hipHostMalloc of the exchange's error word failed");
+            *ll_err = 0;
+        }
         if (hipMalloc((void**)&xbuf, total_bytes()) != hipSuccess) return fail("hipMalloc of the exchange buffer failed");
         if (hipMemset(xbuf, 0, total_bytes()) != hipSuccess) return fail("hipMemset of the exchange buffer failed");
         // (dmabuf IPC: on hosts whose driver has no legacy IPC mode the process must run with HSA_ENABLE_IPC_MODE_LEGACY=0 --
@@ -188,6 +272,23 @@ struct P2PComm {
     // in-place sum of buf[0, n) over the ranks; stream-ordered on st from the caller's point of view
     template <typename X>
     bool allreduce(X* buf, size_t n, hipStream_t st, bool scalars = false) {
+        if (ll_err && *ll_err) return fail("a device-driven exchange timed out waiting for a peer rank");
+        if (ll_max_bytes && n > 0 && (scalars ? (sizeof(X) == 8 && n <= LL_SCAL) : (sizeof(X) == ll_elt && n <= ll_elems))) {
+            // device-driven: one kernel, stream-ordered, nothing on the host
+            const int set = scalars ? 1 : 0;
+            const size_t per = scalars ? (LL_SCAL + nranks - 1) / nranks : ll_per;
+            P2PLLPtrs ll;
+            for (int r = 0; r < nranks; ++r) {
+                ll.inbox[r] = reinterpret_cast<unsigned long long*>(peer[r] + ll_off[set]);
+                ll.outbox[r] = reinterpret_cast<unsigned long long*>(peer[r] + ll_outofs[set]);
+            }
+            const unsigned sq = ++ll_seq[set];
+            const int grid = (int)std::min<size_t>(128, (n + 255) / 256);
+            // (poll budget: 2^25 polls of a system-scope load + s_sleep each per thread -- tens of seconds; a peer may lag by a whole phase)
+            hipLaunchKernelGGL((k_p2p_ll<X>), dim3(grid), dim3(256), 0, st, buf, (int64_t)n, (int64_t)per, (int64_t)per, rank, nranks, ll, sq, ll_err,
+                               (long long)1 << 25);
+            return hipGetLastError() == hipSuccess || fail("p2p: exchange launch failed");
+        }
         const int par = (int)(seq++ & 1);
         const size_t bytes = n * sizeof(X);
         if (!scalars && bytes > cap_bytes) return fail("p2p all-reduce larger than the exchange buffer");
@@ -241,6 +342,7 @@ struct P2PComm {
         finalize();
         for (int r = 0; r < nranks; ++r) if (r != rank && peer[r]) (void)hipIpcCloseMemHandle(peer[r]);
         if (xbuf) (void)hipFree(xbuf);
+        if (ll_err) (void)hipHostFree(ll_err);
         if (ctl) munmap(ctl, sizeof(P2PCtl));
     }
 };

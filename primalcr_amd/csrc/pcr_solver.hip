@@ -143,7 +143,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = -1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
-        fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_ls_recur = 1, allreduce_chunks = 0, cluster_fence = 1, resort_window = 8;
+        fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_ls_recur = 1, allreduce_chunks = 0, cluster_fence = 1, resort_window = 8, p2p_ll = 16;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -156,7 +156,7 @@ struct Tune {
         ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); win16 = pcr_tune_int("win16", 1); sweep_prefetch = pcr_tune_int("sweep_prefetch", -1);
         ustep_ls_recur = pcr_tune_int("ustep_ls_recur", 1);
         allreduce_chunks = pcr_tune_int("allreduce_chunks", 0); cluster_fence = pcr_tune_int("cluster_fence", 1);
-        resort_window = pcr_tune_int("resort_window", 8);
+        resort_window = pcr_tune_int("resort_window", 8); p2p_ll = pcr_tune_int("p2p_ll", 16);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -1724,7 +1724,7 @@ struct Solver final : pcr_solver {
         if (comm || p2p) { pcr_set_error("this solver already has a communicator"); return PCR_ERR_STATE; }
         HIPCHK(hipSetDevice(prm.device));
         p2p.reset(new P2PComm());
-        if (!p2p->init(shm_name, rank, nranks, (size_t)d2 * geo.ld, sizeof(T))) {
+        if (!p2p->init(shm_name, rank, nranks, (size_t)d2 * geo.ld, sizeof(T), (size_t)std::max(0, tune.p2p_ll) << 20)) {
             pcr_set_error("p2p communicator: " + p2p->err);
             p2p.reset();
             return PCR_ERR_COMM;

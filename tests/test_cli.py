@@ -226,11 +226,14 @@ def test_gpus_option_bootstrap_without_a_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ll", ["16", "0"], ids=["device-driven", "host-synchronised"])
 @pytest.mark.parametrize("solver", [2, 1])
-def test_gpus_option_two_ranks_on_one_gpu_equal_one_rank(solver, tmp_path):
+def test_gpus_option_two_ranks_on_one_gpu_equal_one_rank(solver, ll, tmp_path):
     """omp-pmf-train --gpus 2 --devices 0,0 --comm p2p: two worker processes share the one GPU of the test box (RCCL refuses
     two ranks on one device; the peer-to-peer communicator does not care), each owns the users pcr_partition_users gives
-    its rank, every V-side vector goes through the reduce-scatter / all-gather over IPC-mapped buffers.  fp64: objective
+    its rank, every V-side vector goes through the reduce-scatter / all-gather over IPC-mapped buffers -- the device-driven
+    exchange (one kernel per rank, flags inside the words; p2p_ll, the default for small vectors) or the host-synchronised
+    one.  fp64: objective
     lines to the printed digits, model equal to the single-process run to summation-order rounding; --gpus 1 is the
     plain run, byte for byte."""
     import primalcr_amd as pcr
@@ -240,7 +243,7 @@ def test_gpus_option_two_ranks_on_one_gpu_equal_one_rank(solver, tmp_path):
     assert one.returncode == 0, one.stderr
     same = run(base + ["--gpus", "1", d, "same.model"], tmp_path)
     assert same.returncode == 0 and open(tmp_path / "same.model", "rb").read() == open(tmp_path / "one.model", "rb").read()
-    two = run(base + ["--gpus", "2", "--devices", "0,0", "--comm", "p2p", d, "two.model"], tmp_path)
+    two = run(base + ["--gpus", "2", "--devices", "0,0", "--comm", "p2p", "--tune", "p2p_ll=" + ll, d, "two.model"], tmp_path)
     assert two.returncode == 0, two.stderr
     strip = lambda out: [l for l in out.split("\n") if l.startswith(("Iter", "(T"))]
     la, lb = strip(one.stdout), strip(two.stdout)
@@ -358,7 +361,7 @@ def test_gpus_option_large_vectors_take_the_two_phase_exchange(tmp_path):
     d = synth.write_dir(R, str(tmp_path / "data"))
     base = [TRAIN, "-k", "24", "-l", "50", "-t", "2", "-p", "0", "--f64"]
     one = run(base + [d, "one.model"], tmp_path)
-    three = run(base + ["--gpus", "3", "--devices", "0,0,0", "--comm", "p2p", d, "three.model"], tmp_path)
+    three = run(base + ["--gpus", "3", "--devices", "0,0,0", "--comm", "p2p", "--tune", "p2p_ll=0", d, "three.model"], tmp_path)
     assert one.returncode == 0 and three.returncode == 0, three.stderr
     strip = lambda out: [re.sub(r"time \S+", "time T", l) for l in out.split("\n") if l.startswith("Iter")]
     la, lb = strip(one.stdout), strip(three.stdout)
