@@ -77,7 +77,21 @@ def test_eight_rank_sharding_of_a_netflix_shaped_slice():
     assert (cg_sum, ls_sum) == (info_full["cg"], info_full["ls"])
 
 
-def _property_run(R, r, lam, iters=2, precisions=(pcr.PCR_F32, pcr.PCR_F64)):
+def _oracle_sample(oracle, R, s, r, lam, nsample):
+    """At FULL size the oracle cannot run the whole step, but users are independent given V: after the GPU's V step, the first
+    `nsample` users' scores and their U step are compared with the C restatement on exactly those users (fp64: rounding)."""
+    from oracle.oracle_py import CSR
+    a = int(R.index[nsample])
+    X = CSR(nsample, R.d2, R.index[:nsample + 1].astype(np.int64), R.item[:a].astype(np.int64), R.val[:a].astype(np.float64))
+    U, V = s.get_factors()
+    m = s.comp_m()[:a]                                                           # scores of (U, V) on the sample, from the GPU
+    mo = oracle.comp_m(U[:nsample], V, X)
+    assert np.abs(m - mo).max() <= 1e-12 * max(1.0, np.abs(mo).max())
+    Uo, _, info_o = oracle.update_U_new(X, mo, lam, 1.0, V, U[:nsample])
+    return Uo, info_o
+
+
+def _property_run(R, r, lam, iters=2, precisions=(pcr.PCR_F32, pcr.PCR_F64), oracle=None, nsample=3000):
     """obj(0) == #Omega; `iters` outer iterations in fp32 storage and in fp64: decreasing objectives, equal V-side counts,
     quality within the north star's 1e-3."""
     ds = pcr.Dataset.from_ratings(R)
@@ -94,9 +108,13 @@ def _property_run(R, r, lam, iters=2, precisions=(pcr.PCR_F32, pcr.PCR_F64)):
         s.set_factors(pcr.initial(R.d1, r), pcr.initial(R.d2, r))
         s.comp_m(want=False)
         objs, counts = [s.objective()], []
-        for _ in range(iters):
+        for it in range(iters):
             oV, iv = s.update_V()
+            sample = _oracle_sample(oracle, R, s, r, lam, nsample) if (oracle is not None and prec == pcr.PCR_F64 and it == 0) else None
             oU, iu = s.update_U()
+            if sample is not None:
+                Ug = s.get_factors()[0][:nsample]
+                assert rel(Ug, sample[0]) < 1e-7, rel(Ug, sample[0])
             objs += [oV, oU]
             counts.append((iv["cg"], iv["ls"], iv["accepted"]))
             assert iu["ls"] >= R.d1 - 64 and iu["cg"] >= iu["ls"]               # (almost) every user took a Newton step
@@ -117,20 +135,21 @@ def _property_run(R, r, lam, iters=2, precisions=(pcr.PCR_F32, pcr.PCR_F64)):
     return out
 
 
-def test_config3_full_netflix_shape_on_one_gpu():
-    """configs[3] at full size on one GPU (the 8-GPU run shards exactly this set by user)."""
+def test_config3_full_netflix_shape_on_one_gpu(oracle):
+    """configs[3] at full size on one GPU (the 8-GPU run shards exactly this set by user); the first 3000 users' scores and U
+    step are also held to the oracle (users are independent given V)."""
     R = synth.generate_fast("netflix")
     assert (R.d1, R.d2, R.nnz) == (480189, 17770, 100_000_000)
-    out = _property_run(R, 100, 5000.0)
+    out = _property_run(R, 100, 5000.0, oracle=oracle)
     assert out[pcr.PCR_F32]["te"][1] > 0.9                                      # NDCG@10 after two iterations (0.95 at four)
 
 
-def test_config4_yahoo_shaped_share_of_one_gpu_k200():
+def test_config4_yahoo_shaped_share_of_one_gpu_k200(oracle):
     """configs[4]: rank 0's share (1/8 of the users) of the Yahoo!Music-shaped set, k = 200 -- item table (109 MB in fp32)
     beyond all L2s, users with tens of thousands of ratings."""
     R = synth.generate_fast("yahoo", users=(0, 225000))
     assert R.d2 == 136000 and 80_000_000 < R.nnz < 95_000_000 and int(np.diff(R.index).max()) > 30000
-    _property_run(R, 200, 5000.0)
+    _property_run(R, 200, 5000.0, oracle=oracle, nsample=1500)
 
 
 @pytest.mark.timeout(600)
