@@ -48,7 +48,7 @@
 
 #define PCR_P2P_MAXR 16
 
-#define PCR_P2P_MAGIC 0x50435250325033ull     // "PCRP2P3"
+#define PCR_P2P_MAGIC 0x50435250325034ull     // "PCRP2P4"
 struct P2PCtl {                               // in POSIX shared memory, created (O_EXCL) and zero-filled by rank 0
     std::atomic<uint64_t> magic;              // written LAST by rank 0: the block is ready
     uint64_t created_ns;                      // CLOCK_REALTIME at creation: a block older than the rendezvous time-out is a dead job's
@@ -58,6 +58,8 @@ struct P2PCtl {                               // in POSIX shared memory, created
     std::atomic<uint32_t> posted[PCR_P2P_MAXR];
     hipIpcMemHandle_t handle[PCR_P2P_MAXR];
     uint64_t bytes[PCR_P2P_MAXR];
+    hipIpcMemHandle_t ll_handle[PCR_P2P_MAXR];        // the boxes of the device-driven exchange (an allocation of their own)
+    uint64_t ll_bytes[PCR_P2P_MAXR];
 };
 
 template <typename X> struct P2PPtrs { const X* p[PCR_P2P_MAXR]; };
@@ -151,10 +153,15 @@ struct P2PComm {
     unsigned ll_seq[2] = {0, 0};
     int* ll_err = nullptr;
     static constexpr size_t LL_SCAL = 64;                     // doubles in the scalar set
+    // The boxes are FINE-GRAINED device memory (hipExtMallocWithFlags): words a peer stores over xGMI while this rank's kernel is
+    // polling must not be hidden behind lines this GPU's L2 holds for its own (coarse-grained) memory -- the reason RCCL keeps its
+    // LL buffers in such memory too.  (On one device every rank goes through the same L2, which is how the tests run.)
+    char* llbuf = nullptr;
+    char* ll_peer[PCR_P2P_MAXR] = {};
 
     static constexpr size_t SCAL_BYTES = 64 * sizeof(double);
-    size_t ll_bytes() const { return ll_outofs[1] ? ll_outofs[1] + LL_SCAL * 16 - ll_off[0] : 0; }
-    size_t total_bytes() const { return 2 * cap_bytes + 2 * slice_bytes + 2 * SCAL_BYTES + ll_bytes(); }
+    size_t ll_bytes() const { return ll_outofs[1] ? ll_outofs[1] + LL_SCAL * 16 : 0; }
+    size_t total_bytes() const { return 2 * cap_bytes + 2 * slice_bytes + 2 * SCAL_BYTES; }
     char* X_of(char* base, int par) const { return base + (size_t)par * cap_bytes; }
     char* Y_of(char* base, int par) const { return base + 2 * cap_bytes + (size_t)par * slice_bytes; }
     char* S_of(char* base, int par) const { return base + 2 * cap_bytes + 2 * slice_bytes + (size_t)par * SCAL_BYTES; }
@@ -233,7 +240,7 @@ struct P2PComm {
             ll_elems = std::min(elems_max, ll_max_bytes / elt);
             ll_per = (ll_elems + nranks - 1) / nranks;
             const size_t sper = (LL_SCAL + nranks - 1) / nranks;
-            ll_off[0] = 2 * cap_bytes + 2 * slice_bytes + 2 * SCAL_BYTES;
+            ll_off[0] = 0;
             ll_outofs[0] = ll_off[0] + (size_t)nranks * ll_per * W * 8;
             ll_off[1] = (ll_outofs[0] + ll_elems * W * 8 + 255) & ~(size_t)255;
             ll_outofs[1] = ll_off[1] + (size_t)nranks * sper * 2 * 8;
@@ -242,6 +249,15 @@ struct P2PComm {
         }
         if (hipMalloc((void**)&xbuf, total_bytes()) != hipSuccess) return fail("hipMalloc of the exchange buffer failed");
         if (hipMemset(xbuf, 0, total_bytes()) != hipSuccess) return fail("hipMemset of the exchange buffer failed");
+        if (ll_max_bytes) {
+            if (hipExtMallocWithFlags((void**)&llbuf, ll_bytes(), hipDeviceMallocFinegrained) != hipSuccess) {
+                (void)hipGetLastError();
+                if (hipMalloc((void**)&llbuf, ll_bytes()) != hipSuccess) return fail("hipMalloc of the exchange boxes failed");
+            }
+            if (hipMemset(llbuf, 0, ll_bytes()) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail("hipMemset of the exchange boxes failed");
+            if (hipIpcGetMemHandle(&ctl->ll_handle[rank], llbuf) != hipSuccess) return fail("hipIpcGetMemHandle of the exchange boxes failed");
+            ctl->ll_bytes[rank] = ll_bytes();
+        }
         // (dmabuf IPC: on hosts whose driver has no legacy IPC mode the process must run with HSA_ENABLE_IPC_MODE_LEGACY=0 --
         // an environment prerequisite of the ROCm runtime, listed in include/primalcr.h; the library itself reads no variable)
         if (hipIpcGetMemHandle(&ctl->handle[rank], xbuf) != hipSuccess) return fail("hipIpcGetMemHandle failed (on dmabuf-only hosts run with HSA_ENABLE_IPC_MODE_LEGACY=0)");
@@ -261,7 +277,15 @@ struct P2PComm {
             if (hipIpcOpenMemHandle(&p, ctl->handle[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess)
                 return fail("hipIpcOpenMemHandle of rank " + std::to_string(r) + "'s buffer failed");
             peer[r] = static_cast<char*>(p);
+            if (ll_max_bytes) {
+                if (ctl->ll_bytes[r] != ll_bytes()) return fail("ranks disagree on the size of the exchange boxes");
+                void* q = nullptr;
+                if (hipIpcOpenMemHandle(&q, ctl->ll_handle[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess)
+                    return fail("hipIpcOpenMemHandle of rank " + std::to_string(r) + "'s exchange boxes failed");
+                ll_peer[r] = static_cast<char*>(q);
+            }
         }
+        ll_peer[rank] = llbuf;
         ctl->attached.fetch_add(1);
         if (!barrier()) return false;
         if (rank == 0) shm_unlink(name);      // everyone is attached: the name can go (the mapping lives on)
@@ -279,8 +303,8 @@ struct P2PComm {
             const size_t per = scalars ? (LL_SCAL + nranks - 1) / nranks : ll_per;
             P2PLLPtrs ll;
             for (int r = 0; r < nranks; ++r) {
-                ll.inbox[r] = reinterpret_cast<unsigned long long*>(peer[r] + ll_off[set]);
-                ll.outbox[r] = reinterpret_cast<unsigned long long*>(peer[r] + ll_outofs[set]);
+                ll.inbox[r] = reinterpret_cast<unsigned long long*>(ll_peer[r] + ll_off[set]);
+                ll.outbox[r] = reinterpret_cast<unsigned long long*>(ll_peer[r] + ll_outofs[set]);
             }
             const unsigned sq = ++ll_seq[set];
             const int grid = (int)std::min<size_t>(128, (n + 255) / 256);
@@ -321,6 +345,8 @@ struct P2PComm {
     }
 
     void abort_peers() { if (ctl) ctl->error.store(1); }
+    // has a device-driven exchange of this rank run out of its poll budget?  (read after a stream synchronisation)
+    bool exchange_failed() { if (ll_err && *ll_err) { fail("a device-driven exchange timed out waiting for a peer rank"); return true; } return false; }
 
     // Closing rendezvous: the last all-reduce launched its reduce / gather kernel asynchronously after its last host barrier, so a
     // peer's kernel may still be reading this rank's buffers when this rank gets here.  Drain the device, then meet the peers
@@ -341,6 +367,8 @@ struct P2PComm {
     ~P2PComm() {
         finalize();
         for (int r = 0; r < nranks; ++r) if (r != rank && peer[r]) (void)hipIpcCloseMemHandle(peer[r]);
+        for (int r = 0; r < nranks; ++r) if (r != rank && ll_peer[r]) (void)hipIpcCloseMemHandle(ll_peer[r]);
+        if (llbuf) (void)hipFree(llbuf);
         if (xbuf) (void)hipFree(xbuf);
         if (ll_err) (void)hipHostFree(ll_err);
         if (ctl) munmap(ctl, sizeof(P2PCtl));

@@ -1221,6 +1221,7 @@ struct Solver final : pcr_solver {
     int fetch_scal(int count) {
         HIPCHK(hipMemcpyAsync(h_scal, d_scal.p, std::max(count, 44) * sizeof(double), hipMemcpyDeviceToHost, st));   // [32..44): the CG scalars
         HIPCHK(hipStreamSynchronize(st));
+        if (p2p && p2p->exchange_failed()) { pcr_set_error("p2p all-reduce: " + p2p->err); return PCR_ERR_COMM; }
         return PCR_OK;
     }
 
@@ -1515,6 +1516,7 @@ struct Solver final : pcr_solver {
     }
     int ustep_finish(double* now_obj, int64_t* info) {
         ustep_pending = false;
+        if (p2p && p2p->exchange_failed()) { pcr_set_error("p2p all-reduce: " + p2p->err); return PCR_ERR_COMM; }
 #ifdef PCR_USTEP_PROF
         {   // developer build only: per-phase shader-clock totals of thread 0 of every workgroup, by bin class
             static const char* ph[] = {"load", "g.sweep", "g.axpy", "cg.sddmm", "cg.sweep", "cg.axpy", "vec", "ls.sddmm", "ls.sort", "ls.obj", "store", "TOTAL", "wgs"};
