@@ -568,7 +568,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shape", choices=["ml1m", "netflix", "yahoo"], default="ml1m",
                     help="ml1m: configs[1], 6040 users per GPU (weak scaling); netflix: configs[3], 480189 x 17770, 100 M ratings in "
                          "total, user-sharded over the GPUs (strong scaling); yahoo: configs[4], 225000 users per GPU of the 1.8 M "

@@ -178,6 +178,8 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *   prepare_merged  1 / 0 = both LDS classes of k_prepare in one launch, or one launch per length class side by side
  *                   (default: merged below 4 M ratings per shard)
  *   lanes           concurrent streams for length classes (1 = none);  pipeline: 0 = host round trip after every U step
+ *   uplan           "<class>:<stream>,..." explicit placement in launch order (class = index in the built-in launch order, stream =
+ *                   lane 0..3 or 8 = the high-priority stream); a development knob
  *   eval_brute      1 = O(len^2) evaluator
  *   count_rows      1 = the U-step kernels count the rows of V they gather (pcr_solver_counter; a diagnostic that
  *                   costs the short-user classes 10-20 %, so off by default)

@@ -144,7 +144,7 @@ struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = -1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
         fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_ls_recur = 1, allreduce_chunks = 0, cluster_fence = 1, resort_window = 8, p2p_ll = 16;
-    std::string ubins;
+    std::string ubins, uplan;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
         sddmm_csc = pcr_tune_int("sddmm_csc", -1); sddmm_tile = pcr_tune_int("sddmm_tile", 0); sweep_wave_cap = pcr_tune_int("sweep_wave_cap", 0);
@@ -158,6 +158,7 @@ struct Tune {
         allreduce_chunks = pcr_tune_int("allreduce_chunks", 0); cluster_fence = pcr_tune_int("cluster_fence", 1);
         resort_window = pcr_tune_int("resort_window", 8); p2p_ll = pcr_tune_int("p2p_ll", 16);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
+        uplan.clear(); pcr_tune_get("uplan", &uplan);
     }
 };
 
@@ -919,12 +920,35 @@ struct Solver final : pcr_solver {
             // round-robin over the lanes, longest class first -- with the first two lanes swapped: the solver's stream takes
             // the SECOND class (on the headline shape the many-user 256-thread class that finishes last, and the shortest
             // class behind it), so the join at the end finds the other lanes' events already signalled (1.803 -> 1.785 ms)
+            // The classes beyond one per lane (the TAILS: short users, tens of microseconds) go behind the lanes in turn again, but
+            // behind the cluster class before the third lane, and behind the solver's stream last: on the headline shape its
+            // many-user class is the one that ends last (1.478 -> 1.450 ms with the last tail moved off it).
+            // (Re-placing the tails from per-class end times measured in the first U steps -- each behind the stream that ends
+            // first, tried against this plan for a few U steps -- found nothing better on the headline shape and picked worse
+            // placements on the Netflix and Yahoo shapes: 61 and 157 ms against 55 and 135 ms per U step.)
+            std::vector<int> ring;
+            for (int l = 0; l < nlane; ++l) ring.push_back(nlane >= 2 && l < 2 ? l ^ 1 : l);
+            std::vector<int> tail_ring;
+            for (int l : ring) if (l != 0) { tail_ring.push_back(l); if (tail_ring.size() == 1 && nhead) tail_ring.push_back(MAXLANE); }
+            tail_ring.push_back(0);
             for (size_t i = nhead; i < order.size(); ++i) {
-                int l = (int)((i - nhead) % nlane);
-                if (nlane >= 2 && l < 2) l ^= 1;
-                plan.push_back({(int)i, l});
+                const size_t j = i - nhead;
+                plan.push_back({(int)i, j < ring.size() ? ring[j] : tail_ring[(j - ring.size()) % tail_ring.size()]});
             }
         }
+        if (!tune.uplan.empty()) {                                // experiment: "<class index in launch order>:<lane, 8 = high priority>,..."
+            plan.clear();
+            const char* c = tune.uplan.c_str();
+            while (*c) {
+                char* e = nullptr;
+                const long i = strtol(c, &e, 10); if (*e != ':') break;
+                const long l = strtol(e + 1, &e, 10);
+                if (i >= 0 && i < (long)order.size() && ((l >= 0 && l < nlane) || l == MAXLANE)) plan.push_back({(int)i, (int)l});
+                c = *e ? e + 1 : e;
+            }
+        }
+        if (tune.debug && !plan_announced && (plan_announced = true))
+            for (auto& pr : plan) fprintf(stderr, "[pcr] U step: %s on stream %d\n", pname("ustep", *order[pr.first]).c_str(), pr.second);
         // nothing in flight on the solver's stream (the usual case: the V step has just read its objective back): the lanes
         // need no fork event, their kernels start as soon as they are launched
         const bool idle = hipStreamQuery(st) == hipSuccess;
@@ -945,6 +969,7 @@ struct Solver final : pcr_solver {
         HIPCHK(hipGetLastError());
         return PCR_OK;
     }
+    bool plan_announced = false;
     // the same, back to back on the solver's stream (for kernels shorter than a fork/join round trip)
     template <class F>
     int for_bins_seq(std::vector<Bin>& bs, const char* cls, F launch) {
