@@ -160,7 +160,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval2(const int64_t* __restrict__ upt
             else { li[p] = LiOps<LI>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
         }
         __syncthreads();
-        bitonic_sort<T, LI, BLOCK, true, !BIG>(key, li, npad);
+        bitonic_sort<T, LI, BLOCK, true, !BIG>(key, li, npad, n);
         // ---- mis-ordered pairs
         double bad = 0.0;
         for (int p = tid; p < n; p += BLOCK) {

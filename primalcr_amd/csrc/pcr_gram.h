@@ -284,7 +284,7 @@ __global__ __launch_bounds__(BLOCK) void k_ustep_gram(Shard<T> S, Geo geo, const
                 }
                 __syncthreads();
                 UPROF(6);
-                bitonic_sort<T, LI, BLOCK, false, true>(key, li, npad);                    // update_infor_ui (:684-726)
+                bitonic_sort<T, LI, BLOCK, false, true>(key, li, npad, n);                    // update_infor_ui (:684-726)
                 UPROF(8);
                 loss_new = block_objective<T, BLOCK>(key, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, nlev, n, Sx, red, strict);
                 obj_new = lambda / 2.0 * nn + loss_new;

@@ -198,35 +198,35 @@ template <> struct LiOps<uint64_t> {
     static __device__ __forceinline__ unsigned idx(uint64_t x) { return (unsigned)(x & 0xFFFFFFFFu); }
 };
 
-// ascending bitonic sort of (key, li) by (level, key); npad = pow2 >= n, padding carries the
-// maximum level so it sinks to the end.  Tie order among equal (level, key) is irrelevant to
-// every sum computed from the order (the reference's std::sort is unstable too).
+// ascending bitonic sort of (key, li)[0, n) by (level, key); npad = pow2 >= n.  The network is the NORMALISED one: every
+// compare-exchange orders its pair ascending (the first stage of every merge pairs i with its mirror image in the 2 j-block
+// instead of reversing the direction of every other block), so the elements [n, npad) are VIRTUAL -- "+infinity" that no exchange
+// would ever move: a pair that reaches beyond n is skipped, and the arrays need n entries, not npad (the longest user of the
+// headline shape has 2634 ratings: 42 instead of 54 KB of LDS per workgroup of k_prepare_all, three workgroups per CU instead
+// of two).  Tie order among equal (level, key) is irrelevant to every sum computed from the order (the reference's std::sort
+// is unstable too).
 // TIE = true additionally orders equal (level, key) by DESCENDING index (k_eval2: the lowest index then
 // sits at the end of its run and is taken first).
 // Compare-exchange network over LDS.  With stride j <= 64 the pairs a wave works on (64 consecutive t) lie in ITS OWN
-// aligned 128-element chunk, in every such stage alike, so between two short-stride stages a wave-level ordering point
-// replaces the workgroup barrier: of the 78 stages of a 4096-element sort only 21 need __syncthreads().
+// aligned 128-element chunk, in every such stage alike (the mirror pairs of a merge of 2 j <= 128 elements too), so between two
+// short-stride stages a wave-level ordering point replaces the workgroup barrier: of the 78 stages of a 4096-element sort only
+// 21 need __syncthreads().
 // (INLDS = false: the arrays live in global scratch, every stage keeps the workgroup barrier.)
 template <typename T, typename LI, int BLOCK, bool TIE = false, bool INLDS = true>
-__device__ __forceinline__ void bitonic_sort(T* key, LI* li, int npad) {
+__device__ __forceinline__ void bitonic_sort(T* key, LI* li, int npad, int n) {
     const int tid = btid<BLOCK>();
     for (int k = 2; k <= npad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = tid; t < (npad >> 1); t += BLOCK) {
                 const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int l = i | j;
-                const bool up = ((i & k) == 0);
+                const int l = (j == (k >> 1)) ? (i ^ (k - 1)) : (i | j);
+                if (l >= n) continue;                                 // (i < l: the pair's upper element is virtual)
                 T ka = key[i], kb = key[l];
                 LI la = li[i], lb = li[l];
                 unsigned va = LiOps<LI>::lev(la), vb = LiOps<LI>::lev(lb);
                 bool b_lt_a = (vb < va) || (vb == va && kb < ka);
-                bool a_lt_b = (va < vb) || (va == vb && ka < kb);
-                if (TIE && va == vb && ka == kb) {
-                    const unsigned ia = LiOps<LI>::idx(la), ib = LiOps<LI>::idx(lb);
-                    b_lt_a = ib > ia; a_lt_b = ia > ib;
-                }
-                bool sw = up ? b_lt_a : a_lt_b;
-                if (sw) { key[i] = kb; key[l] = ka; li[i] = lb; li[l] = la; }
+                if (TIE && va == vb && ka == kb) b_lt_a = LiOps<LI>::idx(lb) > LiOps<LI>::idx(la);
+                if (b_lt_a) { key[i] = kb; key[l] = ka; li[i] = lb; li[l] = la; }
             }
             const int jnext = j > 1 ? (j >> 1) : k;                 // stride of the next stage (first stage of the next phase: k)
             const bool last = (j == 1 && k == npad);

@@ -1064,7 +1064,7 @@ struct Solver final : pcr_solver {
         RC(launch_sddmm(Vm, d_item.p, d_mcsr.p));
         auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
-            const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
+            const int cap_pad = b.big ? host_pow2(b.cap) : b.cap, rsc = b.max_lev + 2;     // (LDS: the sort pads virtually)
             const size_t bigb = prepare_bytes<T>(b.cap, cap_pad, rsc, b.big ? 8 : 4);
             const size_t lds = small_common(b.block) + (b.big ? 0 : bigb);
             const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
@@ -1080,7 +1080,7 @@ struct Solver final : pcr_solver {
             // both LDS-resident classes (<= 256 ratings: one wave per user; <= 4096: one workgroup) in one launch on the
             // solver's stream (k_prepare_all): no fork / join; only users beyond 4096 ratings take a second launch
             const int na = (int)ba.users.size(), nb = (int)bb.users.size();
-            const int cpa = host_pow2(ba.cap), cpb = host_pow2(bb.cap), rsa = ba.max_lev + 2, rsb = bb.max_lev + 2;
+            const int cpa = ba.cap, cpb = bb.cap, rsa = ba.max_lev + 2, rsb = bb.max_lev + 2;          // (the sort pads virtually)
             const size_t wb = (small_common(64) + prepare_bytes<T>(ba.cap, cpa, rsa, 4) + 15) & ~(size_t)15;
             // workgroup size of the launch = the long users' teams: 512 threads (1024 measured slower: NOTES.md)
             const int wbs = 512, wpb = wbs / 64;

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && UNR == 4 && !RES && K == 1 
                 // (tmp lives in the prefix-sum array, the second key array in ms0: the gradient point's scores are not needed again)
                 bool resorted = false;
                 if constexpr (!BIG) resorted = resort_window<T, LI, BLOCK>(key, li, [&](int p) { return (int)lv0[p]; }, rs, n, reinterpret_cast<int*>(Sx), ms0, S.resort_d, reinterpret_cast<int*>(red));
-                if (!resorted) bitonic_sort<T, LI, BLOCK, false, !BIG>(key, li, npad);
+                if (!resorted) bitonic_sort<T, LI, BLOCK, false, !BIG>(key, li, npad, n);
                 UPROF(8);
                 // objective_u_new (:542-573) of the tried point.  With the LDS window copy (free again: the CG is over) its windows
                 // are searched ONCE, into that copy: the loss reads them (block_objective_win) and the state store below copies

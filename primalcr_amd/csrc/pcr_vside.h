@@ -128,7 +128,7 @@ template <typename T> struct LiSel<T, true> { typedef uint64_t type; };
 
 template <typename T>
 static inline size_t prepare_bytes(int cap, int cap_pad, int rs_cap, int li_bytes) {
-    // only the sort arrays need the power-of-two padding
+    // (cap_pad: what the caller sizes the sort arrays with -- cap is enough, the sort pads virtually)
     return carve_bytes(cap_pad, sizeof(T)) + carve_bytes(cap_pad, li_bytes) + carve_bytes(cap + 1, 8) + carve_bytes(rs_cap, 4);
 }
 
@@ -171,11 +171,9 @@ __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, cons
         // grouped already, and from the third iteration on nearly (level, m)-sorted for the new scores too: resort_window)
         const bool from_prev = !BIG && S.resort_d > 0 && S.prev_valid;
 #pragma unroll 4
-        for (int p = tid; p < npad; p += BLOCK) {
-            if (p < n) {
-                if (from_prev) { const unsigned idx = (unsigned)S.sidx[s0 + p]; li[p] = LiOps<LI>::pack(S.slvl[s0 + p], idx); key[p] = m_in[s0 + idx]; }
-                else { li[p] = LiOps<LI>::pack(S.lvl[s0 + p], (unsigned)p); key[p] = m_in[s0 + p]; }
-            } else { li[p] = LiOps<LI>::pack(0xFFFFu, (unsigned)p); key[p] = (T)0; }
+        for (int p = tid; p < n; p += BLOCK) {                       // (no padding: the sort's elements beyond n are virtual)
+            if (from_prev) { const unsigned idx = (unsigned)S.sidx[s0 + p]; li[p] = LiOps<LI>::pack(S.slvl[s0 + p], idx); key[p] = m_in[s0 + idx]; }
+            else { li[p] = LiOps<LI>::pack(S.lvl[s0 + p], (unsigned)p); key[p] = m_in[s0 + p]; }
         }
         bsync<BLOCK>();
         PPROF(0);
@@ -185,7 +183,7 @@ __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, cons
             if (from_prev)
                 resorted = resort_window<T, LI, BLOCK>(key, li, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, n, reinterpret_cast<int*>(Sx),
                                                        sizeof(T) == 4 ? reinterpret_cast<T*>(reinterpret_cast<int*>(Sx) + n) : (T*)nullptr, S.resort_d, reinterpret_cast<int*>(red));
-        if (!resorted) bitonic_sort<T, LI, BLOCK, false, !BIG>(key, li, npad);
+        if (!resorted) bitonic_sort<T, LI, BLOCK, false, !BIG>(key, li, npad, n);
         PPROF(1);
         for (int p = tid; p < n; p += BLOCK) {
             const LI x = li[p];
