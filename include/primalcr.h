@@ -171,6 +171,8 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *   ubins           "cap:block:resident,..." length classes of the U step below 1024 ratings
  *   spmm_tiles, spmm_chunk, sddmm_tile, sddmm_csc   tiling of the rating-parallel kernels
  *   sweep_wave_cap  ratings up to which a sweep gives a user one wave
+ *   sweep_dense     0 = k_vsweep_all always as the unbounded symbol (default 1: the 64-VGPR symbol, four workgroups per CU, where the
+ *                   longest user's arrays fit 40 KB of LDS)
  *   sweep_prefetch  0 = the sweeps keep one round of per-rating loads in flight instead of four (default 1)
  *   window_cache    0 = sweeps search their hinge windows instead of caching them
  *   win16           0 = 32-bit window-cache entries even when every user has fewer than 65536 ratings (default 1: 16-bit)

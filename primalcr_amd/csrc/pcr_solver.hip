@@ -143,7 +143,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = -1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
-        fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_ls_recur = 1, allreduce_chunks = 0, cluster_fence = 1, resort_window = 8, p2p_ll = 16;
+        fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_ls_recur = 1, allreduce_chunks = 0, cluster_fence = 1, resort_window = 8, p2p_ll = 16, sweep_dense = 1;
     std::string ubins, uplan;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -156,7 +156,7 @@ struct Tune {
         ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); win16 = pcr_tune_int("win16", 1); sweep_prefetch = pcr_tune_int("sweep_prefetch", -1);
         ustep_ls_recur = pcr_tune_int("ustep_ls_recur", 1);
         allreduce_chunks = pcr_tune_int("allreduce_chunks", 0); cluster_fence = pcr_tune_int("cluster_fence", 1);
-        resort_window = pcr_tune_int("resort_window", 8); p2p_ll = pcr_tune_int("p2p_ll", 16);
+        resort_window = pcr_tune_int("resort_window", 8); p2p_ll = pcr_tune_int("p2p_ll", 16); sweep_dense = pcr_tune_int("sweep_dense", 1);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
         uplan.clear(); pcr_tune_get("uplan", &uplan);
     }
@@ -843,6 +843,8 @@ struct Solver final : pcr_solver {
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep<T, 512, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, false, 512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_vsweep_all<T, true, 512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024));
 #define UL(BL, BG, KK, RS, UN) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, BL, BG, KK, RS, UN>, hipFuncAttributeMaxDynamicSharedMemorySize, lim))
         UL(64, false, 1, true, 4); UL(64, false, 1, false, 4); UL(256, false, 1, false, 4);
 #define UL1(BL) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, BL, false, 1, false, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim))
@@ -1140,9 +1142,11 @@ struct Solver final : pcr_solver {
             const int grid = nb + cdiv(na, wpb);
             {
                 ProfScope ps(this, std::string(hv ? "vhv" : "vgrad") + "/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
-#define LVA(HV, WBS) hipLaunchKernelGGL((k_vsweep_all<T, HV, WBS>), dim3(grid), dim3(WBS), lds, st, sh, ba.d_users.p, na, ba.cap, rsa, wb, \
+#define LVA(HV, WBS, MW) hipLaunchKernelGGL((k_vsweep_all<T, HV, WBS, MW>), dim3(grid), dim3(WBS), lds, st, sh, ba.d_users.p, na, ba.cap, rsa, wb, \
                                         bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip, bc)
-                if (hv) LVA(true, 512); else LVA(false, 512);
+                // (four workgroups per CU where the longest user's arrays fit a quarter of the LDS: the 64-VGPR symbol)
+                const bool dense = lds <= (size_t)40 * 1024 && tune.sweep_dense;
+                if (hv) { if (dense) LVA(true, 512, 8); else LVA(true, 512, 1); } else { if (dense) LVA(false, 512, 8); else LVA(false, 512, 1); }
 #undef LVA
             }
             if (!sbins[2].users.empty()) { ProfScope ps(this, pname(hv ? "vhv" : "vgrad", sbins[2]), st, sbins[2].nnz, (int64_t)sbins[2].users.size()); fn(sbins[2], st); }

@@ -381,8 +381,10 @@ __global__ __launch_bounds__(256) void k_vsweep_wave(Shard<T> S, const int32_t* 
 // Both LDS-resident classes in ONE launch of 512-thread workgroups (the two sweeps are each shorter than a launch
 // round trip, so back to back they cost two kernel latencies and side by side a fork/join): workgroups [0, nblk_b)
 // take the long users of list B one per workgroup, the others take eight short users of list A, one per wave.
-template <typename T, bool HV, int WB>
-__global__ __launch_bounds__(WB) void k_vsweep_all(Shard<T> S, const int32_t* __restrict__ users_a, int nusers_a, int cap_a,
+// MINW: the minimum-waves-per-SIMD bound of the symbol (8: at most 64 VGPRs -- four 512-thread workgroups per CU instead of three --
+// which also caps the launch's dynamic LDS at a quarter of a CU's: for shards whose longest users fit 40 KB; 1: no bound)
+template <typename T, bool HV, int WB, int MINW = 1>
+__global__ __launch_bounds__(WB, MINW) void k_vsweep_all(Shard<T> S, const int32_t* __restrict__ users_a, int nusers_a, int cap_a,
                                                     int rs_cap_a, size_t wave_bytes, const int32_t* __restrict__ users_b,
                                                     int nusers_b, int cap_b, int rs_cap_b, int nblk_b,
                                                     const T* __restrict__ bsrc, T* __restrict__ c_out, int strict, const int* skip, int b_csr) {
