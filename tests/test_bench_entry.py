@@ -133,9 +133,9 @@ def test_every_ustep_class_is_one_kernel_symbol_in_the_committed_profiles():
     import csv
     sys.path.insert(0, ROOT)
     import bench
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r03_c_bench.json")).read().strip().split("\n")[-1])
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r03_d_bench.json")).read().strip().split("\n")[-1])
     for shape, rec in (("ml1m", line), ("netflix", line["netflix"])):
-        names = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r03_c_{shape}_f32_kernel_stats.csv")))
+        names = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r03_d_{shape}_f32_kernel_stats.csv")))
                  if r["Name"].startswith("void k_ustep<float")]
         slots = [k for k in rec["kernels"] if k.startswith("ustep/")]
         assert len(slots) >= 6 and len(names) >= len(slots)
