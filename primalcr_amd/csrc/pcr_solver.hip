@@ -948,6 +948,9 @@ struct Solver final : pcr_solver {
                 if (i >= 0 && i < (long)order.size() && ((l >= 0 && l < nlane) || l == MAXLANE)) plan.push_back({(int)i, (int)l});
                 c = *e ? e + 1 : e;
             }
+            std::vector<int> seen(order.size(), 0);
+            for (auto& pr : plan) seen[pr.first]++;
+            for (int n1 : seen) if (n1 != 1) { pcr_set_error("bad pcr_tune uplan: every length class (0 .. " + std::to_string(order.size() - 1) + ") once, streams 0 .. " + std::to_string(nlane - 1) + " or 8"); return PCR_ERR_ARG; }
         }
         if (tune.debug && !plan_announced && (plan_announced = true))
             for (auto& pr : plan) fprintf(stderr, "[pcr] U step: %s on stream %d\n", pname("ustep", *order[pr.first]).c_str(), pr.second);

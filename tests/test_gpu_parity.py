@@ -296,6 +296,8 @@ VARIANTS = [
     {"cluster_users": "64"}, {"cluster_users": "64", "cluster_fence": "0"},   # as many clusters as the chip holds (members on every XCD)
     {"resort_window": "0"}, {"resort_window": "2"}, {"resort_window": "64"},   # the sorts' nearly-sorted fast path: off, narrow, widest
     {"spmm_tiles": "2"}, {"spmm_tiles": "4"},                # tiles bound to groups of 4 / 2 XCDs
+    {"sweep_dense": "0"},                                    # k_vsweep_all as the unbounded symbol (three workgroups per CU)
+    {"uplan": "0:0,1:1,2:2,3:3,4:8,5:1,6:0"}, {"uplan": "6:8,5:3,4:2,3:1,2:0,1:8,0:0"},   # other stream placements / launch orders of the U step's classes
 ]
 
 
