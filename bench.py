@@ -263,7 +263,7 @@ def make_shard(shape, job, users=None, nnz=None):
     return R, u0, total, "strong", int(index[-1])
 
 
-def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name, count_rows=False):
+def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name, count_rows=False, cold_start=True):
     """One solver, `warmup` untimed + exactly `steps` timed outer iterations (barrier + synchronize on both sides, MAX over
     ranks), then the quality after warmup + steps iterations."""
     import primalcr_amd as pcr
@@ -286,7 +286,21 @@ def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name
         if N > 1:
             dist.barrier()
 
-    objs = [rec["obj"] for rec in s.iterate(warmup)]
+    # Cold start: iterations 1..min(5, W) of the warm-up, straight from pcr_initial, on the same clock as the timed steps (the
+    # sorts' nearly-sorted fast path has nothing to start from yet; the reference's default run is -t 10 from cold).  One
+    # untimed iteration first, then back to the initial point: the first launch of every kernel loads its code object.
+    cold = None
+    if warmup >= 1 and cold_start:
+        s.iterate(1)
+        s.set_factors_local(pcr.initial_rows(total, r, first, s.n_users), pcr.initial(d2, r))
+    n_cold = min(5, warmup)
+    barrier()
+    tc = time.perf_counter()
+    objs = [rec["obj"] for rec in s.iterate(n_cold)]
+    barrier()
+    if n_cold:
+        cold = {"iterations": n_cold, "ms_per_step": 1e3 * job.allmax(time.perf_counter() - tc) / n_cold}
+    objs += [rec["obj"] for rec in s.iterate(warmup - n_cold)]
     prof_period = 0
     if profile:
         # sampled: every n-th launch of each kernel carries an event pair (an event pair costs ~3 us of queue time: every 4th
@@ -312,7 +326,7 @@ def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name
     rows_by_class = s.class_row_gathers() if count_rows else {}
     te_err, te_ndcg = s.evaluate(1, 10)
     tr_err, tr_ndcg = s.evaluate(0, 10)
-    out = dict(secs=secs, objs=objs, inner=inner, prof=prof, launches=launches, scope=scope, prof_period=prof_period,
+    out = dict(secs=secs, objs=objs, inner=inner, prof=prof, launches=launches, scope=scope, prof_period=prof_period, cold=cold,
                u_rows=s.counter("ustep_row_gathers") - rows0, rows_by_class=rows_by_class, steps=steps,
                te=(te_err, te_ndcg), tr=(tr_err, tr_ndcg), comm_nranks=s.comm_nranks(), shard=(s.first_user, s.n_users, s.nnz_local))
     s.close()
@@ -335,8 +349,10 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False):
 
     def binding(cls, gb):
         lv, ce, h = ("l2-gather", GATHER_CEILING_GBS["l2-gather"], 1.0) if tiled(cls) else (lvl_v, ceil_v, l2share_v)
-        return {"level": lv, "l2_share": h, "ceiling_GBs": ce, "achieved_GBs": round(gb, 1), "frac": round(gb / ce, 4)}
-    u_rows = (rows_run or {}).get("u_rows", 0)
+        # gb is None: the rows were not counted (--no-rows) -- an unmeasured figure is null, never 0.0
+        return {"level": lv, "l2_share": h, "ceiling_GBs": ce, "achieved_GBs": None if gb is None else round(gb, 1),
+                "frac": None if gb is None else round(gb / ce, 4)}
+    u_rows = rows_run["u_rows"] if rows_run else None             # None: the U step's row counter was off (--no-rows)
     rows_by_class = (rows_run or {}).get("rows_by_class", {})
     roof, roof_phase, kernels = None, {}, {}
     if prof:
@@ -403,16 +419,17 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False):
         # phases: algorithmic bytes of everything a phase launches per step / its wall time per step
         def phase(names, wall_ms_per_step, gather_bytes, cls):
             ab = sum(kernels[k]["algorithmic_bytes"] * run["launches"][k] / steps for k in names)
-            gb = gather_bytes / (wall_ms_per_step / 1e3) / 1e9
+            gb = None if gather_bytes is None else gather_bytes / (wall_ms_per_step / 1e3) / 1e9
             return {"bound": "hbm", "algorithmic_bytes_per_step": int(ab), "wall_us_per_step": round(1e3 * wall_ms_per_step, 1),
                     "achieved": round(ab / (wall_ms_per_step / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ab / (wall_ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
                     "share_of_step": round(wall_ms_per_step / (1e3 * secs / steps), 4),
-                    "gathered_row_bytes_per_step": int(gather_bytes), "gather_GBs": round(gb, 1), "binding": binding(cls, gb)}
+                    "gathered_row_bytes_per_step": None if gb is None else int(gather_bytes),
+                    "gather_GBs": None if gb is None else round(gb, 1), "binding": binding(cls, gb)}
         un = [k for k in kernels if k.startswith("ustep/")]
         if un and prof.get("wall:ustep", (0, 0))[1]:
             wm, wn = prof["wall:ustep"]
-            u_gather = u_rows / steps / N * r * esz           # this rank's share (the counter is the all-rank total)
+            u_gather = None if u_rows is None else u_rows / steps / N * r * esz     # this rank's share (the counter is the all-rank total)
             roof_phase["u_step"] = dict(phase(un, wm / wn, u_gather, "ustep"), kernels=un,
                                         note="all length classes of k_ustep, launched side by side: sum of their algorithmic bytes / fork..join wall "
                                              "time on the solver's stream; gather_GBs = rows of V actually gathered (counted in the kernel: per user "
@@ -447,19 +464,35 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False):
     # U side per rating 1 (gradient) + 2 per CG iteration + 1 per line-search try.
     G = esz * r * nnz
     n_cg_u, n_ls_u = inner["cg_u"] / steps / max(d1, 1), inner["ls_u"] / steps / max(d1, 1)
-    u_half_passes = u_rows / steps / max(nnz, 1)       # counted in k_ustep: rating-weighted, not user-averaged
-    gather_passes = (n_ls + n_cg) + (1 + n_cg) + u_half_passes
-    gg = gather_passes * G / (secs / steps) / 1e9
-    gather = {"bytes_per_half_pass": int(G), "half_passes_per_iteration": round(gather_passes, 2),
-              "u_side_half_passes": round(u_half_passes, 2), "u_side_user_average": round(1 + 2 * n_cg_u + n_ls_u, 2),
-              "achieved_GBs": round(gg, 1), "item_table_bytes": int(v_table), "level": lvl_v, "l2_share": l2share_v,
-              "ceiling_GBs": ceil_v * N, "frac": round(gg / (ceil_v * N), 4),
+    v_passes = (n_ls + n_cg) + (1 + n_cg)
+    if u_rows is None:                                 # --no-rows: the U side's passes are unknown -- no whole-iteration figure
+        u_half_passes = gather_passes = gg = None
+    else:
+        u_half_passes = u_rows / steps / max(nnz, 1)   # counted in k_ustep: rating-weighted, not user-averaged
+        gather_passes = v_passes + u_half_passes
+        gg = gather_passes * G / (secs / steps) / 1e9
+    rnd = lambda x, n: None if x is None else round(x, n)
+    gather = {"bytes_per_half_pass": int(G), "half_passes_per_iteration": rnd(gather_passes, 2), "v_side_half_passes": round(v_passes, 2),
+              "u_side_half_passes": rnd(u_half_passes, 2), "u_side_user_average": round(1 + 2 * n_cg_u + n_ls_u, 2),
+              "u_side_counted": u_rows is not None,
+              "achieved_GBs": rnd(gg, 1), "item_table_bytes": int(v_table), "level": lvl_v, "l2_share": l2share_v,
+              "ceiling_GBs": ceil_v * N, "frac": None if gg is None else round(gg / (ceil_v * N), 4),
               "note": "row gathers (one esz*r-byte factor row per rating and half-pass) sustained over the WHOLE iteration, all "
                       "ranks, against the ceiling of the level the item table of this shape lives in (U side: rows counted by the "
                       "kernel -- long users run more CG iterations than the user average, so the rating-weighted pass count is the "
                       "higher one)"}
+    # N > 1: what one step spends in its exchange steps (the "allreduce" slot: event pairs around ncclAllReduce / the
+    # peer-to-peer exchange on the stream they are queued on) -- so that a scaling curve can be decomposed
+    exchange = None
+    if N > 1 and prof.get("allreduce", (0, 0))[1]:
+        ms, n = prof["allreduce"]
+        per_step = run["launches"]["allreduce"] / steps
+        exchange = {"allreduce_us_avg": round(1e3 * ms / n, 2), "allreduces_per_step": round(per_step, 2), "timed": int(n),
+                    "vector_bytes": int(d2 * ld * esz), "vector_allreduces_per_step": round(1 + n_cg, 2),
+                    "scalar_allreduces_per_step": round(per_step - (1 + n_cg) * wl.get("n_rng", 1), 2),
+                    "us_per_step": round(1e3 * ms / n * per_step, 1), "share_of_step": round(ms / n * per_step / (1e3 * secs / steps), 4)}
     return dict(roofline=roof, roofline_phase=roof_phase, roofline_iteration=it_roof, gather=gather, kernels=kernels,
-                passes_per_step=passes)
+                passes_per_step=passes, exchange=exchange)
 
 
 def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=("f32", "f64"), profile=True, cpu=True,
@@ -491,7 +524,7 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
         # per user, so it is kept out of the timed run): the rating-weighted pass count of the U step, per length class
         runs[pn]["rows"] = None
         if not args.no_rows:
-            rr = timed_run(job, ds, shard, R.d2, r, lam, prec, steps, warmup, False, shm, count_rows=True)
+            rr = timed_run(job, ds, shard, R.d2, r, lam, prec, steps, warmup, False, shm, count_rows=True, cold_start=False)
             runs[pn]["rows"] = dict(u_rows=rr["u_rows"], rows_by_class=rr["rows_by_class"],
                                     launches_counted={k: (warmup + steps) for k in rr["rows_by_class"]})
     bounds = None
@@ -520,7 +553,8 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
         # SURVEY 8d, kernel-level figure: ordered pairs swept per second over the EXECUTED sweep passes of a step
         # (V side: gradient + Hessian-vector products + line-search objectives; U side the same per user, averaged)
         "passes_per_step": an["passes_per_step"], "sweep_pairs_per_s": value * an["passes_per_step"],
-        "comm_nranks": run["comm_nranks"], "shards": bounds,
+        "comm_nranks": run["comm_nranks"], "shards": bounds, "exchange_profile": an["exchange"],
+        "cold_start": run["cold"], "ms_per_step_first5": run["cold"]["ms_per_step"] if run["cold"] and run["cold"]["iterations"] == 5 else None,
         "roofline": an["roofline"], "roofline_phase": an["roofline_phase"], "roofline_iteration": an["roofline_iteration"],
         "gather": an["gather"], "kernels": an["kernels"],
     }
@@ -528,7 +562,7 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
         # the reference computes in fp64 throughout: the same K steps with fp64 storage, same clock, same barriers
         r64 = runs["f64"]
         a64 = analyse(r64, r64["rows"], wl, "f64", N, f"{shape}:f64" if tkey else None)
-        rec["f64"] = {"dtype": "f64", "ms_per_step": 1e3 * r64["secs"] / steps, "value": n_pairs * steps / r64["secs"],
+        rec["f64"] = {"dtype": "f64", "ms_per_step": 1e3 * r64["secs"] / steps, "value": n_pairs * steps / r64["secs"], "cold_start": r64["cold"],
                       "unit": "pairs/s", "ndcg10_test": r64["te"][1], "pairwise_error_test": r64["te"][0],
                       "objective": r64["objs"][-1], "inner_per_step": {k: v / steps for k, v in r64["inner"].items()},
                       "roofline": a64["roofline"], "roofline_phase": a64["roofline_phase"], "roofline_iteration": a64["roofline_iteration"],
@@ -544,6 +578,121 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
     else:
         rec["cpu_baseline"] = None
     return rec
+
+
+LINE_CAP = 4096        # bytes: the driver keeps ~8.6 KB of stdout; round 3's 45 KB line came back unparsed
+
+
+def _r(x, n=4):
+    """Round to n significant-ish digits for the compact line (None stays None)."""
+    if x is None or isinstance(x, (bool, str)):
+        return x
+    if isinstance(x, int):
+        return x
+    return float(f"{x:.{n}g}")
+
+
+def _roof(rf):
+    """The roofline object the contract asks for, without its prose."""
+    if not rf:
+        return None
+    b = rf.get("binding") or {}
+    src = rf.get("traffic_source")
+    return {"bound": rf["bound"], "kernel": rf.get("kernel"), "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"],
+            "frac": rf["frac"], "traffic": rf.get("traffic"), "traffic_over_algorithmic": rf.get("traffic_over_algorithmic"),
+            "traffic_source": None if not src else ("live-pmc" if src.startswith("live") else "stored-pmc:" + src.split(" ")[0]),
+            "avg_launch_us": rf.get("avg_launch_us"), "launches_timed": rf.get("launches_timed"),
+            "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"), "share_of_gpu_time": rf.get("share_of_gpu_time"),
+            "binding": {"level": b.get("level"), "ceiling_GBs": b.get("ceiling_GBs"), "achieved_GBs": b.get("achieved_GBs"),
+                        "frac": b.get("frac")} if b else None}
+
+
+def _cpu(cb):
+    if not cb:
+        return None
+    o = {"value": _r(cb["value"], 6), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:200],
+         "s_per_iter": _r(cb.get("s_per_iter"), 5)}
+    st = cb.get("single_thread")
+    if st:
+        o["single_thread"] = {"value": _r(st["value"], 6), "cores": 1, "s_per_iter": _r(st.get("s_per_iter"), 5)}
+    return o
+
+
+def _phases(rp):
+    o = {}
+    for k, v in (rp or {}).items():
+        o[k] = {"wall_us": v.get("wall_us_per_step"), "share_of_step": v.get("share_of_step"), "frac": v.get("frac"),
+                "gather_GBs": v.get("gather_GBs"), "gather_frac": (v.get("binding") or {}).get("frac")}
+    return o or None
+
+
+def _top_kernels(kernels, n=5):
+    top = sorted((kernels or {}).items(), key=lambda kv: -kv[1].get("gpu_time_share", 0))[:n]
+    return [{"slot": k, "avg_us": v["avg_us"], "share": v["gpu_time_share"], "frac": v["frac_hbm_peak"],
+             "traffic_x": v.get("traffic_over_algorithmic")} for k, v in top] or None
+
+
+def compact_line(full, full_record_path=None):
+    """The ONE stdout line of a bench run, built from the full record: the contract's header, `roofline`, `cpu_baseline`, the
+    quality figures, the fp64 and Netflix-shaped legs as a few numbers each -- and nothing that grows with the number of
+    kernels.  Always below LINE_CAP bytes: optional blocks are dropped, in a fixed order, if a future field pushes it over."""
+    g = full.get
+    cfg = dict(g("config") or {})
+    line = {k: g(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                              "vs_baseline", "dtype", "data")}
+    line["config"] = cfg
+    line["roofline"] = _roof(g("roofline"))
+    line["cpu_baseline"] = _cpu(g("cpu_baseline"))
+    line["speedup_vs_cpu_baseline"] = _r(g("speedup_vs_cpu_baseline"))
+    for k in ("ndcg10_test", "pairwise_error_test"):
+        line[k] = _r(g(k), 6)
+    line["objective"] = _r(g("objective"), 9)
+    line["ms_per_step_first5"] = _r(g("ms_per_step_first5"), 5)
+    line["cold_start"] = {k: _r(v, 5) for k, v in g("cold_start").items()} if g("cold_start") else None
+    line["inner_per_step"] = g("inner_per_step")
+    line["sweep_pairs_per_s"] = _r(g("sweep_pairs_per_s"), 5)
+    line["comm_nranks"] = g("comm_nranks")
+    if g("exchange_profile"):
+        line["exchange"] = g("exchange_profile")
+    if g("shards"):
+        line["shards"] = g("shards") if len(g("shards")) <= 8 else None
+    it, ga = g("roofline_iteration") or {}, g("gather") or {}
+    line["roofline_iteration"] = {"algorithmic_bytes": it.get("algorithmic_bytes_per_iteration"), "achieved": it.get("achieved"),
+                                  "frac": it.get("frac")} if it else None
+    line["gather"] = {"level": ga.get("level"), "half_passes": ga.get("half_passes_per_iteration"), "achieved_GBs": ga.get("achieved_GBs"),
+                      "ceiling_GBs": ga.get("ceiling_GBs"), "frac": ga.get("frac"), "u_side_counted": ga.get("u_side_counted", True)} if ga else None
+    line["roofline_phase"] = _phases(g("roofline_phase"))
+    line["top_kernels"] = _top_kernels(g("kernels"))
+    f64 = g("f64")
+    if f64:
+        rf = f64.get("roofline") or {}
+        line["f64"] = {"ms_per_step": _r(f64["ms_per_step"], 6), "value": _r(f64["value"], 7), "ndcg10_test": _r(f64.get("ndcg10_test"), 6),
+                       "ms_per_step_first5": _r((f64.get("cold_start") or {}).get("ms_per_step"), 5),
+                       "roofline": {"kernel": rf.get("kernel"), "frac": rf.get("frac"), "avg_launch_us": rf.get("avg_launch_us")} if rf else None,
+                       "gather_frac": (f64.get("gather") or {}).get("frac")}
+    nf = g("netflix")
+    if nf:
+        rf, nf64, ncb = nf.get("roofline") or {}, nf.get("f64") or {}, nf.get("cpu_baseline") or {}
+        line["netflix"] = {"workload": "configs[3] Netflix-shaped 480189 x 17770, 100 M ratings, k=100, 1 GPU",
+                           "ms_per_step": _r(nf["ms_per_step"], 6), "value": _r(nf["value"], 7), "steps": nf.get("steps"), "warmup": nf.get("warmup"),
+                           "ndcg10_test": _r(nf.get("ndcg10_test"), 6), "pairwise_error_test": _r(nf.get("pairwise_error_test"), 6),
+                           "roofline": {"kernel": rf.get("kernel"), "frac": rf.get("frac"), "avg_launch_us": rf.get("avg_launch_us"),
+                                        "traffic_over_algorithmic": rf.get("traffic_over_algorithmic")} if rf else None,
+                           "gather": {"level": (nf.get("gather") or {}).get("level"), "frac": (nf.get("gather") or {}).get("frac")},
+                           "f64_ms_per_step": _r(nf64.get("ms_per_step"), 6),
+                           "cpu_baseline": {"value": _r(ncb.get("value"), 6), "cores": ncb.get("cores"), "kind": ncb.get("kind"),
+                                            "s_per_iter": _r(ncb.get("s_per_iter"), 5)} if ncb else None}
+    line["full_record"] = full_record_path
+    # the cap: drop optional blocks (least important first) rather than ever print a line the driver cannot keep
+    size = lambda: len(json.dumps(line, separators=(",", ":")))
+    if size() >= LINE_CAP and len(cfg.get("workload") or "") > 240:
+        cfg["workload"] = cfg["workload"][:240]
+    for victim in ("top_kernels", "roofline_phase", "shards", "inner_per_step", "gather", "roofline_iteration", "cold_start", "exchange",
+                   "netflix", "f64"):
+        if size() < LINE_CAP:
+            break
+        line.pop(victim, None)
+    return line
 
 
 def free_port():
@@ -593,6 +742,9 @@ def main():
     ap.add_argument("--profile-period", type=int, default=0,
                     help="event-time every n-th launch of each kernel (the first one included); 0 = as sparse as leaves a dozen "
                          "samples of the most frequent kernel (11 launches per step): min(16, 11 * steps / 12)")
+    ap.add_argument("--full-record", default=None, help="where the full record (per-kernel tables, phases, notes) is written; default "
+                                                        "bench_full.json next to bench.py.  stdout carries the compact line only")
+    ap.add_argument("--full-line", action="store_true", help="developer tools only: print the full record as the stdout line (tens of KB)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -648,7 +800,17 @@ def main():
                 out[k] = v
         if nf:
             out["netflix"] = nf
-        print(json.dumps(out), flush=True)
+        # The driver reads the LAST stdout line and keeps only a few KB of it: the line is the compact summary (< 4 KB, every
+        # field the contract names + roofline + cpu_baseline), the full record (per-kernel tables, phases, notes) goes to a file.
+        full_path = args.full_record or os.path.join(ROOT, "bench_full.json")
+        try:
+            with open(full_path, "w") as f:
+                json.dump(out, f, indent=1)
+            shown = os.path.relpath(full_path, ROOT) if full_path.startswith(ROOT + os.sep) else full_path
+        except OSError as e:
+            log(f"[bench] could not write the full record to {full_path}: {e}")
+            shown = None
+        print(json.dumps(out) if args.full_line else json.dumps(compact_line(out, shown), separators=(",", ":")), flush=True)
     if N > 1:
         dist.barrier(); dist.destroy_process_group()
 

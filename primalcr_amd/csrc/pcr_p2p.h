@@ -27,8 +27,15 @@
 // Data and flag travel in the SAME 8-byte store (the hardware keeps an aligned 8-byte store whole), so no ordering between a
 // payload and its flag is ever assumed -- the scheme NCCL / RCCL call LL.  A slot is reused by the next call only after its
 // reader has consumed it (a rank leaves a call only when every owner has answered, and an owner answers only after it read
-// every rank's word), so single buffers suffice; seq makes a stale word unmistakable.  Polls are bounded: a rank whose peers
-// never arrive raises an error word in pinned host memory instead of hanging the GPU.  fp64 elements travel as two words.
+// every rank's word), so single buffers suffice; seq makes a stale word unmistakable.  fp64 elements travel as two words.
+// Waits are bounded by a WALL-CLOCK deadline (wall_clock64, ll_timeout_s: 20 s by default -- ranks may enter their first
+// exchange seconds apart, e.g. behind their share of the initial() stream -- pcr_tune "p2p_timeout_ms").  A thread whose
+// wait times out raises an error word in pinned host memory and is DEAD for the rest of the kernel: it waits for nothing more
+// (every later word returns at once), and in place of a sum it publishes a POISON word (the call's seq with the top bit set),
+// at which every peer's waiting thread raises its own error and dies the same way -- no rank consumes a made-up sum as a good
+// result, and no rank sits out its own full deadline behind a peer that already knows.  The host reads the error word at its
+// next synchronisation, raises the job's shared error flag (so that peers on the host-synchronised path leave too) and
+// returns PCR_ERR_COMM.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -48,7 +55,7 @@
 
 #define PCR_P2P_MAXR 16
 
-#define PCR_P2P_MAGIC 0x50435250325034ull     // "PCRP2P4"
+#define PCR_P2P_MAGIC 0x50435250325035ull     // "PCRP2P5"
 struct P2PCtl {                               // in POSIX shared memory, created (O_EXCL) and zero-filled by rank 0
     std::atomic<uint64_t> magic;              // written LAST by rank 0: the block is ready
     uint64_t created_ns;                      // CLOCK_REALTIME at creation: a block older than the rendezvous time-out is a dead job's
@@ -60,6 +67,7 @@ struct P2PCtl {                               // in POSIX shared memory, created
     uint64_t bytes[PCR_P2P_MAXR];
     hipIpcMemHandle_t ll_handle[PCR_P2P_MAXR];        // the boxes of the device-driven exchange (an allocation of their own)
     uint64_t ll_bytes[PCR_P2P_MAXR];
+    uint32_t ll_ok[PCR_P2P_MAXR];                     // 1 = that rank holds FINE-GRAINED boxes (written before posted[] is raised)
 };
 
 template <typename X> struct P2PPtrs { const X* p[PCR_P2P_MAXR]; };
@@ -96,44 +104,52 @@ __device__ __forceinline__ void ll_put(unsigned long long* dst, double v, unsign
     __hip_atomic_store(dst, ((unsigned long long)seq << 32) | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(dst + 1, ((unsigned long long)seq << 32) | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// one word carrying this call's seq, or 0 with *err raised once the poll budget is spent (or another thread already failed)
-__device__ __forceinline__ unsigned ll_word(const unsigned long long* src, unsigned seq, int* err, long long& budget) {
-    for (;;) {
-        const unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((unsigned)(w >> 32) == seq) return (unsigned)w;
-        __builtin_amdgcn_s_sleep(1);
-        if ((--budget & 4095) == 0 && (budget <= 0 || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+#define PCR_LL_POISON 0x80000000u              // top bit of a word's tag: "the rank that owed this word gave up" (seq stays below it)
+struct LLWait { long long deadline; bool dead; };      // per thread: wall_clock64 deadline of the kernel; dead = it has failed
+// one word carrying this call's seq -- or 0 with the thread dead and *err raised: the deadline passed, the word is poisoned, or
+// another thread of this rank has already failed.  A dead thread returns at once.
+__device__ __forceinline__ unsigned ll_word(const unsigned long long* src, unsigned seq, int* err, LLWait& w) {
+    if (w.dead) return 0u;
+    for (unsigned spins = 1;; ++spins) {
+        const unsigned long long x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned tag = (unsigned)(x >> 32);
+        if (tag == seq) return (unsigned)x;
+        if (tag == (seq | PCR_LL_POISON) ||
+            ((spins & 255u) == 0 && ((long long)wall_clock64() - w.deadline > 0 || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0))) {
             __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            w.dead = true;
             return 0u;
         }
+        __builtin_amdgcn_s_sleep(1);
     }
 }
-__device__ __forceinline__ float ll_get(const unsigned long long* src, unsigned seq, int* err, long long& budget, float) {
-    return __int_as_float((int)ll_word(src, seq, err, budget));
+__device__ __forceinline__ float ll_get(const unsigned long long* src, unsigned seq, int* err, LLWait& w, float) {
+    return __int_as_float((int)ll_word(src, seq, err, w));
 }
-__device__ __forceinline__ double ll_get(const unsigned long long* src, unsigned seq, int* err, long long& budget, double) {
-    const unsigned lo = ll_word(src, seq, err, budget), hi = ll_word(src + 1, seq, err, budget);
+__device__ __forceinline__ double ll_get(const unsigned long long* src, unsigned seq, int* err, LLWait& w, double) {
+    const unsigned lo = ll_word(src, seq, err, w), hi = ll_word(src + 1, seq, err, w);
     return __hiloint2double((int)hi, (int)lo);
 }
 // buf[0, n) <- sum over the ranks, in rank order, the same bits on every rank.  The grid must be co-resident (the host keeps it
 // at <= 128 workgroups); inbox of rank q: [sender][per * W] words, outbox: [n_max * W] words.
 template <typename X>
 __global__ __launch_bounds__(256) void k_p2p_ll(X* __restrict__ buf, int64_t n, int64_t per, int64_t box_stride, int me, int nranks,
-                                                P2PLLPtrs ll, unsigned seq, int* err, long long budget0) {
+                                                P2PLLPtrs ll, unsigned seq, int* err, long long budget_ticks) {
     constexpr int W = LLWords<X>::W;
     const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x, dt = (int64_t)gridDim.x * 256;
-    long long budget = budget0;
+    LLWait wt{(long long)wall_clock64() + budget_ticks, false};
     for (int64_t i = t0; i < n; i += dt) {                                           // scatter
         const int64_t q = i / per;
         ll_put(ll.inbox[q] + ((int64_t)me * box_stride + (i - q * per)) * W, buf[i], seq);
     }
     const int64_t lo = per * me < n ? per * me : n, hi = lo + per < n ? lo + per : n;
     for (int64_t j = lo + t0; j < hi; j += dt) {                                     // reduce my slice, answer everybody
-        X s = ll_get(ll.inbox[me] + (j - lo) * W, seq, err, budget, X());
-        for (int r = 1; r < nranks; ++r) s += ll_get(ll.inbox[me] + ((int64_t)r * box_stride + (j - lo)) * W, seq, err, budget, X());
-        for (int p = 0; p < nranks; ++p) ll_put(ll.outbox[p] + j * W, s, seq);
+        X s = ll_get(ll.inbox[me] + (j - lo) * W, seq, err, wt, X());
+        for (int r = 1; r < nranks; ++r) s += ll_get(ll.inbox[me] + ((int64_t)r * box_stride + (j - lo)) * W, seq, err, wt, X());
+        // (a dead thread has no sum: it answers with poison, so that every rank fails this call instead of consuming garbage)
+        for (int p = 0; p < nranks; ++p) ll_put(ll.outbox[p] + j * W, wt.dead ? X(0) : s, wt.dead ? (seq | PCR_LL_POISON) : seq);
     }
-    for (int64_t i = t0; i < n; i += dt) buf[i] = ll_get(ll.outbox[me] + i * W, seq, err, budget, X());      // gather
+    for (int64_t i = t0; i < n; i += dt) buf[i] = ll_get(ll.outbox[me] + i * W, seq, err, wt, X());      // gather
 }
 
 struct P2PComm {
@@ -144,7 +160,13 @@ struct P2PComm {
     char* peer[PCR_P2P_MAXR] = {};
     size_t cap_bytes = 0, slice_bytes = 0;    // one X / one Y (bytes)
     uint64_t seq = 0;
-    double timeout_s = 120.0;
+    double timeout_s = 120.0;                 // host barriers and the rendezvous
+    double ll_timeout_s = 20.0;               // wall-clock deadline of one device-driven exchange (pcr_tune "p2p_timeout_ms")
+    long long ll_ticks = 0;                   // ... in wall_clock64 ticks of this device
+    int fault_skip_call = 0;                  // test hook (pcr_tune "fault_p2p_skip"): this rank never launches its n-th device-driven exchange
+    bool fault_coarse = false;                // test hook (pcr_tune "fault_p2p_coarse"): pretend the fine-grained allocation failed on this rank
+    bool debug = false;
+    int ll_calls = 0;
     std::string err;
     // device-driven exchange (k_p2p_ll): two box sets in this rank's buffer, one for vectors of at most ll_elems elements of elt
     // bytes, one for the scalars; per-set sequence numbers; an error word the kernels raise, in pinned host memory
@@ -249,14 +271,24 @@ struct P2PComm {
         }
         if (hipMalloc((void**)&xbuf, total_bytes()) != hipSuccess) return fail("hipMalloc of the exchange buffer failed");
         if (hipMemset(xbuf, 0, total_bytes()) != hipSuccess) return fail("hipMemset of the exchange buffer failed");
+        ctl->ll_ok[rank] = 0;
         if (ll_max_bytes) {
-            if (hipExtMallocWithFlags((void**)&llbuf, ll_bytes(), hipDeviceMallocFinegrained) != hipSuccess) {
+            // The boxes must be fine-grained: a kernel that polls coarse-grained memory may never see a peer's store over xGMI
+            // (it can stay hidden behind a line this GPU's L2 holds), so every poll would run into its deadline.  A rank that
+            // cannot get such memory says so in the control block, and then EVERY rank takes the host-synchronised path.
+            if (fault_coarse || hipExtMallocWithFlags((void**)&llbuf, ll_bytes(), hipDeviceMallocFinegrained) != hipSuccess) {
                 (void)hipGetLastError();
-                if (hipMalloc((void**)&llbuf, ll_bytes()) != hipSuccess) return fail("hipMalloc of the exchange boxes failed");
+                llbuf = nullptr;
+                if (debug) fprintf(stderr, "[pcr] p2p rank %d: no fine-grained memory for the exchange boxes -- device-driven exchange off\n", rank);
+            } else {
+                if (hipMemset(llbuf, 0, ll_bytes()) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail("hipMemset of the exchange boxes failed");
+                if (hipIpcGetMemHandle(&ctl->ll_handle[rank], llbuf) != hipSuccess) return fail("hipIpcGetMemHandle of the exchange boxes failed");
+                ctl->ll_bytes[rank] = ll_bytes();
+                ctl->ll_ok[rank] = 1;
             }
-            if (hipMemset(llbuf, 0, ll_bytes()) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail("hipMemset of the exchange boxes failed");
-            if (hipIpcGetMemHandle(&ctl->ll_handle[rank], llbuf) != hipSuccess) return fail("hipIpcGetMemHandle of the exchange boxes failed");
-            ctl->ll_bytes[rank] = ll_bytes();
+            int khz = 0, dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+            ll_ticks = (long long)(ll_timeout_s * 1e3 * (double)khz);
         }
         // (dmabuf IPC: on hosts whose driver has no legacy IPC mode the process must run with HSA_ENABLE_IPC_MODE_LEGACY=0 --
         // an environment prerequisite of the ROCm runtime, listed in include/primalcr.h; the library itself reads no variable)
@@ -270,6 +302,17 @@ struct P2PComm {
                 if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return fail("rendezvous timed out");
                 std::this_thread::yield();
             }
+        if (ll_max_bytes) {       // posted[] was raised after ll_ok[]: every rank takes the same decision from the same words
+            bool all_ok = true;
+            for (int r = 0; r < nranks; ++r) all_ok = all_ok && ctl->ll_ok[r] == 1;
+            if (!all_ok) {
+                ll_max_bytes = 0;
+                if (debug && rank == 0) fprintf(stderr, "[pcr] p2p: a rank has no fine-grained exchange boxes: all ranks take the host-synchronised exchange\n");
+            }
+        }
+        if (debug && rank == 0)
+            fprintf(stderr, "[pcr] p2p: %d ranks, vectors up to %zu bytes %s\n", nranks, ll_max_bytes ? ll_elems * elt : (size_t)0,
+                    ll_max_bytes ? "device-driven (fine-grained boxes), larger ones host-synchronised" : "-- every exchange host-synchronised");
         for (int r = 0; r < nranks; ++r) {
             if (r == rank) { peer[r] = xbuf; continue; }
             if (ctl->bytes[r] != total_bytes()) return fail("ranks disagree on the exchange buffer size");
@@ -306,11 +349,12 @@ struct P2PComm {
                 ll.inbox[r] = reinterpret_cast<unsigned long long*>(ll_peer[r] + ll_off[set]);
                 ll.outbox[r] = reinterpret_cast<unsigned long long*>(ll_peer[r] + ll_outofs[set]);
             }
-            const unsigned sq = ++ll_seq[set];
+            unsigned sq = ++ll_seq[set] & (PCR_LL_POISON - 1);            // tags 1 .. 2^31 - 1 (0 = an untouched box, top bit = poison)
+            if (sq == 0) sq = ++ll_seq[set] & (PCR_LL_POISON - 1);
             const int grid = (int)std::min<size_t>(128, (n + 255) / 256);
-            // (poll budget: 2^25 polls of a system-scope load + s_sleep each per thread -- tens of seconds; a peer may lag by a whole phase)
+            if (fault_skip_call && ++ll_calls == fault_skip_call) return true;       // test hook: this rank "forgets" one exchange
             hipLaunchKernelGGL((k_p2p_ll<X>), dim3(grid), dim3(256), 0, st, buf, (int64_t)n, (int64_t)per, (int64_t)per, rank, nranks, ll, sq, ll_err,
-                               (long long)1 << 25);
+                               ll_ticks);
             return hipGetLastError() == hipSuccess || fail("p2p: exchange launch failed");
         }
         const int par = (int)(seq++ & 1);
@@ -368,6 +412,7 @@ struct P2PComm {
         finalize();
         for (int r = 0; r < nranks; ++r) if (r != rank && peer[r]) (void)hipIpcCloseMemHandle(peer[r]);
         for (int r = 0; r < nranks; ++r) if (r != rank && ll_peer[r]) (void)hipIpcCloseMemHandle(ll_peer[r]);
+        ll_peer[rank] = nullptr;
         if (llbuf) (void)hipFree(llbuf);
         if (xbuf) (void)hipFree(xbuf);
         if (ll_err) (void)hipHostFree(ll_err);

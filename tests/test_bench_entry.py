@@ -126,6 +126,84 @@ def test_two_physical_gpus_equal_one_rank(comm, chunks):
     assert s.evaluate(1, 10)[1] == pytest.approx(a["ndcg10_test"], abs=1e-9)
 
 
+def _canned_full_record():
+    """A full bench record as round 3 printed it on ONE stdout line (45 KB: the driver keeps ~8.6 KB and could not parse it)."""
+    return json.loads(open(os.path.join(ROOT, "profiles", "r03_d_bench.json")).read().strip().split("\n")[-1])
+
+
+def test_stdout_line_is_compact_and_carries_what_the_driver_reads():
+    """The driver parses the LAST stdout line and keeps only a few KB of stdout: the line must stay small whatever the
+    number of kernels, classes and sub-records, and still hold every contract field, `roofline` and `cpu_baseline`."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = _canned_full_record()
+    assert len(json.dumps(full)) > 40000
+    # an N = 8 job's extras on top (exchange profile, shards), a cold-start clock, and absurdly many kernels
+    full["exchange_profile"] = {"allreduce_us_avg": 31.25, "allreduces_per_step": 14.0, "timed": 18, "vector_bytes": 1580800,
+                                "vector_allreduces_per_step": 11.0, "scalar_allreduces_per_step": 3.0, "us_per_step": 437.5, "share_of_step": 0.2261}
+    full["shards"] = [[6040 * q, 6040, 939809] for q in range(8)]
+    full["cold_start"] = {"iterations": 5, "ms_per_step": 1.71234567}
+    full["ms_per_step_first5"] = 1.71234567
+    for i in range(200):
+        full["kernels"][f"ustep/extra{i}"] = dict(full["kernels"]["sddmm"])
+    line = bench.compact_line(full, "bench_full.json")
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < 4096 and len(text) < bench.LINE_CAP, len(text)
+    back = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "full_record"):
+        assert k in back, k
+    assert back["value"] == full["value"] and back["ms_per_step"] == full["ms_per_step"]          # the headline is not rounded
+    assert back["config"]["workload"].startswith("ml1m-shaped")
+    rf = back["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=5e-3)
+    assert rf["traffic"] and rf["kernel"].startswith("ustep/") and rf["binding"]["level"] == "l2-gather"
+    assert rf["achieved"] == pytest.approx(rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9, rel=2e-3)
+    cb = back["cpu_baseline"]
+    assert cb["kind"] == "reference" and cb["cores"] == 16 and cb["value"] > 0 and cb["unit"] == "pairs/s" and cb["sample"]
+    assert cb["single_thread"]["s_per_iter"] > cb["s_per_iter"]
+    assert back["ms_per_step_first5"] == pytest.approx(1.7123, rel=1e-3)
+    assert back["f64"]["ms_per_step"] > back["ms_per_step"] and back["netflix"]["ms_per_step"] > 100
+    assert back["netflix"]["cpu_baseline"]["value"] > 0 and back["netflix"]["roofline"]["kernel"].startswith("ustep/")
+    assert back["exchange"]["allreduces_per_step"] == 14.0 and len(back["shards"]) == 8
+    assert len(back["top_kernels"]) <= 5
+    # a record that outgrows the cap loses optional blocks, never the contract's fields
+    full["config"]["workload"] = "x" * 3000
+    small = bench.compact_line(full, "bench_full.json")
+    assert len(json.dumps(small, separators=(",", ":"))) < bench.LINE_CAP and len(small["config"]["workload"]) == 240
+    cap, bench.LINE_CAP = bench.LINE_CAP, 2600
+    try:
+        small = bench.compact_line(full, "bench_full.json")
+    finally:
+        bench.LINE_CAP = cap
+    assert len(json.dumps(small, separators=(",", ":"))) < 2600
+    assert small["roofline"] and small["cpu_baseline"] and "top_kernels" not in small and "roofline_phase" not in small
+
+
+def test_uncounted_gather_figures_are_null_not_zero():
+    """--no-rows switches the U step's row counter off: every figure derived from it must read null (unmeasured), never 0.0."""
+    sys.path.insert(0, ROOT)
+    import bench
+    prof = {"sddmm": (0.3, 11), "spmm": (0.3, 11), "ustep/256.512": (2.0, 5), "wall:ustep": (2.5, 5)}
+    run = dict(secs=0.03, inner={"cg_v": 200, "ls_v": 20, "cg_u": 290000, "ls_u": 120800}, prof=prof, steps=20, prof_period=16,
+               launches={"sddmm": 220, "spmm": 220, "ustep/256.512": 20, "wall:ustep": 20},
+               scope={"sddmm": (939809, 6040), "spmm": (939809, 6040), "ustep/256.512": (400000, 1500), "wall:ustep": (-1, -1)},
+               shard=(0, 6040, 939809))
+    wl = dict(d1=6040, d2=3952, nnz=939809, r=100)
+    off = bench.analyse(run, None, wl, "f32", 1, None)
+    u = off["roofline_phase"]["u_step"]
+    assert u["gather_GBs"] is None and u["gathered_row_bytes_per_step"] is None and u["binding"]["frac"] is None and u["binding"]["achieved_GBs"] is None
+    assert off["gather"]["frac"] is None and off["gather"]["achieved_GBs"] is None and off["gather"]["u_side_half_passes"] is None
+    assert off["gather"]["u_side_counted"] is False and off["gather"]["v_side_half_passes"] == 22.0
+    assert off["roofline_phase"]["v_step"]["gather_GBs"] > 0                  # the V side needs no counter
+    on = bench.analyse(run, dict(u_rows=20 * 9.1 * 939809, rows_by_class={"ustep/256.512": 25 * 9.5 * 400000},
+                                 launches_counted={"ustep/256.512": 25}), wl, "f32", 1, None)
+    assert on["roofline_phase"]["u_step"]["gather_GBs"] > 0 and on["gather"]["frac"] > 0 and on["gather"]["u_side_half_passes"] == 9.1
+    line = bench.compact_line(dict(_canned_full_record(), gather=off["gather"], roofline_phase=off["roofline_phase"]), None)
+    assert line["gather"]["frac"] is None and line["gather"]["u_side_counted"] is False and line["roofline_phase"]["u_step"]["gather_frac"] is None
+
+
 def test_every_ustep_class_is_one_kernel_symbol_in_the_committed_profiles():
     """bench.py prices a HIP-event slot with the PMC bytes of 'its' kernel symbol (profiles/r03_traffic.json): every U-step length
     class of the committed bench line (ml1m and the Netflix-shaped sub-record) must match exactly one k_ustep symbol of the
