@@ -290,6 +290,8 @@ def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name
     # sorts' nearly-sorted fast path has nothing to start from yet; the reference's default run is -t 10 from cold).  One
     # untimed iteration first, then back to the initial point: the first launch of every kernel loads its code object.
     cold = None
+    if N > 1:
+        dist.barrier()              # ranks leave their share of the initial() stream seconds apart: meet before the first exchange
     if warmup >= 1 and cold_start:
         s.iterate(1)
         s.set_factors_local(pcr.initial_rows(total, r, first, s.n_users), pcr.initial(d2, r))

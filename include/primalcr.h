@@ -160,34 +160,40 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *                   counting (verified; else the full bitonic network); default 8, 0 = always the full network, at most 64
  *   p2p_ll          peer-to-peer communicator: vectors of at most this many MB (and the objective's scalars) take the device-driven
  *                   exchange (one kernel per rank, flags inside the 8-byte words, no host barrier); larger ones the host-synchronised
- *                   reduce-scatter / all-gather; default 16, 0 = host-synchronised always
+ *                   reduce-scatter / all-gather; default 16, 0 = host-synchronised always.  (If any rank cannot allocate
+ *                   fine-grained device memory for its exchange boxes, EVERY rank takes the host-synchronised path.)
+ *   p2p_timeout_ms  wall-clock deadline of one device-driven exchange (default 20000): a rank whose peers do not arrive in time
+ *                   reports PCR_ERR_COMM, poisons its answers (no rank consumes a made-up sum) and raises the job's error flag
  *   cluster_fence   0 = the hand-off between the workgroups of a cluster without the agent-scope release / acquire (its payload
  *                   is sc1 both ways; measured valid on gfx950, not an architectural guarantee; default 1: fenced)
  *   ustep_ls_recur  0 = k_ustep's first line-search try gathers the rows for its scores (default 1: m - s sum alpha_k b_k from the
  *                   CG's own b_k = V_I p_k, no pass)
- *   ustep_seq       1 = the U step's length classes back to back on one stream
  *   ustep_gram      dual (Gram-matrix on MFMA) U step for users with at most that many ratings (<= 128; default 0 = off)
  *   cluster_k       4 (default) or 1: workgroups per clustered long user;  cluster_users: how many users get clusters
  *   ubins           "cap:block:resident,..." length classes of the U step below 1024 ratings
  *   spmm_tiles, spmm_chunk, sddmm_tile, sddmm_csc   tiling of the rating-parallel kernels
  *   sweep_wave_cap  ratings up to which a sweep gives a user one wave
- *   sweep_dense     0 = k_vsweep_all always as the unbounded symbol (default 1: the 64-VGPR symbol, four workgroups per CU, where the
- *                   longest user's arrays fit 40 KB of LDS)
  *   sweep_prefetch  0 = the sweeps keep one round of per-rating loads in flight instead of four (default 1)
  *   window_cache    0 = sweeps search their hinge windows instead of caching them
  *   win16           0 = 32-bit window-cache entries even when every user has fewer than 65536 ratings (default 1: 16-bit)
  *   ustep_win_lds   0 = k_ustep reads the window cache from global memory in every sweep (default 1: LDS copy)
  *   prepare_merged  1 / 0 = both LDS classes of k_prepare in one launch, or one launch per length class side by side
  *                   (default: merged below 4 M ratings per shard)
- *   lanes           concurrent streams for length classes (1 = none);  pipeline: 0 = host round trip after every U step
- *   uplan           "<class>:<stream>,..." explicit placement in launch order (class = index in the built-in launch order, stream =
- *                   lane 0..3 or 8 = the high-priority stream); a development knob
- *   eval_brute      1 = O(len^2) evaluator
+ *   lanes           concurrent streams for length classes (1 = none: the layout a process ends up with when every side stream
+ *                   shares a hardware queue with the solver's);  pipeline: 0 = host round trip after every U step
  *   count_rows      1 = the U-step kernels count the rows of V they gather (pcr_solver_counter; a diagnostic that
  *                   costs the short-user classes 10-20 %, so off by default)
  *   debug           1 = print launch decisions to stderr
  *   fault_cluster_member   test hook: one member of every workgroup cluster leaves early (the launch must report
- *                   PCR_ERR_DEVICE through the bounded hand-off wait instead of hanging) */
+ *                   PCR_ERR_DEVICE through the bounded hand-off wait instead of hanging)
+ *   fault_p2p_skip  test hook: this rank never launches its n-th device-driven exchange (its peers must time out, poison their
+ *                   answers and fail with PCR_ERR_COMM; nobody may hang or consume garbage)
+ *   fault_p2p_coarse   test hook: this rank behaves as if fine-grained memory were unavailable (all ranks must fall back to the
+ *                   host-synchronised exchange together)
+ * Stream layout: the solver creates its stream, a high-priority stream and its side streams in that order, and measures which
+ * side streams share a hardware QUEUE with the solver's stream (pick_lanes).  Which queues share a command-processor PIPE is
+ * not observable through HIP and follows the process-wide order in which streams were created: up to four streams created by
+ * the host application before the solver moved the headline step by at most 3 % (NOTES.md); results never depend on it. */
 int pcr_tune(const char *key, const char *value);                          /* [host] */
 
 typedef struct pcr_solver pcr_solver;
@@ -279,7 +285,8 @@ typedef void (*pcr_log_fn)(void *ctx, const char *line);
 
 /* pcrpp.cpp:841-901 pcrpp() / pcr.cpp:616-704 pcr(): the whole training loop
  * from the current device factors.  Emits the reference's log lines through
- * `log` (NULL = stdout).  hist may be NULL, else holds maxiter+1 records. */
+ * `log` (NULL = stdout, rank 0 only; a callback is invoked on EVERY rank of a multi-rank job with the
+ * same lines).  hist may be NULL, else holds maxiter+1 records. */
 int pcr_train(pcr_solver *s, pcr_log_fn log, void *log_ctx, pcr_iter_stats *hist);
 /* The body of that loop (pcrpp.cpp:869-895: update_V_new, update_U_new, no evaluation) n times from the current state,
  * with one host round trip per iteration: the U step is queued without waiting for it and its objective is read back

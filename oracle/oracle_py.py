@@ -58,7 +58,8 @@ class IterRec(C.Structure):
 
 
 class Oracle:
-    def __init__(self, path=ORACLE_SO):
+    def __init__(self, path=None):
+        path = path or ORACLE_SO                 # (read at call time: tests/conftest.py points it at the sanitizer build)
         if not os.path.exists(path):
             build("oracle")
         self.lib = L = C.CDLL(path)

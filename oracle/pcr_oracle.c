@@ -210,7 +210,7 @@ static void ub_build(ubundle_t *b, const double *mm, const double *val,
     /* find_levels: sorted distinct lround(val) */
     long T = 0;
     for (long j = 0; j < len; ++j) b->levels[j] = lround(val[j]);
-    qsort(b->levels, (size_t)len, sizeof(long), cmp_long);
+    if (len > 1) qsort(b->levels, (size_t)len, sizeof(long), cmp_long);     /* (an empty user has no arrays: UBSan, nonnull) */
     for (long j = 0; j < len; ++j)
         if (j == 0 || b->levels[j] != b->levels[T - 1]) b->levels[T++] = b->levels[j];
     b->num_levels = T;

@@ -9,7 +9,7 @@
 //                  (the reference only has a commented-out text-file variant, pmf-train.cpp:262-263)
 //   --cache F      binary side-car of the parsed data set: read F if it matches the text files' size and
 //                  modification time, else parse the text and (best effort) write F
-//   --snapshot-every N  also write <model>.iter<k> after every N-th outer iteration
+//   --snapshot-every N  also write <model>.iter<k> after every N-th outer iteration (with --gpus N too: every rank deposits its rows)
 //   --cg-iters N / --cg-tol X  truncated-Newton knobs (the reference hard-codes 10 / 0.01); --cg-iters k with a
 //                       small --cg-tol makes the U step an exact Newton step
 //   --gpus N       user-shard the training over N GPUs of this node: the data set is parsed once, then one
@@ -110,6 +110,7 @@ static void write_outputs(const pcr_params& param, const std::string& model, con
 struct SharedHdr {
     std::atomic<int> id_ready, failed, nranks_reported;
     std::atomic<int> done[16];               // rank q has deposited its rows of U (and rank 0 V): all of them before the model is written
+    std::atomic<int> snap[16];               // --snapshot-every: the last outer iteration whose factors rank q has deposited
     unsigned char nccl_id[128];
     char shm_name[64];
 };
@@ -122,6 +123,17 @@ static void forward_signal(int sig) {
     g_signalled = sig;
     for (int i = 0; i < g_nkids; ++i) if (g_kids[i] > 0) kill(g_kids[i], SIGTERM);
 }
+
+// --snapshot-every with --gpus N (pmf-train.cpp:297-310 writes the model only once, at the end: a long 8-GPU run has no
+// resume point).  pcr_train hands every rank the log lines; at every n-th "Iter k" line each rank deposits its own rows of U
+// (rank 0 also V) in the shared block and publishes k; rank 0 waits until every rank has published k and writes
+// <model>.iter<k>.  No rank can overwrite its rows with a later iteration's meanwhile: the next outer iteration needs
+// all-reduces that rank 0, busy here, has not joined yet.
+struct MultiSnap {
+    pcr_solver* s; int every, rank, nranks; struct SharedHdr* hdr; double* Ush; double* Vsh;
+    int64_t d1, d2, first, nu; int k; std::string model; bool failed;
+};
+static void multi_snap_log(void* vctx, const char* line);
 
 // body of worker `rank`: everything that touches a GPU happens here, after the fork
 static int worker(const pcr_dataset* ds, pcr_params param, int rank, int nranks, const std::string& comm_kind, SharedHdr* hdr,
@@ -151,12 +163,12 @@ static int worker(const pcr_dataset* ds, pcr_params param, int rank, int nranks,
         fprintf(stderr, "[rank %d] device %d: users [%ld, %ld), %ld ratings\n", rank, param.device, (long)f0, (long)(f0 + n0), (long)z0);
     }
     if (pcr_solver_set_factors(s, U0.data(), V0.data()) != PCR_OK) return fail("set_factors");
-    // snapshots: rank 0 alone sees the log lines, and a snapshot needs every rank's rows of U -- not offered with --gpus > 1
-    (void)snapshot_every; (void)model;
-    if (pcr_train(s, nullptr, nullptr, nullptr) != PCR_OK) return fail("train");
-    // "all-gather of U shards" (SURVEY 8e): every rank deposits its own rows; V is replicated, rank 0 deposits it
     int64_t first = 0, nu = 0;
     pcr_solver_shard(s, &first, &nu, nullptr);
+    MultiSnap snap{s, snapshot_every, rank, nranks, hdr, Ush, Vsh, d1, d2, first, nu, param.k, model, false};
+    if (pcr_train(s, snapshot_every > 0 ? multi_snap_log : nullptr, &snap, nullptr) != PCR_OK) return fail("train");
+    if (snap.failed) { hdr->failed.store(1); return 1; }
+    // "all-gather of U shards" (SURVEY 8e): every rank deposits its own rows; V is replicated, rank 0 deposits it
     std::vector<double> Uf((size_t)d1 * param.k), Vf((size_t)d2 * param.k);
     if (pcr_solver_get_factors(s, Uf.data(), rank == 0 ? Vf.data() : nullptr) != PCR_OK) return fail("get_factors");
     memcpy(Ush + first * param.k, Uf.data() + first * param.k, (size_t)nu * param.k * sizeof(double));
@@ -170,10 +182,37 @@ static int worker(const pcr_dataset* ds, pcr_params param, int rank, int nranks,
     return 0;
 }
 
+static void multi_snap_log(void* vctx, const char* line) {
+    MultiSnap* c = static_cast<MultiSnap*>(vctx);
+    if (c->rank == 0) { fputs(line, stdout); fputc('\n', stdout); fflush(stdout); }
+    int it = 0;
+    if (c->failed || sscanf(line, "Iter %d time", &it) != 1 || it <= 0 || it % c->every != 0) return;
+    if (pcr_solver_get_factors_local(c->s, c->Ush + c->first * c->k, c->rank == 0 ? c->Vsh : nullptr) != PCR_OK) {
+        fprintf(stderr, "[rank %d] snapshot at iteration %d: %s\n", c->rank, it, pcr_last_error());
+        c->failed = true; c->hdr->failed.store(1);
+        return;
+    }
+    c->hdr->snap[c->rank].store(it, std::memory_order_release);
+    if (c->rank != 0) return;
+    for (int q = 0; q < c->nranks; ++q)
+        for (long spins = 0; c->hdr->snap[q].load(std::memory_order_acquire) < it; ++spins) {
+            if (c->hdr->failed.load() || spins > 120L * 1000) {
+                fprintf(stderr, "[rank 0] snapshot at iteration %d: rank %d did not deposit its rows\n", it, q);
+                c->failed = true; c->hdr->failed.store(1);
+                return;
+            }
+            usleep(1000);
+        }
+    const std::string path = c->model + ".iter" + std::to_string(it);
+    if (pcr_model_save(path.c_str(), c->Ush, c->d1, c->Vsh, c->d2, c->k) != PCR_OK) {
+        fprintf(stderr, "snapshot %s: %s\n", path.c_str(), pcr_last_error());
+        c->failed = true; c->hdr->failed.store(1);
+    }
+}
+
 static int train_multi(const pcr_dataset* ds, const pcr_params& param, int gpus, const std::vector<int>& devices,
                        const std::string& comm_kind, std::vector<double>& U, std::vector<double>& V, int64_t d1, int64_t d2,
                        int snapshot_every, const std::string& model) {
-    if (snapshot_every > 0) { fprintf(stderr, "--snapshot-every is not available with --gpus > 1\n"); return 1; }
     const size_t nU = (size_t)d1 * param.k, nV = (size_t)d2 * param.k;
     const size_t bytes = sizeof(SharedHdr) + (nU + nV) * sizeof(double) + 64;
     void* mem = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
@@ -181,6 +220,7 @@ static int train_multi(const pcr_dataset* ds, const pcr_params& param, int gpus,
     SharedHdr* hdr = new (mem) SharedHdr();
     hdr->id_ready.store(0); hdr->failed.store(0); hdr->nranks_reported.store(0);
     for (auto& d : hdr->done) d.store(0);
+    for (auto& d : hdr->snap) d.store(0);
     {   // the control block's name: pid + something a bystander cannot predict
         unsigned long long rnd = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
         if (FILE* ur = fopen("/dev/urandom", "rb")) { if (fread(&rnd, sizeof rnd, 1, ur) != 1) rnd ^= (unsigned long long)getpid() << 32; fclose(ur); }
@@ -323,6 +363,8 @@ int main(int argc, char** argv) {
     pcr_dataset* ds = nullptr;
     if ((cache.empty() ? pcr_dataset_load_mt(input.c_str(), param.threads, &ds)
                        : pcr_dataset_load_cached(input.c_str(), param.threads, cache.c_str(), &ds)) != PCR_OK) die("load");
+    // (every way out of main from here on releases the data set and the solver: found by LeakSanitizer on the failure paths)
+    struct Holder { pcr_dataset* ds; pcr_solver* s; ~Holder() { if (s) pcr_solver_destroy(s); if (ds) pcr_dataset_free(ds); } } hold{ds, nullptr};
     int64_t d1, d2, nnz, tnnz;
     pcr_dataset_dims(ds, &d1, &d2, &nnz, &tnnz);
     const int k = param.k;
@@ -352,22 +394,21 @@ int main(int argc, char** argv) {
         const int rc = train_multi(ds, param, gpus, devices, comm_kind, U, V, d1, d2, snapshot_every, model);
         if (rc != 0) return rc;
         write_outputs(param, model, U, V, d1, d2);
-        pcr_dataset_free(ds);
         return 0;
     }
     auto t0 = std::chrono::steady_clock::now();
     pcr_solver* s = nullptr;
     if (!devices.empty()) param.device = devices[0];
-    if (pcr_solver_create(ds, &param, 0, 1, &s) != PCR_OK) die("solver");
-    if (pcr_solver_set_factors(s, U.data(), V.data()) != PCR_OK) die("set_factors");
+    if (pcr_solver_create(ds, &param, 0, 1, &s) != PCR_OK) { fprintf(stderr, "solver: %s\n", pcr_last_error()); return 1; }
+    hold.s = s;
+    auto fail = [](const char* what) { fprintf(stderr, "%s: %s\n", what, pcr_last_error()); return 1; };
+    if (pcr_solver_set_factors(s, U.data(), V.data()) != PCR_OK) return fail("set_factors");
     SnapCtx snap{s, snapshot_every, model, d1, d2, k, &U, &V, false};
-    if (pcr_train(s, snapshot_every > 0 ? snap_log : nullptr, &snap, nullptr) != PCR_OK) die("train");
+    if (pcr_train(s, snapshot_every > 0 ? snap_log : nullptr, &snap, nullptr) != PCR_OK) return fail("train");
     if (snap.failed) return 1;
-    if (pcr_solver_get_factors(s, U.data(), V.data()) != PCR_OK) die("get_factors");
+    if (pcr_solver_get_factors(s, U.data(), V.data()) != PCR_OK) return fail("get_factors");
     printf("Wall-time: %lg secs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 
     write_outputs(param, model, U, V, d1, d2);
-    pcr_solver_destroy(s);
-    pcr_dataset_free(ds);
     return 0;
 }

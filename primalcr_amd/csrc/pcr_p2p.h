@@ -244,9 +244,10 @@ struct P2PComm {
                     close(fd);
                     if (m != MAP_FAILED) {
                         P2PCtl* c = static_cast<P2PCtl*>(m);
-                        const uint64_t age = now_ns() - c->created_ns;
+                        // (the magic word first: rank 0 writes it LAST, with release -- the plain fields may only be read
+                        // behind this acquire; found by the ThreadSanitizer harness, sanitize/p2p_tsan_harness.cpp)
                         if (c->magic.load(std::memory_order_acquire) == PCR_P2P_MAGIC && c->nranks_expected == (uint32_t)nranks &&
-                            age < (uint64_t)(timeout_s * 1e9)) { ctl = c; break; }
+                            now_ns() - c->created_ns < (uint64_t)(timeout_s * 1e9)) { ctl = c; break; }
                         munmap(m, sizeof(P2PCtl));               // not (yet) this job's block: rank 0 will replace it
                     }
                 }

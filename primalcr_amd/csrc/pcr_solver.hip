@@ -142,23 +142,25 @@ struct pcr_solver {
 // launch knobs: pcr_tune() values read once when the solver is created (include/primalcr.h lists them)
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
-        cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = -1, ustep_seq = 0, eval_brute = 0, pipeline = 1, debug = 0,
-        fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_ls_recur = 1, allreduce_chunks = 0, cluster_fence = 1, resort_window = 8, p2p_ll = 16, sweep_dense = 1;
-    std::string ubins, uplan;
+        cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = -1, pipeline = 1, debug = 0,
+        fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_ls_recur = 1, allreduce_chunks = 0, cluster_fence = 1, resort_window = 8, p2p_ll = 16,
+        p2p_timeout_ms = 20000, fault_p2p_skip = 0, fault_p2p_coarse = 0;
+    std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
         sddmm_csc = pcr_tune_int("sddmm_csc", -1); sddmm_tile = pcr_tune_int("sddmm_tile", 0); sweep_wave_cap = pcr_tune_int("sweep_wave_cap", 0);
         ustep_mode = pcr_tune_int("ustep_mode", 0); ustep_many = pcr_tune_int("ustep_many", 0); cluster_k = pcr_tune_int("cluster_k", 4);
         cluster_users = pcr_tune_int("cluster_users", 0); window_cache = pcr_tune_int("window_cache", 1);
-        prepare_merged = pcr_tune_int("prepare_merged", -1); ustep_seq = pcr_tune_int("ustep_seq", 0); eval_brute = pcr_tune_int("eval_brute", 0);
+        prepare_merged = pcr_tune_int("prepare_merged", -1);
         pipeline = pcr_tune_int("pipeline", 1); debug = pcr_tune_int("debug", 0); fault_cluster_member = pcr_tune_int("fault_cluster_member", 0);
         ustep_gram = pcr_tune_int("ustep_gram", -1); count_rows = pcr_tune_int("count_rows", 0);
         ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); win16 = pcr_tune_int("win16", 1); sweep_prefetch = pcr_tune_int("sweep_prefetch", -1);
         ustep_ls_recur = pcr_tune_int("ustep_ls_recur", 1);
         allreduce_chunks = pcr_tune_int("allreduce_chunks", 0); cluster_fence = pcr_tune_int("cluster_fence", 1);
-        resort_window = pcr_tune_int("resort_window", 8); p2p_ll = pcr_tune_int("p2p_ll", 16); sweep_dense = pcr_tune_int("sweep_dense", 1);
+        resort_window = pcr_tune_int("resort_window", 8); p2p_ll = pcr_tune_int("p2p_ll", 16);
+        p2p_timeout_ms = pcr_tune_int("p2p_timeout_ms", 20000); fault_p2p_skip = pcr_tune_int("fault_p2p_skip", 0);
+        fault_p2p_coarse = pcr_tune_int("fault_p2p_coarse", 0);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
-        uplan.clear(); pcr_tune_get("uplan", &uplan);
     }
 };
 
@@ -938,24 +940,15 @@ struct Solver final : pcr_solver {
                 plan.push_back({(int)i, j < ring.size() ? ring[j] : tail_ring[(j - ring.size()) % tail_ring.size()]});
             }
         }
-        if (!tune.uplan.empty()) {                                // experiment: "<class index in launch order>:<lane, 8 = high priority>,..."
-            plan.clear();
-            const char* c = tune.uplan.c_str();
-            while (*c) {
-                char* e = nullptr;
-                const long i = strtol(c, &e, 10); if (*e != ':') break;
-                const long l = strtol(e + 1, &e, 10);
-                if (i >= 0 && i < (long)order.size() && ((l >= 0 && l < nlane) || l == MAXLANE)) plan.push_back({(int)i, (int)l});
-                c = *e ? e + 1 : e;
-            }
-            std::vector<int> seen(order.size(), 0);
-            for (auto& pr : plan) seen[pr.first]++;
-            for (int n1 : seen) if (n1 != 1) { pcr_set_error("bad pcr_tune uplan: every length class (0 .. " + std::to_string(order.size() - 1) + ") once, streams 0 .. " + std::to_string(nlane - 1) + " or 8"); return PCR_ERR_ARG; }
-        }
         if (tune.debug && !plan_announced && (plan_announced = true))
             for (auto& pr : plan) fprintf(stderr, "[pcr] U step: %s on stream %d\n", pname("ustep", *order[pr.first]).c_str(), pr.second);
         // nothing in flight on the solver's stream (the usual case: the V step has just read its objective back): the lanes
-        // need no fork event, their kernels start as soon as they are launched
+        // need no fork event, their kernels start as soon as they are launched.
+        // INVARIANT this rests on: "st idle" means "the solver idle" -- every producer on another stream (the lanes and the
+        // high-priority stream here and in for_bins, ar_st in launch_spmm) is joined back INTO st (a wait of st on its event, or a
+        // host wait) before the call that launched it returns, so no kernel that writes U, V or the sorted state can still be
+        // running on a side stream once st has drained.  Anything that ever launches asynchronously on a lane without joining
+        // it into st must record / wait ev_fork here unconditionally.
         const bool idle = hipStreamQuery(st) == hipSuccess;
         ProfScope wall(this, "wall:ustep", st);
         bool used[MAXLANE + 1] = {};
@@ -1148,7 +1141,7 @@ struct Solver final : pcr_solver {
 #define LVA(HV, WBS, MW) hipLaunchKernelGGL((k_vsweep_all<T, HV, WBS, MW>), dim3(grid), dim3(WBS), lds, st, sh, ba.d_users.p, na, ba.cap, rsa, wb, \
                                         bb.d_users.p, nb, bb.cap, rsb, nb, d_b.p, d_c.p, strict(), skip, bc)
                 // (four workgroups per CU where the longest user's arrays fit a quarter of the LDS: the 64-VGPR symbol)
-                const bool dense = lds <= (size_t)40 * 1024 && tune.sweep_dense;
+                const bool dense = lds <= (size_t)40 * 1024;
                 if (hv) { if (dense) LVA(true, 512, 8); else LVA(true, 512, 1); } else { if (dense) LVA(false, 512, 8); else LVA(false, 512, 1); }
 #undef LVA
             }
@@ -1250,11 +1243,16 @@ struct Solver final : pcr_solver {
         HIPCHK(hipGetLastError());
         return PCR_OK;
     }
-    int fetch_scal(int count) {
-        HIPCHK(hipMemcpyAsync(h_scal, d_scal.p, std::max(count, 44) * sizeof(double), hipMemcpyDeviceToHost, st));   // [32..44): the CG scalars
+    // Every host read of all-reduced data goes through this: wait for the stream, then ask whether a device-driven exchange
+    // ran into its deadline on the way (the data would be garbage; the job's shared error flag is raised for the peers).
+    int sync_checked() {
         HIPCHK(hipStreamSynchronize(st));
         if (p2p && p2p->exchange_failed()) { pcr_set_error("p2p all-reduce: " + p2p->err); return PCR_ERR_COMM; }
         return PCR_OK;
+    }
+    int fetch_scal(int count) {
+        HIPCHK(hipMemcpyAsync(h_scal, d_scal.p, std::max(count, 44) * sizeof(double), hipMemcpyDeviceToHost, st));   // [32..44): the CG scalars
+        return sync_checked();
     }
 
     // all-rank |U|^2 (cached until U changes)
@@ -1263,7 +1261,7 @@ struct Solver final : pcr_solver {
         RC(norm2(d_U.p, (int64_t)n_users * geo.ld, 8));
         RC(allreduce_f64(d_scal.p + 8, 1));
         HIPCHK(hipMemcpyAsync(h_scal + 8, d_scal.p + 8, sizeof(double), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        RC(sync_checked());                                        // (an all-reduced value is only valid if its exchange completed)
         unorm2 = h_scal[8];
         unorm_valid = true;
         return PCR_OK;
@@ -1310,7 +1308,7 @@ struct Solver final : pcr_solver {
     int download_mat(const T* D, int64_t rows, double* H) {
         std::vector<T> tmp((size_t)rows * geo.ld);
         if (!tmp.empty()) HIPCHK(hipMemcpyAsync(tmp.data(), D, tmp.size() * sizeof(T), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        RC(sync_checked());
         for (int64_t i = 0; i < rows; ++i)
             for (int j = 0; j < geo.r; ++j) H[i * geo.r + j] = (double)tmp[(size_t)i * geo.ld + j];
         return PCR_OK;
@@ -1404,7 +1402,7 @@ struct Solver final : pcr_solver {
         }
         if (iters) {
             HIPCHK(hipMemcpyAsync(h_cg, d_cgp, sizeof(CGState), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            RC(sync_checked());
             *iters = h_cg->iters;
         }
         return PCR_OK;
@@ -1511,7 +1509,7 @@ struct Solver final : pcr_solver {
 #undef LU
 #undef LUS
         };
-        if (tune.ustep_seq) RC(for_bins_seq(ubins, "ustep", fn)); else RC(for_ubins(fn));
+        RC(for_ubins(fn));
         return PCR_OK;
     }
 
@@ -1598,7 +1596,7 @@ struct Solver final : pcr_solver {
         }
         // dcg uses gain/discount products in the reference's order: gain / log2(k+1); keep the division exact
         {
-            const bool fast_eval = es.max_raw_levels <= 64 && !tune.eval_brute;
+            const bool fast_eval = es.max_raw_levels <= 64;
             const int64_t* up = which == 0 ? d_uptr.p : es.uptr.p;
             const int32_t* it = which == 0 ? d_item.p : es.item.p;
             auto fn = [&](Bin& b, hipStream_t q) {
@@ -1638,7 +1636,7 @@ struct Solver final : pcr_solver {
         }
         RC(allreduce_f64(d_scal.p + 16, 4));
         HIPCHK(hipMemcpyAsync(h_scal + 16, d_scal.p + 16, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        RC(sync_checked());
         if (err) *err = h_scal[16] / h_scal[17];                    // util.cpp:537
         if (ndcg) *ndcg = h_scal[18] / h_scal[19];
         return PCR_OK;
@@ -1647,7 +1645,9 @@ struct Solver final : pcr_solver {
     // pcrpp.cpp:841-901 / pcr.cpp:616-704
     int train(pcr_log_fn log, void* ctx, pcr_iter_stats* hist) override {
         char line[512];
-        auto emit = [&](const char* s) { if (rank != 0) return; if (log) log(ctx, s); else { fputs(s, stdout); fputc('\n', stdout); fflush(stdout); } };
+        // (a caller's callback receives the lines on EVERY rank -- they are computed from all-reduced values, the same text
+        // everywhere -- so that a job can act on them rank by rank, e.g. deposit its rows for a snapshot; only rank 0 prints)
+        auto emit = [&](const char* s) { if (log) log(ctx, s); else if (rank == 0) { fputs(s, stdout); fputc('\n', stdout); fflush(stdout); } };
         const bool pp = prm.solver_type == PCR_SOLVER_PCRPP;
         snprintf(line, sizeof line, "running %s ndcg_k is %d", pp ? "PrimalCR++" : "PrimalCR", prm.ndcg_k); emit(line);
         snprintf(line, sizeof line, "using %d threads. ", prm.threads); emit(line);
@@ -1758,6 +1758,9 @@ struct Solver final : pcr_solver {
         if (comm || p2p) { pcr_set_error("this solver already has a communicator"); return PCR_ERR_STATE; }
         HIPCHK(hipSetDevice(prm.device));
         p2p.reset(new P2PComm());
+        p2p->ll_timeout_s = std::max(1, tune.p2p_timeout_ms) / 1e3;
+        p2p->fault_skip_call = rank == nranks - 1 ? tune.fault_p2p_skip : 0; p2p->fault_coarse = rank == nranks - 1 && tune.fault_p2p_coarse != 0;     // (test hooks: the last rank misbehaves)
+        p2p->debug = tune.debug != 0;
         if (!p2p->init(shm_name, rank, nranks, (size_t)d2 * geo.ld, sizeof(T), (size_t)std::max(0, tune.p2p_ll) << 20)) {
             pcr_set_error("p2p communicator: " + p2p->err);
             p2p.reset();
@@ -1776,7 +1779,7 @@ struct Solver final : pcr_solver {
         if (comm && ncclCommCount(comm, &n) != ncclSuccess) n = -1;
         return n;
     }
-    int sync() override { HIPCHK(hipStreamSynchronize(st)); return PCR_OK; }
+    int sync() override { RC(sync_checked()); return PCR_OK; }
 };
 
 // ------------------------------------------------------------------------------------------

@@ -177,12 +177,20 @@ __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, cons
         }
         bsync<BLOCK>();
         PPROF(0);
-        // (tmp and the second key array share the prefix-sum array, idle until the loss: 4-byte scores only -- fp64 sorts fully)
+        // (tmp and the second array share the prefix-sum array, idle until the loss: n + 1 doubles hold tmp + a second key array
+        // of 4-byte scores; with 8-byte scores tmp + the permuted li, and the scores are re-read in their new order)
         bool resorted = false;
-        if constexpr (!BIG)
-            if (from_prev)
-                resorted = resort_window<T, LI, BLOCK>(key, li, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, n, reinterpret_cast<int*>(Sx),
-                                                       sizeof(T) == 4 ? reinterpret_cast<T*>(reinterpret_cast<int*>(Sx) + n) : (T*)nullptr, S.resort_d, reinterpret_cast<int*>(red));
+        if constexpr (!BIG) {
+            if (from_prev) {
+                auto levf = [&](int p) { return (int)LiOps<LI>::lev(li[p]); };
+                if constexpr (sizeof(T) == 4)
+                    resorted = resort_window<T, LI, BLOCK>(key, li, levf, rs, n, reinterpret_cast<int*>(Sx), reinterpret_cast<T*>(reinterpret_cast<int*>(Sx) + n),
+                                                           S.resort_d, reinterpret_cast<int*>(red));
+                else
+                    resorted = resort_window_li<T, LI, BLOCK>(key, li, levf, rs, n, reinterpret_cast<int*>(Sx), reinterpret_cast<LI*>(reinterpret_cast<int*>(Sx) + n),
+                                                              S.resort_d, reinterpret_cast<int*>(red), [&](LI x) { return m_in[s0 + LiOps<LI>::idx(x)]; });
+            }
+        }
         if (!resorted) bitonic_sort<T, LI, BLOCK, false, !BIG>(key, li, npad, n);
         PPROF(1);
         for (int p = tid; p < n; p += BLOCK) {

@@ -1,0 +1,100 @@
+// sanitize/p2p_tsan_harness.cpp -- ThreadSanitizer run of the host side of the peer-to-peer communicator (pcr_p2p.h): the
+// POSIX shared-memory rendezvous (O_EXCL creation, magic word written last, age / rank-count check), the generation barrier,
+// the shared error flag and the closing rendezvous -- the lock-free code between the ranks of a job.
+//
+// The ranks run as THREADS of this process (TSan follows one process), with HIP mocked out (mock_hip/).  Every rank maps the
+// control block itself, as in production; so that TSan sees ONE address per shared word, mmap / munmap of the block are routed
+// (by macro, in this harness only) through a table that hands the same mapping to every rank.  Scenarios:
+//   1. N ranks rendezvous (rank 0 deliberately late, a stale block of a "crashed job" left under the name), run 200 scalar and
+//      vector all-reduces on the host-synchronised path (four barriers each), finalize, destroy;
+//   2. the same with one rank reporting an error mid-way: every other rank must leave its barrier with an error, none may hang;
+//   3. a rank that never shows up: the others time out of the rendezvous.
+// Exit code 0 and no "WARNING: ThreadSanitizer" on stderr = clean (tests/test_sanitizers.py).
+#include <sys/mman.h>
+#include <sys/stat.h>
+
+#include <atomic>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+static std::mutex g_map_mu;
+struct Mapping { void* p; size_t len; int refs; };
+static std::map<ino_t, Mapping> g_maps;
+static void* shared_mmap(void* addr, size_t len, int prot, int flags, int fd, off_t off) {
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) return MAP_FAILED;
+    std::lock_guard<std::mutex> lk(g_map_mu);
+    auto it = g_maps.find(sb.st_ino);
+    if (it != g_maps.end() && it->second.len == len) { it->second.refs++; return it->second.p; }
+    void* p = mmap(addr, len, prot, flags, fd, off);
+    if (p != MAP_FAILED) g_maps[sb.st_ino] = Mapping{p, len, 1};
+    return p;
+}
+static int shared_munmap(void* p, size_t len) {
+    std::lock_guard<std::mutex> lk(g_map_mu);
+    for (auto it = g_maps.begin(); it != g_maps.end(); ++it)
+        if (it->second.p == p) {
+            if (--it->second.refs > 0) return 0;
+            g_maps.erase(it);
+            break;
+        }
+    return munmap(p, len);
+}
+#define mmap shared_mmap
+#define munmap shared_munmap
+#include "../pcr_p2p.h"
+#undef mmap
+#undef munmap
+
+static int run_job(const char* name, int N, int fail_rank, int absent_rank, double timeout_s) {
+    std::vector<std::thread> th;
+    std::atomic<int> ok{0}, failed{0};
+    for (int r = 0; r < N; ++r) {
+        if (r == absent_rank) continue;
+        th.emplace_back([&, r]() {
+            if (r == 0) std::this_thread::sleep_for(std::chrono::milliseconds(30));      // the others find no (or a stale) block first
+            P2PComm c;
+            c.timeout_s = timeout_s;
+            if (!c.init(name, r, N, 1000, 4, 0)) { failed++; return; }
+            std::vector<float> v(1000, (float)(r + 1));
+            std::vector<double> s(8, (double)(r + 1));
+            bool good = true;
+            for (int it = 0; it < 200 && good; ++it) {
+                if (r == fail_rank && it == 57) { c.abort_peers(); good = false; break; }
+                good = c.allreduce<float>(v.data(), v.size(), nullptr) && c.allreduce<double>(s.data(), s.size(), nullptr, true);
+            }
+            if (good) ok++; else failed++;
+        });
+    }
+    for (auto& t : th) t.join();
+    fprintf(stderr, "[harness] %-28s ranks %d: %d ok, %d failed\n", name, N, ok.load(), failed.load());
+    return ok.load() * 100 + failed.load();
+}
+
+int main() {
+    int bad = 0;
+    {   // a dead job's block under the name: magic set, old creation time, an error flag, posted words
+        const char* name = "/pcr_tsan_h1";
+        shm_unlink(name);
+        int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+        if (fd >= 0 && ftruncate(fd, sizeof(P2PCtl)) == 0) {
+            void* m = ::mmap(nullptr, sizeof(P2PCtl), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if (m != MAP_FAILED) {
+                P2PCtl* c = static_cast<P2PCtl*>(m);
+                c->created_ns = 1; c->nranks_expected = 4; c->error.store(1); c->posted[1].store(1);
+                c->magic.store(PCR_P2P_MAGIC);
+                ::munmap(m, sizeof(P2PCtl));
+            }
+        }
+        if (fd >= 0) close(fd);
+        if (run_job(name, 4, -1, -1, 20.0) != 400) bad |= 1;
+    }
+    if (run_job("/pcr_tsan_h2", 3, 1, -1, 20.0) != 3) bad |= 2;            // rank 1 fails: all three leave with an error
+    if (run_job("/pcr_tsan_h3", 3, -1, 2, 1.0) != 2) bad |= 4;             // rank 2 never comes: the others time out
+    shm_unlink("/pcr_tsan_h3");
+    fprintf(stderr, bad ? "[harness] FAILED (%d)\n" : "[harness] all scenarios behaved\n", bad);
+    return bad ? 1 : 0;
+}

@@ -218,13 +218,20 @@ class CsrRatings:
 
 
 _synth_lib = None
+_synth_lib_override = None
+
+
+def use_library(path):
+    """Load `path` instead of lib/libpcrsynth.so (the sanitizer build of the generator, tests/test_sanitizers.py)."""
+    global _synth_lib, _synth_lib_override
+    _synth_lib, _synth_lib_override = None, path
 
 
 def _slib():
     global _synth_lib
     if _synth_lib is None:
         import ctypes as C
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpcrsynth.so")
+        path = _synth_lib_override or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpcrsynth.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: build it with make -C primalcr_amd/csrc")
         L = C.CDLL(path)

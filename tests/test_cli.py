@@ -12,11 +12,11 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, ROOT, load_golden
+from conftest import BIN_DIR, GOLDEN_CASES, ROOT, load_golden
 from primalcr_amd import synth
 
-TRAIN = os.path.join(ROOT, "primalcr_amd", "bin", "omp-pmf-train")
-PREDICT = os.path.join(ROOT, "primalcr_amd", "bin", "omp-pmf-predict")
+TRAIN = os.path.join(BIN_DIR, "omp-pmf-train")
+PREDICT = os.path.join(BIN_DIR, "omp-pmf-predict")
 NUM = r"[-+]?(?:\d+\.?\d*|\.\d+)(?:e[-+]?\d+)?"
 
 
@@ -51,6 +51,37 @@ def test_default_model_name_rule(tmp_path):
     r = run([TRAIN, "some/dir/mydata///"], tmp_path)
     assert r.returncode == 1                                       # data dir does not exist ...
     assert (tmp_path / "mydata.model").exists()                    # ... but the model file was created first
+
+
+def test_predict_on_the_host_needs_no_gpu(tmp_path):
+    """BASELINE configs[0] ("plumbing, runs without a GPU"), predict half: `omp-pmf-predict --host` scores with the reference's
+    own loop (one fp64 dot product per line, pmf-predict.cpp:56-64) -- the same bytes as the reference binary writes -- and
+    only when asked: without --host a machine without a GPU gets an error, never a silent CPU path."""
+    import primalcr_amd as pcr
+    from oracle import oracle_py
+    R = synth.generate("tiny")
+    d = synth.write_dir(R, str(tmp_path / "data"))
+    rng = np.random.default_rng(3)
+    U, V = rng.normal(size=(R.d1, 7)), rng.normal(size=(R.d2, 7))
+    pcr.model_save(str(tmp_path / "m.model"), U, V)
+    test_file = os.path.join(d, "test.ratings")
+    r = run([PREDICT, "--host", test_file, "m.model", "ours.txt"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    ours = open(tmp_path / "ours.txt").read()
+    want = "".join("%f\n" % float(U[u] @ V[i]) for u, i in zip(R.tuser, R.titem))
+    got = [float(x) for x in ours.split()]
+    assert len(got) == len(R.tuser) and np.allclose(got, [float(U[u] @ V[i]) for u, i in zip(R.tuser, R.titem)], atol=1e-6)
+    if os.path.exists(oracle_py.REF_PREDICT):
+        ref = run([oracle_py.REF_PREDICT, test_file, "m.model", "ref.txt"], tmp_path)
+        assert ref.returncode == 0 and open(tmp_path / "ref.txt").read() == ours          # byte for byte
+    else:
+        assert ours == want
+    bad = run([PREDICT, "--host", test_file, "m.model"], tmp_path)                         # usage is unchanged
+    assert bad.returncode == 1 and bad.stdout.startswith("Usage: omp-pmf-predict test_file model output_file")
+    import torch
+    if not torch.cuda.is_available():
+        r = run([PREDICT, test_file, "m.model", "gpu.txt"], tmp_path)
+        assert r.returncode == 1 and "no HIP device" in r.stderr
 
 
 def golden_dir(name, tmp_path):
@@ -386,3 +417,77 @@ def test_gpus_option_a_failing_rank_takes_the_job_down(tmp_path):
     assert "timed out" in r.stderr and "a GPU worker failed" in r.stderr
     ok = run([TRAIN, "-k", "8", "-t", "2", "-p", "0", "--gpus", "2", "--devices", "0,0", "--comm", "p2p", d, "m.model"], tmp_path)
     assert ok.returncode == 0, ok.stderr                               # ... and the GPU is fine afterwards
+
+
+@pytest.mark.gpu
+def test_gpus_option_a_rank_that_misses_an_exchange_fails_the_job_within_the_deadline(tmp_path):
+    """The device-driven peer-to-peer exchange waits on a wall-clock deadline (pcr_tune p2p_timeout_ms).  Fault injection: the
+    last rank never launches its 5th exchange.  Its peer's kernel must give up at the deadline (not spin for a minute), answer
+    with poison instead of a made-up sum, and the job must end with exit code 1 and a time-out message -- promptly, and
+    leaving the GPU usable."""
+    import time
+    g, meta, d = golden_dir("mid5", tmp_path)
+    cmd = [TRAIN, "-k", str(int(g["r"])), "-l", repr(float(g["lam"])), "-t", "3", "-p", "0", "--gpus", "2", "--devices", "0,0", "--comm", "p2p",
+           "--tune", "fault_p2p_skip=5", "--tune", "p2p_timeout_ms=700", d, "m.model"]
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    took = time.time() - t0
+    assert r.returncode == 1, (r.stdout, r.stderr)
+    assert "timed out waiting for a peer rank" in r.stderr and "a GPU worker failed" in r.stderr
+    assert os.path.getsize(tmp_path / "m.model") == 0                  # (opened before training, pmf-train.cpp:252-259) no model from a failed job
+    assert took < 30, took
+    ok = run([TRAIN, "-k", str(int(g["r"])), "-t", "2", "-p", "0", "--gpus", "2", "--devices", "0,0", "--comm", "p2p", d, "m.model"], tmp_path)
+    assert ok.returncode == 0, ok.stderr
+
+
+@pytest.mark.gpu
+def test_gpus_option_without_fine_grained_boxes_every_rank_takes_the_host_path(tmp_path):
+    """A rank that cannot get fine-grained memory for its exchange boxes (fault injection on the last rank) must not poll
+    coarse-grained memory for stores that arrive over xGMI: it says so in the control block and ALL ranks use the
+    host-synchronised exchange -- same results as the device-driven run."""
+    g, meta, d = golden_dir("mid5", tmp_path)
+    base = [TRAIN, "-k", str(int(g["r"])), "-l", repr(float(g["lam"])), "-t", "3", "--f64", "-p", "0", "--gpus", "2", "--devices", "0,0",
+            "--comm", "p2p", "--tune", "debug=1"]
+    a = run(base + [d, "a.model"], tmp_path)
+    b = run(base + ["--tune", "fault_p2p_coarse=1", d, "b.model"], tmp_path)
+    assert a.returncode == 0 and b.returncode == 0, b.stderr
+    assert "device-driven (fine-grained boxes)" in a.stderr and "all ranks take the host-synchronised exchange" not in a.stderr
+    assert "all ranks take the host-synchronised exchange" in b.stderr and "every exchange host-synchronised" in b.stderr
+    la = [l for l in a.stdout.split("\n") if l.startswith("Iter")]; lb = [l for l in b.stdout.split("\n") if l.startswith("Iter")]
+    assert len(la) == len(lb) == 4
+    for x, y in zip(la, lb):
+        fx = [float(v) for v in re.findall(NUM, x)]; fy = [float(v) for v in re.findall(NUM, y)]
+        assert fx[:1] + fx[2:] == fy[:1] + fy[2:], (x, y)              # both exchanges sum in rank order: the same digits
+    ma = np.frombuffer(open(tmp_path / "a.model", "rb").read(), np.float64)
+    mb = np.frombuffer(open(tmp_path / "b.model", "rb").read(), np.float64)
+    assert np.array_equal(ma, mb)
+
+
+@pytest.mark.gpu
+def test_gpus_option_snapshots_give_a_resume_point(tmp_path):
+    """SURVEY 8f-4 across ranks: --snapshot-every 2 with two ranks (on the one GPU) writes <model>.iter2 / .iter4 from rows
+    every rank deposits at that iteration; .iter2 equals the model of a 2-iteration run, .iter4 the final model, and 2 more
+    iterations from .iter2 (--init-model, again two ranks) continue the trajectory to the 4-iteration model.
+    The reference writes its model once, at the end (pmf-train.cpp:297-310)."""
+    g, meta, d = golden_dir("mid5", tmp_path)
+    base = [TRAIN, "-k", str(int(g["r"])), "-l", repr(float(g["lam"])), "-p", "0", "--f64", "--gpus", "2", "--devices", "0,0", "--comm", "p2p"]
+    four = run(base + ["-t", "4", "--snapshot-every", "2", d, "four.model"], tmp_path)
+    assert four.returncode == 0, four.stderr
+    two = run(base + ["-t", "2", d, "two.model"], tmp_path)
+    assert two.returncode == 0, two.stderr
+    rd = lambda n: np.frombuffer(open(tmp_path / n, "rb").read(), np.float64)
+    assert (tmp_path / "four.model.iter2").exists() and (tmp_path / "four.model.iter4").exists()
+    assert not (tmp_path / "four.model.iter1").exists() and not (tmp_path / "four.model.iter3").exists()
+    assert np.array_equal(rd("four.model.iter4"), rd("four.model"))
+    assert np.array_equal(rd("four.model.iter2"), rd("two.model"))               # the exchange sums in rank order: same bits
+    resumed = run(base + ["-t", "2", "--init-model", "four.model.iter2", d, "resumed.model"], tmp_path)
+    assert resumed.returncode == 0, resumed.stderr
+    a, b = rd("four.model"), rd("resumed.model")
+    assert a.shape == b.shape and np.nanmax(np.abs(a[2:] - b[2:])) < 1e-9 * np.nanmax(np.abs(a[2:]))
+    iters = lambda s: [re.sub(r"time \S+", "time T", l) for l in s.split("\n") if l.startswith("Iter ")]
+    assert iters(four.stdout)[:3] == iters(two.stdout)
+    # against one rank, to summation-order rounding
+    one = run([TRAIN, "-k", str(int(g["r"])), "-l", repr(float(g["lam"])), "-p", "0", "--f64", "-t", "4", d, "one.model"], tmp_path)
+    c = rd("one.model")
+    assert one.returncode == 0 and np.nanmax(np.abs(a[2:] - c[2:])) < 1e-9 * np.nanmax(np.abs(c[2:]))
+

@@ -288,7 +288,7 @@ VARIANTS = [
     {"lanes": "1"},                                          # every class on the solver's stream
     {"ustep_win_lds": "0"}, {"win16": "0"}, {"win16": "0", "ustep_win_lds": "0"}, {"sweep_prefetch": "1"}, {"sweep_prefetch": "0"}, {"ustep_ls_recur": "0"},                # window-cache widths and copies, sweep load depth, line-search recurrence
     {"ustep_gram": "128"}, {"ustep_gram": "40"}, {"ustep_gram": "64", "window_cache": "0"},   # dual (Gram matrix on MFMA) form for short users
-    {"window_cache": "0"}, {"prepare_merged": "0"}, {"ustep_seq": "1"}, {"pipeline": "0"},   # searching sweeps, per-class prepare, serial classes
+    {"window_cache": "0"}, {"prepare_merged": "0"}, {"pipeline": "0"},   # searching sweeps, per-class prepare, host round trip per U step
     {"sddmm_csc": "1"}, {"sddmm_csc": "1", "spmm_tiles": "16"},   # the CG's SDDMM over the tile-major CSC (wide item tables)
     {"allreduce_chunks": "3"}, {"allreduce_chunks": "5", "spmm_tiles": "16"}, {"allreduce_chunks": "4", "sddmm_csc": "1"},   # SpMM item range by item range (the N > 1 overlap form)
     {"allreduce_chunks": "3", "spmm_tiles": "8"},            # ... with exactly one tile per XCD (the tile <-> XCD affinity inside every range's plan)
@@ -296,8 +296,6 @@ VARIANTS = [
     {"cluster_users": "64"}, {"cluster_users": "64", "cluster_fence": "0"},   # as many clusters as the chip holds (members on every XCD)
     {"resort_window": "0"}, {"resort_window": "2"}, {"resort_window": "64"},   # the sorts' nearly-sorted fast path: off, narrow, widest
     {"spmm_tiles": "2"}, {"spmm_tiles": "4"},                # tiles bound to groups of 4 / 2 XCDs
-    {"sweep_dense": "0"},                                    # k_vsweep_all as the unbounded symbol (three workgroups per CU)
-    {"uplan": "0:0,1:1,2:2,3:3,4:8,5:1,6:0"}, {"uplan": "6:8,5:3,4:2,3:1,2:0,1:8,0:0"},   # other stream placements / launch orders of the U step's classes
 ]
 
 

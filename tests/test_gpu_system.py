@@ -40,6 +40,52 @@ def test_training_through_rccl_single_rank():
         assert a["obj"] == b["obj"] and a["cg_v"] == b["cg_v"] and a["cg_u"] == b["cg_u"]
 
 
+def test_item_range_overlap_through_rccl_single_rank():
+    """The N > 1 overlap form under RCCL itself: with allreduce_chunks the SpMM runs item range by item range, range r's
+    ncclAllReduce is queued on the exchange stream (ar_st) behind an event while range r + 1 computes on the solver's stream,
+    and the objective's scalar all-reduce goes through the solver's stream in between (launch_spmm / allreduce_T /
+    allreduce_f64).  A 1-rank communicator executes exactly that interleaving of streams, events and collectives; the
+    trajectory must equal the one-all-reduce-per-vector run and the communicator-free run bit for bit.
+    Replaces the omp atomics of pcrpp.cpp:240-243, :323-327."""
+    import torch  # noqa: F401
+    import primalcr_amd as pcr
+    from primalcr_amd import synth
+    R = synth.generate("small", seed=7)
+    ds = pcr.Dataset.from_ratings(R)
+    U0, V0 = pcr.initial(R.d1, 24), pcr.initial(R.d2, 24)
+    runs = {}
+    for name, knobs, use_comm in (("plain", {}, False), ("rccl", {}, True), ("rccl-ranges", {"allreduce_chunks": 4}, True),
+                                  ("ranges-no-comm", {"allreduce_chunks": 4}, False)):
+        for prec in (pcr.PCR_F64, pcr.PCR_F32):
+            with pcr.tuned(**knobs):
+                s = pcr.Solver(ds, pcr.Parameter(k=24, precision=prec, do_predict=0, **{"lambda": 50.0}))
+            if use_comm:
+                s.comm_init(pcr.comm_unique_id())
+                assert s.comm_nranks() == 1
+            s.set_factors(U0, V0)
+            g = s.comp_m() is not None and s.obtain_g()              # one all-reduced vector read back directly
+            it = s.iterate(3)
+            U, V = s.get_factors()
+            runs[name, prec] = (g, [(r["obj"], r["cg_v"], r["cg_u"], r["ls_u"]) for r in it], U, V, s.evaluate(1, 10))
+            s.close()
+    for prec in (pcr.PCR_F64, pcr.PCR_F32):
+        rt, at = (1e-11, 1e-9) if prec == pcr.PCR_F64 else (2e-4, 1e-3)
+        # the same kernels with and without RCCL in the way: item ranges switch the fused dot products off either way, so the
+        # communicator-free run and the RCCL run execute the same arithmetic -> the same bits
+        ga, ita, Ua, Va, ea = runs["ranges-no-comm", prec]
+        gb, itb, Ub, Vb, eb = runs["rccl-ranges", prec]
+        assert np.array_equal(ga, gb) and ita == itb and np.array_equal(Ua, Ub) and np.array_equal(Va, Vb) and ea == eb
+        # against the plain run (dot products fused into k_spmm_fin: another summation order) and the one-all-reduce-per-vector
+        # RCCL run: the same trajectory to rounding, identical inner-iteration counts
+        for other in ("plain", "rccl"):
+            g0, it0, U0_, V0_, e0 = runs[other, prec]
+            assert np.allclose(ga, g0, rtol=rt, atol=at), (other, prec)
+            assert [x[1:] for x in ita] == [x[1:] for x in it0], (other, prec)
+            assert np.allclose([x[0] for x in ita], [x[0] for x in it0], rtol=rt)
+            assert np.allclose(Ua, U0_, rtol=0, atol=rt * np.abs(U0_).max() * 100) and np.allclose(Va, V0_, rtol=0, atol=rt * np.abs(V0_).max() * 100)
+            assert np.allclose(ea, e0, atol=rt * 10)
+
+
 def test_headline_config_matches_reference_binary(tmp_path):
     """BASELINE configs[1]: ml1m-shaped synthetic, PrimalCR++ -k 100 -l 5000, 3 outer iterations, default
     (fp32) precision on the GPU vs the UNMODIFIED reference binary (oracle/_ref/omp-pmf-train, all host
