@@ -170,6 +170,7 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *                   CG's own b_k = V_I p_k, no pass)
  *   ustep_gram      dual (Gram-matrix on MFMA) U step for users with at most that many ratings (<= 128; default 0 = off)
  *   cluster_k       4 (default) or 1: workgroups per clustered long user;  cluster_users: how many users get clusters
+ *   cluster2_users  n longest users of the 513..1024 class as clusters of 2 workgroups (default 0: measured, no gain -- NOTES.md)
  *   ubins           "cap:block:resident,..." length classes of the U step below 1024 ratings
  *   spmm_tiles, spmm_chunk, sddmm_tile, sddmm_csc   tiling of the rating-parallel kernels
  *   sweep_wave_cap  ratings up to which a sweep gives a user one wave

@@ -144,7 +144,7 @@ struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
         cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = -1, pipeline = 1, debug = 0,
         fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_ls_recur = 1, allreduce_chunks = 0, cluster_fence = 1, resort_window = 8, p2p_ll = 16,
-        p2p_timeout_ms = 20000, fault_p2p_skip = 0, fault_p2p_coarse = 0;
+        p2p_timeout_ms = 20000, fault_p2p_skip = 0, fault_p2p_coarse = 0, cluster2_users = 0;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -159,7 +159,7 @@ struct Tune {
         allreduce_chunks = pcr_tune_int("allreduce_chunks", 0); cluster_fence = pcr_tune_int("cluster_fence", 1);
         resort_window = pcr_tune_int("resort_window", 8); p2p_ll = pcr_tune_int("p2p_ll", 16);
         p2p_timeout_ms = pcr_tune_int("p2p_timeout_ms", 20000); fault_p2p_skip = pcr_tune_int("fault_p2p_skip", 0);
-        fault_p2p_coarse = pcr_tune_int("fault_p2p_coarse", 0);
+        fault_p2p_coarse = pcr_tune_int("fault_p2p_coarse", 0); cluster2_users = pcr_tune_int("cluster2_users", 0);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -625,6 +625,31 @@ struct Solver final : pcr_solver {
                 b.users.erase(b.users.begin(), b.users.begin() + take);
                 b.cap = b.users.empty() ? 0 : (int)(uptr[b.users[0] + 1] - uptr[b.users[0]]);
             }
+            // pcr_tune("cluster2_users", n): the n longest users of the 513..1024 class as clusters of TWO 512-thread workgroups
+            // (latency form, LDS image of each member's rows) -- the class whose chain ends last on the headline shape.  All
+            // cluster workgroups together stay within half the CUs.  Off by default: measured, NOTES.md (round 4).
+            if (tune.cluster2_users > 0) {
+                Bin head2;
+                head2.block = 512; head2.K = 2;
+                const size_t used = head.users.size() * (size_t)cluster_k;
+                size_t budget2 = std::min<size_t>((size_t)tune.cluster2_users, ((size_t)ncu / 2 > used ? (size_t)ncu / 2 - used : 0) / 2);
+                for (size_t q = nsmall; q < ubins.size() && budget2 > 0; ++q) {
+                    Bin& b = ubins[q];
+                    if (b.limit != 1024 || b.big) continue;
+                    const size_t take = std::min(budget2, b.users.size());
+                    head2.max_lev = b.max_lev;
+                    for (size_t i = 0; i < take; ++i) {
+                        const int32_t u = b.users[i];
+                        const int64_t len = uptr[u + 1] - uptr[u];
+                        head2.users.push_back(u); head2.nnz += len; head2.cap = std::max<int>(head2.cap, (int)len);
+                        b.nnz -= len;
+                    }
+                    b.users.erase(b.users.begin(), b.users.begin() + take);
+                    b.cap = b.users.empty() ? 0 : (int)(uptr[b.users[0] + 1] - uptr[b.users[0]]);
+                    budget2 = 0;
+                }
+                if (!head2.users.empty()) { head2.limit = 1024; ubins.push_back(std::move(head2)); }
+            }
             if (!head.users.empty()) ubins.push_back(std::move(head));
         }
         for (size_t q = nsmall; q < ubins.size(); ++q) {
@@ -852,7 +877,7 @@ struct Solver final : pcr_solver {
 #define UL1(BL) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, BL, false, 1, false, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim))
         UL1(64); UL1(256); UL1(512);
 #undef UL1
-        UL(512, false, 1, true, 8); UL(512, false, 4, true, 8);
+        UL(512, false, 1, true, 8); UL(512, false, 4, true, 8); UL(512, false, 2, true, 8);
         if (sizeof(T) == 4) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 1, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         else UL(512, false, 1, false, 4);
         UL(512, true, 1, true, 8); UL(512, true, 1, false, 4); UL(512, true, 4, true, 8);
@@ -910,9 +935,9 @@ struct Solver final : pcr_solver {
     template <class F>
     int for_ubins(F launch) {
         std::vector<Bin*> order;                       // [cluster class, then the others longest first]
-        for (auto& b : ubins) if (!b.users.empty() && b.K > 1) order.push_back(&b);
+        for (auto& b : ubins) if (!b.users.empty() && b.K > 2) order.push_back(&b);
         const size_t nhead = order.size();
-        for (auto& b : ubins) if (!b.users.empty() && b.K <= 1) order.push_back(&b);
+        for (auto& b : ubins) if (!b.users.empty() && b.K <= 2) order.push_back(&b);
         if (order.empty()) return PCR_OK;
         std::stable_sort(order.begin() + nhead, order.end(), [](const Bin* a, const Bin* b) { return a->cap > b->cap; });
         // plan: (class, stream) in launch order.  Streams: 0..MAXLANE-1 = lane[], MAXLANE = hi.
@@ -988,7 +1013,7 @@ struct Solver final : pcr_solver {
         // (k_ustep: l = the latency form, 8 rows in flight; r = one-wave class with its rows LDS-resident; #n = symbol id -- together
         // with the workgroup size they name ONE kernel symbol, so a profiler's per-symbol rows can be matched to a class)
         const bool us = !strcmp(cls, "ustep");
-        return s + (b.big ? "g" : "") + (b.K > 1 ? "c" : "") + (us && b.K == 1 && b.unr == 8 ? "l" : "") + (us && b.block == 64 && b.rcap > 0 ? "r" : "") +
+        return s + (b.big ? "g" : "") + (b.K > 1 ? "c" : "") + (b.K == 2 ? "2" : "") + (us && b.K == 1 && b.unr == 8 ? "l" : "") + (us && b.block == 64 && b.rcap > 0 ? "r" : "") +
                (b.sym ? "#" + std::to_string(b.sym) : "");
     }
     std::string ustep_classes() override {
@@ -1503,6 +1528,7 @@ struct Solver final : pcr_solver {
             else if (b.block == 64) { if (b.rcap > 0) LU(64, false, 1, true, 4); else LU2(64); }
             else if (b.block == 256) LU2(256);
             else if (b.K == 4) LU(512, false, 4, true, 8);
+            else if (b.K == 2) LU(512, false, 2, true, 8);
             else if (b.unr == 8) LU(512, false, 1, true, 8);
             else LU2(512);
 #undef LU2
