@@ -215,6 +215,57 @@ def cpu_baseline(R, n_pairs, r, lam, sample_ratings=2_000_000, single_thread=Tru
             "sample": f"C restatement, first {nu} users ({int(keep.sum())} ratings, {pairs} pairs), 1 iteration = {secs:.2f} s"}
 
 
+def live_traffic(shape, prec, r, timeout_s=170):
+    """HBM traffic of THIS box, now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE -- one counter per pass, no trace domain
+    beside it, the program directly behind "--": MI355X_MICROARCH.md) of a short replay of the same workload in a child process
+    (16 outer iterations from pcr_initial, no event timing).  Returns ({kernel name: {"launches", "fetch_bytes_per_launch_raw",
+    "write_bytes_per_launch"}}, seconds) or (None, reason).  FETCH_SIZE / WRITE_SIZE are in KiB; the gfx950 doubling of
+    FETCH_SIZE is applied where the bytes are used (analyse)."""
+    import collections, csv, glob, shutil, signal
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    t0 = time.time()
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    tmp = tempfile.mkdtemp(prefix="pcr_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--shape", shape,
+                   "--precision", prec, "--rank-k", str(r), "--steps", "10", "--warmup", "5", "--no-cpu", "--no-f64", "--no-netflix", "--no-rows",
+                   "--no-profile", "--no-live-traffic", "--full-record", os.path.join(tmp, "child.json")]
+            p = subprocess.Popen(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                 text=True, start_new_session=True)
+            try:
+                _, err = p.communicate(timeout=max(20.0, timeout_s - (time.time() - t0)))
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)              # exactly the group this call started
+                p.wait()
+                return None, f"the {ctr} pass did not finish within the time budget"
+            if p.returncode != 0:
+                return None, f"the {ctr} pass exited with {p.returncode}: {(err or '').strip()[-200:]}"
+            files = glob.glob(os.path.join(out, "*", "*counter_collection.csv"))
+            if not files:
+                return None, f"the {ctr} pass left no counter_collection.csv"
+            seen = set()
+            for row in csv.DictReader(open(files[0])):
+                k = row["Kernel_Name"]
+                acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+                d = (row.get("Dispatch_Id"), k)
+                if d not in seen:
+                    seen.add(d)
+                    acc[k]["launches_" + ctr] += 1
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    kernels = {}
+    for k, v in acc.items():
+        nf, nw = v.get("launches_FETCH_SIZE", 0), v.get("launches_WRITE_SIZE", 0)
+        if nf and nw:
+            kernels[k] = {"launches": int(max(nf, nw)), "fetch_bytes_per_launch_raw": 1024.0 * v.get("FETCH_SIZE", 0.0) / nf,
+                          "write_bytes_per_launch": 1024.0 * v.get("WRITE_SIZE", 0.0) / nw}
+    return (kernels, time.time() - t0) if kernels else (None, "no kernel appeared in both passes")
+
+
 class Job:
     """The process group (or none) and this rank's place in it."""
 
@@ -335,7 +386,7 @@ def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name
     return out
 
 
-def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False):
+def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False, live=None):
     """Roofline blocks of one timed run.  wl: dict(d1, d2, nnz, r) of the JOB; run["shard"] is this rank's part."""
     secs, inner, prof, steps = run["secs"], run["inner"], run["prof"], run["steps"]
     d1, d2, nnz, r = wl["d1"], wl["d2"], wl["nnz"], wl["r"]
@@ -364,6 +415,8 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False):
             tj = json.load(open(tpath)).get("workloads", {}).get(traffic_key)      # taken on exactly this workload, or absent
             if tj:
                 traffic, traffic_src = tj.get("kernels", {}), tj.get("source")
+        if live:                                                  # measured on this box by this run (live_traffic)
+            traffic, traffic_src = live, "live"
         # Launches are SAMPLED, so a slot's time in the region is its average times ALL its launches.
         est = {name: ((ms / n) * max(run["launches"][name], n) if n else 0.0) for name, (ms, n) in prof.items()}
         total_ms = sum(v for k, v in est.items() if not k.startswith("wall:"))
@@ -408,9 +461,13 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False):
                 "avg_launch_us": kd["avg_us"],
                 "launches_timed": kd["timed_launches"], "algorithmic_bytes_per_launch": kd["algorithmic_bytes"],
                 "share_of_gpu_time": kd["gpu_time_share"], "binding": kd.get("binding"),
-                "traffic_source": (traffic_src or f"profiles/{TRAFFIC_FILE}") + ": stored rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                  "command (separate runs), per launch, 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md); not "
-                                  "measured by this run" if kd["traffic_bytes"] is not None else None,
+                "traffic_source": (None if kd["traffic_bytes"] is None else
+                                   "live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes started by this run on this box (child "
+                                   "processes replaying 16 iterations of the workload), per launch, 2 x FETCH_SIZE + WRITE_SIZE "
+                                   "(MI355X_MICROARCH.md)" if traffic_src == "live" else
+                                   (traffic_src or f"profiles/{TRAFFIC_FILE}") + ": stored rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                   "command (separate runs), per launch, 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md); not "
+                                   "measured by this run"),
                 "note": "dominant = largest GPU time (average launch duration x launches, HIP events on the launch stream), as "
                         f"rocprofv3 --stats ranks kernels; every {run['prof_period']}th launch of a kernel is event-timed (once-per-step "
                         "kernels every 4th). 'frac' prices the launch's ALGORITHMIC bytes against the HBM peak (the north star's "
@@ -542,7 +599,12 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
     run = runs[main_p]
     secs, objs, inner = run["secs"], run["objs"], run["inner"]
     tkey = f"{shape}:{main_p}" if (users is None and nnz is None and N == 1 and r == (200 if shape == "yahoo" else 100)) else None
-    an = analyse(run, run["rows"], wl, main_p, N, tkey, verbose)
+    live, live_note = None, None
+    if args.live_traffic and N == 1 and profile and tkey and shape == "ml1m":
+        live, took = live_traffic(shape, main_p, r)
+        live_note = f"{took:.0f} s for the two passes" if live else f"not available ({took}): stored passes used"
+        log(f"[traffic] live rocprofv3 --pmc passes: {live_note}")
+    an = analyse(run, run["rows"], wl, main_p, N, tkey, verbose, live)
     value = n_pairs * steps / secs
     rec = {
         "value": value, "unit": "pairs/s", "ms_per_step": 1e3 * secs / steps, "s_per_iter": secs / steps, "steps": steps, "warmup": warmup,
@@ -746,6 +808,9 @@ def main():
                          "samples of the most frequent kernel (11 launches per step): min(16, 11 * steps / 12)")
     ap.add_argument("--full-record", default=None, help="where the full record (per-kernel tables, phases, notes) is written; default "
                                                         "bench_full.json next to bench.py.  stdout carries the compact line only")
+    ap.add_argument("--no-live-traffic", dest="live_traffic", action="store_false",
+                    help="do not start the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic on this box "
+                         "(default N = 1 ml1m run only; the stored passes of profiles/ are used instead)")
     ap.add_argument("--full-line", action="store_true", help="developer tools only: print the full record as the stdout line (tens of KB)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()

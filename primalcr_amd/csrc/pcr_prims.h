@@ -313,62 +313,6 @@ __device__ __forceinline__ bool resort_window(T* key, LI* li, LevF levf, const i
     return false;
 }
 
-// The same for teams with no room for a second key array (k_prepare with 8-byte scores: the idle prefix-sum array holds
-// n + 1 doubles = tmp AND the permuted li, but not n more scores): the verification reads the keys THROUGH tmp instead of from a
-// permuted copy, only li is permuted (through li2), and refill(p) -- the caller's re-read of the score of the rating that now
-// sits at position p, from global memory, where the team has just read this user's segment -- replaces the permuted key copy.
-// Same ranks, same acceptance test, hence the same order as resort_window_d.
-template <typename T, typename LI, int BLOCK, class LevF, class RefillF>
-__device__ __forceinline__ bool resort_window_li(T* key, LI* li, LevF levf, const int* rs, int n, int* tmp, LI* li2, int D, int* flag, RefillF refill) {
-    if (D <= 0) return false;
-    const int tid = btid<BLOCK>();
-#pragma unroll 1
-    for (int tier = 0; tier < 2; ++tier) {
-        if (tier) { bsync<BLOCK>(); D *= 4; if (D >= n) break; }
-#pragma unroll 1
-        for (int p = tid; p < n; p += BLOCK) tmp[p] = -1;
-        if (BLOCK > PCR_WAVE && tid == 0) *flag = 0;
-        bsync<BLOCK>();
-#pragma unroll 1
-        for (int p = tid; p < n; p += BLOCK) {
-            const int lev = levf(p);
-            const int lo = max(rs[lev], p - D), hi = min(rs[lev + 1], p + D + 1);
-            const T kp = key[p];
-            int r = p;
-#pragma unroll 2
-            for (int q = lo; q < p; ++q) r -= (key[q] > kp) ? 1 : 0;
-#pragma unroll 2
-            for (int q = p + 1; q < hi; ++q) r += (key[q] < kp) ? 1 : 0;
-            tmp[r] = p;
-        }
-        bsync<BLOCK>();
-        int bad = 0;
-#pragma unroll 1
-        for (int p = tid; p < n; p += BLOCK) {
-            const int src = tmp[p];
-            bad |= (src < 0) ? 1 : 0;
-            if (p + 1 < rs[levf(p) + 1]) {                                            // the next position belongs to the same run
-                const int nxt = tmp[p + 1];
-                bad |= (nxt < 0 || key[nxt < 0 ? 0 : nxt] < key[src < 0 ? 0 : src]) ? 1 : 0;
-            }
-        }
-        if (BLOCK == PCR_WAVE) bad = __any(bad);
-        else { if (bad) *flag = 1; __syncthreads(); bad = *flag; }
-#ifdef PCR_RESORT_STAT
-        if (tid == 0) { atomicAdd(&g_resort_stat[bad ? 1 : 0], 1ull); atomicAdd(&g_resort_stat[bad ? 3 : 2], (unsigned long long)n); }
-#endif
-        if (bad) continue;
-#pragma unroll 1
-        for (int p = tid; p < n; p += BLOCK) li2[p] = li[tmp[p]];
-        bsync<BLOCK>();
-#pragma unroll 1
-        for (int p = tid; p < n; p += BLOCK) { li[p] = li2[p]; key[p] = refill(li2[p]); }
-        bsync<BLOCK>();
-        return true;
-    }
-    return false;
-}
-
 // first index in [s,e) with a[q] > x   (= s + #{a[q] <= x})
 template <typename T>
 __device__ __forceinline__ int ubound(const T* a, int s, int e, T x) {

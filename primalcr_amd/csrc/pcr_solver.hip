@@ -185,6 +185,9 @@ struct Solver final : pcr_solver {
     hipStream_t lane[MAXLANE] = {};
     hipEvent_t ev_lane[MAXLANE] = {};
     int nlane = 1;
+    int pipe_lanes = 0;                                           // side lanes measured to share the solver's stream's command-processor pipe (they are last in lane[])
+    bool hi_on_solver_pipe = false;
+    std::vector<hipStream_t> hi_spare;                            // high-priority streams that landed on the solver's pipe and were replaced
     ncclComm_t comm = nullptr;
     std::unique_ptr<P2PComm> p2p;                                 // the direct peer-to-peer alternative (pcr_p2p.h)
     bool single() const { return (nranks == 1 && !comm && !p2p) || local_only; }     // no exchange step: one shard, or shard-local mode
@@ -307,6 +310,7 @@ struct Solver final : pcr_solver {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (int i = 0; i < MAXLANE; ++i) if (ev_lane[i]) (void)hipEventDestroy(ev_lane[i]);
         if (hi) (void)hipStreamDestroy(hi);
+        for (hipStream_t x : hi_spare) (void)hipStreamDestroy(x);
         if (ev_hi) (void)hipEventDestroy(ev_hi);
         if (st) (void)hipStreamDestroy(st);
     }
@@ -371,6 +375,39 @@ struct Solver final : pcr_solver {
         *out = us > 150.0;                                         // the spin lasts 300 us
         return PCR_OK;
     }
+    // Do the hardware queues of `busy` and `other` share a command-processor PIPE?  Queues on one pipe share workgroup dispatch:
+    // a queue that merely holds a waiting or spinning kernel slows every kernel of the other (tools/ubench/gate_probe.hip: 27 ->
+    // 62-68 us per dependent 65536-workgroup kernel; NOTES.md round 3).  Measured the same way here: a chain of empty
+    // 65536-workgroup kernels on `busy`, alone (-> *base_us per kernel, once) and with a spinning one-wave kernel on `other`
+    // (twice, the smaller figure counts: noise only adds).  gate_probe's mode 10 is this probe against a known pair: 14.9 -> 24.1 us
+    // per kernel on a shared pipe, 14.9 -> 14.9 otherwise; in the solver's own layout the third side lane reads 14.9 -> 17.9.
+    int shares_pipe(hipStream_t busy, hipStream_t other, long long spin_ticks, double* base_us, bool* out) {
+        constexpr int N = 12;
+        hipEvent_t e0 = ev_get(), e1 = ev_get();
+        auto chain = [&](double* us) -> int {
+            HIPCHK(hipEventRecord(e0, busy));
+            for (int i = 0; i < N; ++i) hipLaunchKernelGGL(k_nop, dim3(65536), dim3(64), 0, busy);
+            HIPCHK(hipEventRecord(e1, busy));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            *us = 1e3 * ms / N;
+            return PCR_OK;
+        };
+        if (*base_us <= 0.0) { double warm; RC(chain(&warm)); RC(chain(base_us)); }
+        double with = 1e30;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, other, spin_ticks);
+            double w = 0.0;
+            RC(chain(&w));
+            HIPCHK(hipStreamSynchronize(other));
+            with = std::min(with, w);
+        }
+        ev_pool.push_back(e0); ev_pool.push_back(e1);
+        *out = with > 1.1 * *base_us;                              // (a queue on another pipe reproduces the base figure to 0.1 us)
+        if (tune.debug) fprintf(stderr, "[pcr] pipe probe: %.1f us per kernel alone, %.1f with the other queue held -> %s\n", *base_us, with, *out ? "SAME pipe" : "separate pipes");
+        return PCR_OK;
+    }
     int pick_lanes() {
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, prm.device) != hipSuccess || khz <= 0) khz = 100000;
@@ -387,6 +424,37 @@ struct Solver final : pcr_solver {
             if (!clash) lane[nlane++] = side[c];
             if (tune.debug) fprintf(stderr, "[pcr] side stream %d %s\n", c, clash ? "shares a queue with a lane" : "is a lane");
         }
+        // Which lane shares the solver's stream's command-processor pipe?  Until round 4 that was arranged by the order in which
+        // the streams are created (and held only while the host application created none of its own before the solver); now it is
+        // measured: a lane on the solver's pipe goes LAST (its class is throttled by, and throttles, the solver's stream: it takes
+        // the class that is off the critical path), and the high-priority stream of the cluster class must NOT be on that pipe
+        // (612 instead of 373 us for the cluster class when it is) -- up to three replacements are tried.
+        const long long spin = ticks * 2;                          // 0.6 ms: longer than the probe's chain (12 x 15-24 us) even on a shared pipe
+        double base_us = 0.0;
+        std::vector<hipStream_t> keep, shared;
+        for (int l = 1; l < nlane; ++l) {
+            bool same = false;
+            RC(shares_pipe(st, lane[l], spin, &base_us, &same));
+            (same ? shared : keep).push_back(lane[l]);
+        }
+        int q = 1;
+        for (hipStream_t x : keep) lane[q++] = x;
+        for (hipStream_t x : shared) lane[q++] = x;
+        pipe_lanes = (int)shared.size();
+        for (int attempt = 0; attempt < 4; ++attempt) {
+            bool same = false;
+            RC(shares_pipe(st, hi, spin, &base_us, &same));
+            hi_on_solver_pipe = same;
+            if (!same || attempt == 3) break;
+            int least = 0, greatest = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            hipStream_t again = nullptr;
+            HIPCHK(hipStreamCreateWithPriority(&again, hipStreamNonBlocking, greatest));
+            hi_spare.push_back(hi);                                // (kept until the solver goes: destroying it would hand its queue to the next stream)
+            hi = again;
+        }
+        if (tune.debug) fprintf(stderr, "[pcr] lanes: %d side lane(s), %d of them on the solver's pipe (placed last); the high-priority stream is %s the solver's pipe\n",
+                                nlane - 1, pipe_lanes, hi_on_solver_pipe ? "ON" : "off");
         return PCR_OK;
     }
 

@@ -169,7 +169,7 @@ __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, cons
         const int npad = next_pow2(n);
         // start from the user's PREVIOUS order when there is one (any earlier sorted state: levels are static, so it is level-
         // grouped already, and from the third iteration on nearly (level, m)-sorted for the new scores too: resort_window)
-        const bool from_prev = !BIG && S.resort_d > 0 && S.prev_valid;
+        const bool from_prev = !BIG && sizeof(T) == 4 && S.resort_d > 0 && S.prev_valid;
 #pragma unroll 4
         for (int p = tid; p < n; p += BLOCK) {                       // (no padding: the sort's elements beyond n are virtual)
             if (from_prev) { const unsigned idx = (unsigned)S.sidx[s0 + p]; li[p] = LiOps<LI>::pack(S.slvl[s0 + p], idx); key[p] = m_in[s0 + idx]; }
@@ -177,20 +177,16 @@ __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, cons
         }
         bsync<BLOCK>();
         PPROF(0);
-        // (tmp and the second array share the prefix-sum array, idle until the loss: n + 1 doubles hold tmp + a second key array
-        // of 4-byte scores; with 8-byte scores tmp + the permuted li, and the scores are re-read in their new order)
+        // (tmp and the second key array share the prefix-sum array, idle until the loss: 4-byte scores only.  With 8-byte scores
+        // there is room for tmp + a permuted index array but not for a second key array; that variant -- keys verified through
+        // tmp, the scores re-read from global memory in their new order -- was built and measured SLOWER than the network
+        // (one-wave teams 22.6 -> 41.5 kclk per user, 512-thread teams 67.5 -> 75.9: the re-read is one more dependent global
+        // round trip in a chain of ~10 us; NOTES.md round 4), so fp64 sorts fully here)
         bool resorted = false;
-        if constexpr (!BIG) {
-            if (from_prev) {
-                auto levf = [&](int p) { return (int)LiOps<LI>::lev(li[p]); };
-                if constexpr (sizeof(T) == 4)
-                    resorted = resort_window<T, LI, BLOCK>(key, li, levf, rs, n, reinterpret_cast<int*>(Sx), reinterpret_cast<T*>(reinterpret_cast<int*>(Sx) + n),
-                                                           S.resort_d, reinterpret_cast<int*>(red));
-                else
-                    resorted = resort_window_li<T, LI, BLOCK>(key, li, levf, rs, n, reinterpret_cast<int*>(Sx), reinterpret_cast<LI*>(reinterpret_cast<int*>(Sx) + n),
-                                                              S.resort_d, reinterpret_cast<int*>(red), [&](LI x) { return m_in[s0 + LiOps<LI>::idx(x)]; });
-            }
-        }
+        if constexpr (!BIG && sizeof(T) == 4)
+            if (from_prev)
+                resorted = resort_window<T, LI, BLOCK>(key, li, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, n, reinterpret_cast<int*>(Sx),
+                                                       reinterpret_cast<T*>(reinterpret_cast<int*>(Sx) + n), S.resort_d, reinterpret_cast<int*>(red));
         if (!resorted) bitonic_sort<T, LI, BLOCK, false, !BIG>(key, li, npad, n);
         PPROF(1);
         for (int p = tid; p < n; p += BLOCK) {

@@ -160,6 +160,9 @@ def test_stdout_line_is_compact_and_carries_what_the_driver_reads():
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=5e-3)
     assert rf["traffic"] and rf["kernel"].startswith("ustep/") and rf["binding"]["level"] == "l2-gather"
     assert rf["achieved"] == pytest.approx(rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9, rel=2e-3)
+    assert rf["traffic_source"] == "stored-pmc:profiles/r03_traffic.json"           # round 3's record replayed stored PMC passes ...
+    live = dict(full, roofline=dict(full["roofline"], traffic_source="live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes started by this run"))
+    assert bench.compact_line(live, None)["roofline"]["traffic_source"] == "live-pmc"   # ... this round's run measures them itself
     cb = back["cpu_baseline"]
     assert cb["kind"] == "reference" and cb["cores"] == 16 and cb["value"] > 0 and cb["unit"] == "pairs/s" and cb["sample"]
     assert cb["single_thread"]["s_per_iter"] > cb["s_per_iter"]

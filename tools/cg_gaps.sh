@@ -1,7 +1,7 @@
 #!/bin/bash
 # Dev tool (GPU box): the gaps between the five kernels of a V-side CG iteration (end of one -> start of the next), from a
 # rocprofv3 kernel trace of the bench workload.  Evidence for DESIGN.md 3.6b ("one persistent kernel per CG iteration").
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tr && rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-f64 --no-profile --steps 10 > /dev/null 2>&1
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tr && rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python3 $GRAFT_REPO_ROOT/bench.py --no-live-traffic --no-cpu --no-f64 --no-profile --steps 10 > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 f=$(ls /tmp/tr/*/*kernel_trace.csv | head -1)
 python - "$f" <<'PY'

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Dev tool (GPU box): kernel timeline of one outer iteration of the bench workload + busy/idle summary.
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tr && rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-profile --steps 20 > /dev/null 2>&1
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tr && rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python3 $GRAFT_REPO_ROOT/bench.py --no-live-traffic --no-cpu --no-profile --steps 20 > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 f=$(ls /tmp/tr/*/*kernel_trace.csv | head -1)
 python tools/trace_gaps.py $f 0.5 0.9

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Dev tool (GPU box): every kernel of one outer iteration of the bench workload (start, duration, gap to the previous end, queue).
 # usage: timeline_full.sh [bench args]
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tr && rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-profile --no-f64 --no-netflix --no-rows --steps 20 "$@" > /dev/null 2>&1
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tr && rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python3 $GRAFT_REPO_ROOT/bench.py --no-live-traffic --no-cpu --no-profile --no-f64 --no-netflix --no-rows --steps 20 "$@" > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 f=$(ls /tmp/tr/*/*kernel_trace.csv | head -1)
 python - "$f" <<'PY'

@@ -19,6 +19,8 @@ __global__ void k_wait(const int* flag) {
         __builtin_amdgcn_s_sleep(32);
     }
 }
+__global__ void k_empty() {}
+__global__ void k_spin_us(int us) { const long long t0 = wall_clock64(); for (int i = 0; i < (1 << 22) && wall_clock64() - t0 < 100ll * us; ++i) __builtin_amdgcn_s_sleep(16); }
 __global__ void k_set(int* flag, int v) { __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 int main(int argc, char** argv) {
     const int nB = argc > 1 ? atoi(argv[1]) : 4, N = argc > 2 ? atoi(argv[2]) : 400;
@@ -62,6 +64,23 @@ int main(int argc, char** argv) {
             CK(hipEventRecord(e1, A)); CK(hipDeviceSynchronize());
             float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) printf("mode %d: %8.2f us per kernel on the busy stream\n", mode, 1e3 * ms / N);
+        }
+    }
+    // mode 10 = the probe pcr_solver.hip's pick_lanes runs (shares_pipe): a chain of 24 EMPTY 16384-workgroup kernels on A, alone and
+    // with a spinning one-wave kernel (nothing queued behind it) on one other stream -- every B stream and H in turn
+    {
+        std::vector<hipStream_t> X = B; X.push_back(H); X.push_back(H2);
+        for (int wgs : {16384, 65536}) {
+        auto chain = [&]() { CK(hipEventRecord(e0, A)); for (int i = 0; i < 24; ++i) hipLaunchKernelGGL(k_empty, dim3(wgs), dim3(64), 0, A); CK(hipEventRecord(e1, A));
+                             CK(hipEventSynchronize(e1)); float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); return 1e3 * ms / 24; };
+        chain();
+        const double base = chain();
+        for (size_t j = 0; j < X.size(); ++j) {
+            hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(64), 0, X[j], 2400);
+            const double with = chain();
+            CK(hipStreamSynchronize(X[j]));
+            printf("mode 10 (%d workgroups): stream %zu%s: %.1f us per empty kernel alone, %.1f with that queue held\n", wgs, j, j == B.size() ? " (high priority)" : "", base, with);
+        }
         }
     }
     return 0;
