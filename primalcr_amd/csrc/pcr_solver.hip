@@ -753,6 +753,8 @@ struct Solver final : pcr_solver {
         const int sh_ws_for_bins = (tune.window_cache && lv.max_levels >= 2 && lv.max_levels <= 9) ? lv.max_levels - 1 : 0;
         {   // LDS residency: what is left of the 160 KB after the r-vectors and the per-rating arrays, in rows of V
             const int nchp = geo.nchunk | 1;
+            // (capping the image at 128 / 112 / 96 / 64 KB, so that workgroups of the short classes could share the CU, changes
+            // nothing: ml1m 1.424-1.438 ms per step at every cap, Netflix-shaped U step 62.6-62.8 ms -- NOTES.md round 4)
             const size_t lim = 160 * 1024;
             for (size_t bi = 0; bi < ubins.size(); ++bi) {
                 Bin& b = ubins[bi];
