@@ -208,15 +208,15 @@ def test_uncounted_gather_figures_are_null_not_zero():
 
 
 def test_every_ustep_class_is_one_kernel_symbol_in_the_committed_profiles():
-    """bench.py prices a HIP-event slot with the PMC bytes of 'its' kernel symbol (profiles/r03_traffic.json): every U-step length
+    """bench.py prices a HIP-event slot with the PMC bytes of 'its' kernel symbol (live passes, or profiles/r04_traffic.json): every U-step length
     class of the committed bench line (ml1m and the Netflix-shaped sub-record) must match exactly one k_ustep symbol of the
     rocprofv3 kernel stats of the same shape, and no symbol may serve two classes."""
     import csv
     sys.path.insert(0, ROOT)
     import bench
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r03_d_bench.json")).read().strip().split("\n")[-1])
+    line = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_full.json")))
     for shape, rec in (("ml1m", line), ("netflix", line["netflix"])):
-        names = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r03_d_{shape}_f32_kernel_stats.csv")))
+        names = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r04_b_{shape}_f32_kernel_stats.csv")))
                  if r["Name"].startswith("void k_ustep<float")]
         slots = [k for k in rec["kernels"] if k.startswith("ustep/")]
         assert len(slots) >= 6 and len(names) >= len(slots)

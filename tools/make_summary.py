@@ -38,9 +38,9 @@ for k in names:
                + (f"{100*hit/(hit+miss):.1f} %" if hit + miss else "-") + " | "
                + (f"{100*bc/act:.1f} %" if act else "-") + " | " + (f"{1000*ld.get('SQ_INSTS_LDS', 0)/(4*wc):.1f}" if wc else "-") + " |")
 open(base + "_counters.md", "w").write("\n".join(out) + "\n")
-tpath = f"{dst}/r03_traffic.json"
+tpath = f"{dst}/{tag[:3]}_traffic.json"
 tj = json.load(open(tpath)) if os.path.exists(tpath) else {"workloads": {}}
-tj["workloads"][f"{shape}:{prec}"] = {"source": f"profiles/r03_traffic.json [{shape}:{prec}] ({tag}, {note})", "kernels": traffic}
+tj["workloads"][f"{shape}:{prec}"] = {"source": f"profiles/{tag[:3]}_traffic.json [{shape}:{prec}] ({tag}, {note})", "kernels": traffic}
 json.dump(tj, open(tpath, "w"), indent=0)
 for tbl, title in (("pmc_occupancy_table.txt", "Achieved occupancy (SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE, its own pass)"),
                    ("pmc_mix_table.txt", "Where the wave cycles go (SQ_WAVE_CYCLES SQ_ACTIVE_INST_* SQ_WAIT_* SQ_INSTS_*, its own pass)")):
