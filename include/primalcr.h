@@ -151,40 +151,37 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  * No environment variable is read anywhere on the product path.  (The ROCm runtime has one prerequisite of its own for
  * pcr_solver_comm_init_p2p / RCCL across processes on hosts whose driver only supports dmabuf IPC:
  * HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment of every rank.)
- *   ustep_mode      1 = latency form of k_ustep for every long class, 2 = throughput form (default: by user count)
- *   ustep_many      user count above which a long class counts as throughput-bound (default CUs/4)
- *   allreduce_chunks N = item ranges of the SpMM whose all-reduces overlap the next range's SpMM (default 1: one all-reduce per
- *                   vector on the solver's stream; opt-in, meant for vectors of 16 MB and more -- about one range per 4 MB)
+ *   ustep_mode      1 = latency form of k_ustep for every long class, 2 = throughput form (default: by user count, more than CUs/4
+ *                   users = throughput)
+ *   cluster_k       4 (default) or 1: workgroups per clustered long user;  cluster_users: how many users get clusters
+ *   ubins           "cap:block:resident,..." length classes of the U step below 1024 ratings
+ *   ustep_gram      dual (Gram-matrix on MFMA) U step for users with at most that many ratings (<= 128; default 0 = off)
+ *   spmm_tiles, spmm_chunk, sddmm_csc   tiling of the rating-parallel kernels (user tiles per XCD group, ratings per lane group, the
+ *                   CG's SDDMM over the tile-major CSC: chosen from the shard's shape)
+ *   window_cache    0 = sweeps search their hinge windows instead of caching them (the form users with more than 9 levels take)
+ *   prepare_merged  1 / 0 = both LDS classes of k_prepare in one launch, or one launch per length class side by side
+ *                   (default: merged below 4 M ratings per shard)
  *   resort_window   half-width D of the nearly-sorted fast path of the per-user sorts (k_prepare, k_ustep's line search): a user
  *                   whose ratings moved by at most D positions since the previous sorted state is re-sorted by windowed rank
  *                   counting (verified; else the full bitonic network); default 8, 0 = always the full network, at most 64
+ *   lanes           concurrent streams for length classes (1 = none: the layout a process ends up with when every side stream
+ *                   shares a hardware queue with the solver's);  pipeline: 0 = host round trip after every U step
+ *   allreduce_chunks N = item ranges of the SpMM whose all-reduces overlap the next range's SpMM (default 1: one all-reduce per
+ *                   vector on the solver's stream; opt-in, meant for vectors of 16 MB and more -- about one range per 4 MB)
  *   p2p_ll          peer-to-peer communicator: vectors of at most this many MB (and the objective's scalars) take the device-driven
  *                   exchange (one kernel per rank, flags inside the 8-byte words, no host barrier); larger ones the host-synchronised
  *                   reduce-scatter / all-gather; default 16, 0 = host-synchronised always.  (If any rank cannot allocate
  *                   fine-grained device memory for its exchange boxes, EVERY rank takes the host-synchronised path.)
  *   p2p_timeout_ms  wall-clock deadline of one device-driven exchange (default 20000): a rank whose peers do not arrive in time
  *                   reports PCR_ERR_COMM, poisons its answers (no rank consumes a made-up sum) and raises the job's error flag
- *   cluster_fence   0 = the hand-off between the workgroups of a cluster without the agent-scope release / acquire (its payload
- *                   is sc1 both ways; measured valid on gfx950, not an architectural guarantee; default 1: fenced)
- *   ustep_ls_recur  0 = k_ustep's first line-search try gathers the rows for its scores (default 1: m - s sum alpha_k b_k from the
- *                   CG's own b_k = V_I p_k, no pass)
- *   ustep_gram      dual (Gram-matrix on MFMA) U step for users with at most that many ratings (<= 128; default 0 = off)
- *   cluster_k       4 (default) or 1: workgroups per clustered long user;  cluster_users: how many users get clusters
- *   cluster2_users  n longest users of the 513..1024 class as clusters of 2 workgroups (default 0: measured, no gain -- NOTES.md)
- *   ubins           "cap:block:resident,..." length classes of the U step below 1024 ratings
- *   spmm_tiles, spmm_chunk, sddmm_tile, sddmm_csc   tiling of the rating-parallel kernels
- *   sweep_wave_cap  ratings up to which a sweep gives a user one wave
- *   sweep_prefetch  0 = the sweeps keep one round of per-rating loads in flight instead of four (default 1)
- *   window_cache    0 = sweeps search their hinge windows instead of caching them
- *   win16           0 = 32-bit window-cache entries even when every user has fewer than 65536 ratings (default 1: 16-bit)
- *   ustep_win_lds   0 = k_ustep reads the window cache from global memory in every sweep (default 1: LDS copy)
- *   prepare_merged  1 / 0 = both LDS classes of k_prepare in one launch, or one launch per length class side by side
- *                   (default: merged below 4 M ratings per shard)
- *   lanes           concurrent streams for length classes (1 = none: the layout a process ends up with when every side stream
- *                   shares a hardware queue with the solver's);  pipeline: 0 = host round trip after every U step
  *   count_rows      1 = the U-step kernels count the rows of V they gather (pcr_solver_counter; a diagnostic that
  *                   costs the short-user classes 10-20 %, so off by default)
  *   debug           1 = print launch decisions to stderr
+ *   win16, ustep_win_lds   test hooks: 0 = the forms shards with very long users take anyway -- 32-bit window-cache entries (a user
+ *                   of 65536 ratings or more), k_ustep reading the window cache from global memory (a class whose LDS is full) --
+ *                   forced on small data so that the fuzz tests cover them
+ * (Knobs of experiments that are closed -- stream placements, serial classes, cluster hand-off without fences, window-cache
+ * widths and copies, sweep load depth, clusters of two -- are gone with their code paths; NOTES.md keeps the numbers.)
  *   fault_cluster_member   test hook: one member of every workgroup cluster leaves early (the launch must report
  *                   PCR_ERR_DEVICE through the bounded hand-off wait instead of hanging)
  *   fault_p2p_skip  test hook: this rank never launches its n-th device-driven exchange (its peers must time out, poison their

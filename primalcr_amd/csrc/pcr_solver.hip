@@ -141,25 +141,22 @@ struct pcr_solver {
 
 // launch knobs: pcr_tune() values read once when the solver is created (include/primalcr.h lists them)
 struct Tune {
-    int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, sddmm_tile = 0, sweep_wave_cap = 0, ustep_mode = 0, ustep_many = 0,
-        cluster_k = 4, cluster_users = 0, window_cache = 1, prepare_merged = -1, pipeline = 1, debug = 0,
-        fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, ustep_win_lds = 1, win16 = 1, sweep_prefetch = -1, ustep_ls_recur = 1, allreduce_chunks = 0, cluster_fence = 1, resort_window = 8, p2p_ll = 16,
-        p2p_timeout_ms = 20000, fault_p2p_skip = 0, fault_p2p_coarse = 0, cluster2_users = 0;
+    int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, ustep_mode = 0, cluster_k = 4, cluster_users = 0, window_cache = 1,
+        prepare_merged = -1, pipeline = 1, debug = 0, fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, allreduce_chunks = 0,
+        resort_window = 8, p2p_ll = 16, p2p_timeout_ms = 20000, fault_p2p_skip = 0, fault_p2p_coarse = 0, win16 = 1, ustep_win_lds = 1;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
-        sddmm_csc = pcr_tune_int("sddmm_csc", -1); sddmm_tile = pcr_tune_int("sddmm_tile", 0); sweep_wave_cap = pcr_tune_int("sweep_wave_cap", 0);
-        ustep_mode = pcr_tune_int("ustep_mode", 0); ustep_many = pcr_tune_int("ustep_many", 0); cluster_k = pcr_tune_int("cluster_k", 4);
+        sddmm_csc = pcr_tune_int("sddmm_csc", -1); ustep_mode = pcr_tune_int("ustep_mode", 0); cluster_k = pcr_tune_int("cluster_k", 4);
         cluster_users = pcr_tune_int("cluster_users", 0); window_cache = pcr_tune_int("window_cache", 1);
         prepare_merged = pcr_tune_int("prepare_merged", -1);
         pipeline = pcr_tune_int("pipeline", 1); debug = pcr_tune_int("debug", 0); fault_cluster_member = pcr_tune_int("fault_cluster_member", 0);
         ustep_gram = pcr_tune_int("ustep_gram", -1); count_rows = pcr_tune_int("count_rows", 0);
-        ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); win16 = pcr_tune_int("win16", 1); sweep_prefetch = pcr_tune_int("sweep_prefetch", -1);
-        ustep_ls_recur = pcr_tune_int("ustep_ls_recur", 1);
-        allreduce_chunks = pcr_tune_int("allreduce_chunks", 0); cluster_fence = pcr_tune_int("cluster_fence", 1);
+        allreduce_chunks = pcr_tune_int("allreduce_chunks", 0);
         resort_window = pcr_tune_int("resort_window", 8); p2p_ll = pcr_tune_int("p2p_ll", 16);
         p2p_timeout_ms = pcr_tune_int("p2p_timeout_ms", 20000); fault_p2p_skip = pcr_tune_int("fault_p2p_skip", 0);
-        fault_p2p_coarse = pcr_tune_int("fault_p2p_coarse", 0); cluster2_users = pcr_tune_int("cluster2_users", 0);
+        fault_p2p_coarse = pcr_tune_int("fault_p2p_coarse", 0);
+        win16 = pcr_tune_int("win16", 1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -600,7 +597,6 @@ struct Solver final : pcr_solver {
                 if (best == 0.0 || cost < best) { best = cost; sweep_wave_cap = c; }
             }
         }
-        if (tune.sweep_wave_cap > 0) sweep_wave_cap = std::max(64, tune.sweep_wave_cap);
         if (tune.debug) fprintf(stderr, "[pcr] sweep wave cap %d\n", sweep_wave_cap);
         make_bins(uptr, nu, &lv.run_ofs, sbins, {std::min(sweep_wave_cap, 4095), 4096}, {64, 512, 512});
         for (auto& b : sbins) RC(b.d_users.upload(b.users, st));
@@ -609,7 +605,7 @@ struct Solver final : pcr_solver {
         for (auto& b : pbins) RC(b.d_users.upload(b.users, st));
         // (measured, ml1m: 1024-thread teams make both launches slower -- k_vsweep_all 23 -> 31 us, k_prepare_all 99 -> 133 us:
         // sixteen one-wave users per workgroup cost more occupancy than the longest user's chain gains -- so 512 stays)
-        sweep_pf4 = tune.sweep_prefetch != 0;
+        sweep_pf4 = true;
         // U step: users with more than 1024 ratings are bound by one CU's gather bandwidth -> clusters of 4 workgroups
         // The U step keeps each user's rows of V in LDS (k_ustep, stage_rows), so its occupancy is set by LDS bytes, not
         // registers: finer length classes than the V side, and a workgroup size that grows with the class.
@@ -654,7 +650,7 @@ struct Solver final : pcr_solver {
         // CUs/4 users: the greedy one-per-CU workgroups of all long classes together must leave CUs for the short classes
         // (ml1m: 88 + 221 users in throughput form 2.09 -> 2.03 ms per iteration; Netflix shape: U step 87 -> 69 ms).
         const int force_mode = tune.ustep_mode;                                                  // 1 latency, 2 throughput
-        const int64_t many_users = tune.ustep_many > 0 ? tune.ustep_many : std::max<int64_t>(1, ncu / 4);
+        const int64_t many_users = std::max<int64_t>(1, ncu / 4);
         auto many = [&](int64_t users) { return force_mode ? force_mode == 2 : users > many_users; };
         int64_t n_mid = 0;
         for (int64_t u = 0; u < nu; ++u) { const int64_t len = uptr[u + 1] - uptr[u]; n_mid += len > 1024 && len <= 4096; }
@@ -692,31 +688,6 @@ struct Solver final : pcr_solver {
                 }
                 b.users.erase(b.users.begin(), b.users.begin() + take);
                 b.cap = b.users.empty() ? 0 : (int)(uptr[b.users[0] + 1] - uptr[b.users[0]]);
-            }
-            // pcr_tune("cluster2_users", n): the n longest users of the 513..1024 class as clusters of TWO 512-thread workgroups
-            // (latency form, LDS image of each member's rows) -- the class whose chain ends last on the headline shape.  All
-            // cluster workgroups together stay within half the CUs.  Off by default: measured, NOTES.md (round 4).
-            if (tune.cluster2_users > 0) {
-                Bin head2;
-                head2.block = 512; head2.K = 2;
-                const size_t used = head.users.size() * (size_t)cluster_k;
-                size_t budget2 = std::min<size_t>((size_t)tune.cluster2_users, ((size_t)ncu / 2 > used ? (size_t)ncu / 2 - used : 0) / 2);
-                for (size_t q = nsmall; q < ubins.size() && budget2 > 0; ++q) {
-                    Bin& b = ubins[q];
-                    if (b.limit != 1024 || b.big) continue;
-                    const size_t take = std::min(budget2, b.users.size());
-                    head2.max_lev = b.max_lev;
-                    for (size_t i = 0; i < take; ++i) {
-                        const int32_t u = b.users[i];
-                        const int64_t len = uptr[u + 1] - uptr[u];
-                        head2.users.push_back(u); head2.nnz += len; head2.cap = std::max<int>(head2.cap, (int)len);
-                        b.nnz -= len;
-                    }
-                    b.users.erase(b.users.begin(), b.users.begin() + take);
-                    b.cap = b.users.empty() ? 0 : (int)(uptr[b.users[0] + 1] - uptr[b.users[0]]);
-                    budget2 = 0;
-                }
-                if (!head2.users.empty()) { head2.limit = 1024; ubins.push_back(std::move(head2)); }
             }
             if (!head.users.empty()) ubins.push_back(std::move(head));
         }
@@ -947,7 +918,7 @@ struct Solver final : pcr_solver {
 #define UL1(BL) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, BL, false, 1, false, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim))
         UL1(64); UL1(256); UL1(512);
 #undef UL1
-        UL(512, false, 1, true, 8); UL(512, false, 4, true, 8); UL(512, false, 2, true, 8);
+        UL(512, false, 1, true, 8); UL(512, false, 4, true, 8);
         if (sizeof(T) == 4) HIPCHK(hipFuncSetAttribute((const void*)k_ustep<T, 512, false, 1, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         else UL(512, false, 1, false, 4);
         UL(512, true, 1, true, 8); UL(512, true, 1, false, 4); UL(512, true, 4, true, 8);
@@ -1005,9 +976,9 @@ struct Solver final : pcr_solver {
     template <class F>
     int for_ubins(F launch) {
         std::vector<Bin*> order;                       // [cluster class, then the others longest first]
-        for (auto& b : ubins) if (!b.users.empty() && b.K > 2) order.push_back(&b);
+        for (auto& b : ubins) if (!b.users.empty() && b.K > 1) order.push_back(&b);
         const size_t nhead = order.size();
-        for (auto& b : ubins) if (!b.users.empty() && b.K <= 2) order.push_back(&b);
+        for (auto& b : ubins) if (!b.users.empty() && b.K <= 1) order.push_back(&b);
         if (order.empty()) return PCR_OK;
         std::stable_sort(order.begin() + nhead, order.end(), [](const Bin* a, const Bin* b) { return a->cap > b->cap; });
         // plan: (class, stream) in launch order.  Streams: 0..MAXLANE-1 = lane[], MAXLANE = hi.
@@ -1083,7 +1054,7 @@ struct Solver final : pcr_solver {
         // (k_ustep: l = the latency form, 8 rows in flight; r = one-wave class with its rows LDS-resident; #n = symbol id -- together
         // with the workgroup size they name ONE kernel symbol, so a profiler's per-symbol rows can be matched to a class)
         const bool us = !strcmp(cls, "ustep");
-        return s + (b.big ? "g" : "") + (b.K > 1 ? "c" : "") + (b.K == 2 ? "2" : "") + (us && b.K == 1 && b.unr == 8 ? "l" : "") + (us && b.block == 64 && b.rcap > 0 ? "r" : "") +
+        return s + (b.big ? "g" : "") + (b.K > 1 ? "c" : "") + (us && b.K == 1 && b.unr == 8 ? "l" : "") + (us && b.block == 64 && b.rcap > 0 ? "r" : "") +
                (b.sym ? "#" + std::to_string(b.sym) : "");
     }
     std::string ustep_classes() override {
@@ -1124,7 +1095,6 @@ struct Solver final : pcr_solver {
                 const int64_t fit = cdiv(nnz_local, (int64_t)ncu * per_cu * ngrp0);
                 if (fit > 64 && fit <= 128) sddmm_tile = (int)((fit + 7) / 8 * 8);
             }
-            if (tune.sddmm_tile > 0) sddmm_tile = std::max(8, tune.sddmm_tile / 8 * 8);
         }
         const int tile = sddmm_tile;
         const int ngrp = 256 / geo.G, span = ngrp * tile;
@@ -1581,7 +1551,7 @@ struct Solver final : pcr_solver {
             // clusters: grid <= one workgroup per CU so that every member of every cluster is resident
             const int grid = b.ugrid;
             char* scr = d_scratch.p + (size_t)b.scratch_ofs * scratch_stride;
-#define LUS(BL, BG, KK, RS, UN, SY) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN, SY>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb, (tune.fault_cluster_member ? 1 : 0) | (tune.count_rows ? 2 : 0) | (state_of_rejected_V ? 4 : 0) | (tune.ustep_ls_recur ? 8 : 0) | (tune.cluster_fence ? 0 : 16), b.wcap)
+#define LUS(BL, BG, KK, RS, UN, SY) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN, SY>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb, (tune.fault_cluster_member ? 1 : 0) | (tune.count_rows ? 2 : 0) | (state_of_rejected_V ? 4 : 0), b.wcap)
 #define LU(BL, BG, KK, RS, UN) LUS(BL, BG, KK, RS, UN, 0)
 #define LU2(BL) do { if (b.sym) LUS(BL, false, 1, false, 4, 1); else LUS(BL, false, 1, false, 4, 0); } while (0)
             if (b.gram) {
@@ -1598,7 +1568,6 @@ struct Solver final : pcr_solver {
             else if (b.block == 64) { if (b.rcap > 0) LU(64, false, 1, true, 4); else LU2(64); }
             else if (b.block == 256) LU2(256);
             else if (b.K == 4) LU(512, false, 4, true, 8);
-            else if (b.K == 2) LU(512, false, 2, true, 8);
             else if (b.unr == 8) LU(512, false, 1, true, 8);
             else LU2(512);
 #undef LU2

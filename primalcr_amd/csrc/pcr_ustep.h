@@ -13,12 +13,11 @@
 // Hand-off protocol (cdna_hip_programming.md Guideline 16): every handed-off byte is stored by an agent-scope (sc1, written
 // through) store -> every wave s_waitcnt vmcnt(0) -> workgroup barrier -> lane 0: agent-scope RELEASE, vmcnt(0), relaxed agent
 // atomic add on the cluster's arrival counter -> relaxed poll (bounded, with s_sleep) -> agent-scope ACQUIRE, vmcnt(0) ->
-// workgroup barrier -> loads of the handed-off bytes (agent-scope, sc1).  That is the formally ordered form and the default.
-// fenced = false (pcr_tune "cluster_fence" = 0) drops the release and the acquire: the payload is sc1 both ways, which is the
-// first row of MI355X_MICROARCH.md's table of hand-offs measured valid WITHOUT the acquire on gfx950 -- measured, "not an
-// architectural guarantee", and its "one workgroup per CU" cell does not hold while other length classes share the CUs -- for
-// 5 % of the cluster class (ml1m: 409 -> 388 us, 1 % of a step).  Placement-independent either way; the launch keeps the grid
-// <= one workgroup per CU so all members are co-resident.
+// workgroup barrier -> loads of the handed-off bytes (agent-scope, sc1).  That is the formally ordered form and the only one.
+// (Without the release and the acquire -- the payload is sc1 both ways, the first row of MI355X_MICROARCH.md's table of hand-offs
+// measured valid on gfx950, "not an architectural guarantee", and its "one workgroup per CU" cell does not hold while other length
+// classes share the CUs -- the cluster class ran 5 % faster, 0.7 % of a step: measured in rounds 2-3, not kept.)
+// Placement-independent; the launch keeps the grid <= one workgroup per CU so all members are co-resident.
 // ---------------------------------------------------------------------------------------
 struct ClusterBufs {
     unsigned* bar;          // one arrival counter per cluster (zeroed before every launch)
@@ -28,16 +27,14 @@ struct ClusterBufs {
 };
 
 template <int K>
-__device__ __forceinline__ void cluster_barrier(unsigned* bar, unsigned& phase, unsigned long long* err, bool fenced) {
+__device__ __forceinline__ void cluster_barrier(unsigned* bar, unsigned& phase, unsigned long long* err) {
     if (K == 1) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // every storing wave drains its write-through stores
     __syncthreads();
     phase += 1;
     if (threadIdx.x == 0) {
-        if (fenced) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (explicit: the compiler may drop the wait behind the write-back)
-        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (explicit: the compiler may drop the wait behind the write-back)
         __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = phase * K;
         unsigned spins = 0;
@@ -48,10 +45,8 @@ __device__ __forceinline__ void cluster_barrier(unsigned* bar, unsigned& phase, 
             if ((++spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
             if (spins > (1u << 21)) { atomicAdd(err, 1ull); break; }
         }
-        if (fenced) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");            // (no instruction: keeps the payload loads below the poll)
     __syncthreads();
@@ -152,7 +147,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && UNR == 4 && !RES && K == 1 
         // exchange buffers are re-used, and the per-XCD L2s are not coherent with each other: every
         // store and load of handed-off bytes is agent-scope (sc1: write-through / L2-revalidated)
         for (int p = r0 + tid; p < r1; p += BLOCK) __hip_atomic_store(buf + p, key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cluster_barrier<K>(bar, phase, counters + 3, !(fault & 16));
+        cluster_barrier<K>(bar, phase, counters + 3);
         for (int p = tid; p < n; p += BLOCK) key[p] = __hip_atomic_load(buf + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
     };
@@ -162,7 +157,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && UNR == 4 && !RES && K == 1 
         double* buf = (xv_par & 1) ? xv1 : xv0; xv_par += 1;
         for (int t = tid; t < ld; t += BLOCK)
             __hip_atomic_store(buf + (size_t)mem * ld + t, part[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cluster_barrier<K>(bar, phase, counters + 3, !(fault & 16));
+        cluster_barrier<K>(bar, phase, counters + 3);
         for (int t = tid; t < ld; t += BLOCK) {
             double sum = 0.0;
             for (int j = 0; j < K; ++j) sum += __hip_atomic_load(buf + (size_t)j * ld + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -266,7 +261,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && UNR == 4 && !RES && K == 1 
             // writes its coefficients beside b (into the sort's index array, idle until the line search) so that b survives
             // until alpha is known.  Not when the sorted state belongs to a REJECTED V_new (its m is not V_I u, quirk q5), not
             // without the window cache (the sweeps then search ms0), not when T is wider than the index array (fp64 in LDS).
-            const bool mrec = (fault & 8) && !(fault & 4) && win && sizeof(T) <= sizeof(LI);
+            const bool mrec = !(fault & 4) && win && sizeof(T) <= sizeof(LI);
             T* cst = mrec ? reinterpret_cast<T*>(li) : key;
             ls_free = mrec ? 1 : 0;
             __syncthreads();

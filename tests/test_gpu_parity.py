@@ -286,14 +286,12 @@ VARIANTS = [
     {"spmm_tiles": "5"}, {"spmm_tiles": "16"}, {"spmm_tiles": "64"},   # user tiles of the SpMM (incl. more tiles than XCDs)
     {"spmm_chunk": "32"}, {"spmm_chunk": "128"},         # ratings per SpMM lane group (the default adapts to the shard: 64 here)
     {"lanes": "1"},                                          # every class on the solver's stream
-    {"ustep_win_lds": "0"}, {"win16": "0"}, {"win16": "0", "ustep_win_lds": "0"}, {"sweep_prefetch": "1"}, {"sweep_prefetch": "0"}, {"ustep_ls_recur": "0"},                # window-cache widths and copies, sweep load depth, line-search recurrence
     {"ustep_gram": "128"}, {"ustep_gram": "40"}, {"ustep_gram": "64", "window_cache": "0"},   # dual (Gram matrix on MFMA) form for short users
     {"window_cache": "0"}, {"prepare_merged": "0"}, {"pipeline": "0"},   # searching sweeps, per-class prepare, host round trip per U step
     {"sddmm_csc": "1"}, {"sddmm_csc": "1", "spmm_tiles": "16"},   # the CG's SDDMM over the tile-major CSC (wide item tables)
     {"allreduce_chunks": "3"}, {"allreduce_chunks": "5", "spmm_tiles": "16"}, {"allreduce_chunks": "4", "sddmm_csc": "1"},   # SpMM item range by item range (the N > 1 overlap form)
     {"allreduce_chunks": "3", "spmm_tiles": "8"},            # ... with exactly one tile per XCD (the tile <-> XCD affinity inside every range's plan)
-    {"cluster_fence": "0"},                                  # cluster hand-off without the agent-scope release / acquire
-    {"cluster_users": "64"}, {"cluster_users": "64", "cluster_fence": "0"},   # as many clusters as the chip holds (members on every XCD)
+    {"cluster_users": "64"},                                 # as many clusters as the chip holds (members on every XCD)
     {"resort_window": "0"}, {"resort_window": "2"}, {"resort_window": "64"},   # the sorts' nearly-sorted fast path: off, narrow, widest
     {"spmm_tiles": "2"}, {"spmm_tiles": "4"},                # tiles bound to groups of 4 / 2 XCDs
 ]
