@@ -115,7 +115,8 @@ __device__ __forceinline__ unsigned ll_word(const unsigned long long* src, unsig
         const unsigned tag = (unsigned)(x >> 32);
         if (tag == seq) return (unsigned)x;
         if (tag == (seq | PCR_LL_POISON) ||
-            ((spins & 255u) == 0 && ((long long)wall_clock64() - w.deadline > 0 || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0))) {
+            // (every 4096 polls, ~0.4 ms: the error word lives in pinned HOST memory -- thousands of waiting threads must not read it often)
+            ((spins & 4095u) == 0 && ((long long)wall_clock64() - w.deadline > 0 || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0))) {
             __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             w.dead = true;
             return 0u;
