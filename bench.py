@@ -215,13 +215,39 @@ def cpu_baseline(R, n_pairs, r, lam, sample_ratings=2_000_000, single_thread=Tru
             "sample": f"C restatement, first {nu} users ({int(keep.sum())} ratings, {pairs} pairs), 1 iteration = {secs:.2f} s"}
 
 
+def pmc_accumulate(csv_path, ctr, acc):
+    """One rocprofv3 --pmc pass (its *counter_collection.csv: one row per dispatch, counter and -- on multi-XCD parts -- instance)
+    summed per kernel into acc[kernel][counter]; acc[kernel]["launches_<ctr>"] counts the dispatches of this pass."""
+    import csv
+    seen = set()
+    for row in csv.DictReader(open(csv_path)):
+        k = row["Kernel_Name"]
+        acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        d = (row.get("Dispatch_Id"), k)
+        if d not in seen:
+            seen.add(d)
+            acc[k]["launches_" + ctr] += 1
+
+
+def pmc_per_launch(acc):
+    """{kernel: launches, raw FETCH_SIZE bytes and WRITE_SIZE bytes per launch} for the kernels seen in BOTH passes (the counters are
+    in KiB; the gfx950 doubling of FETCH_SIZE is applied where the bytes are used)."""
+    kernels = {}
+    for k, v in acc.items():
+        nf, nw = v.get("launches_FETCH_SIZE", 0), v.get("launches_WRITE_SIZE", 0)
+        if nf and nw:
+            kernels[k] = {"launches": int(max(nf, nw)), "fetch_bytes_per_launch_raw": 1024.0 * v.get("FETCH_SIZE", 0.0) / nf,
+                          "write_bytes_per_launch": 1024.0 * v.get("WRITE_SIZE", 0.0) / nw}
+    return kernels
+
+
 def live_traffic(shape, prec, r, timeout_s=170):
     """HBM traffic of THIS box, now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE -- one counter per pass, no trace domain
     beside it, the program directly behind "--": MI355X_MICROARCH.md) of a short replay of the same workload in a child process
     (16 outer iterations from pcr_initial, no event timing).  Returns ({kernel name: {"launches", "fetch_bytes_per_launch_raw",
     "write_bytes_per_launch"}}, seconds) or (None, reason).  FETCH_SIZE / WRITE_SIZE are in KiB; the gfx950 doubling of
     FETCH_SIZE is applied where the bytes are used (analyse)."""
-    import collections, csv, glob, shutil, signal
+    import collections, glob, shutil, signal
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not found"
@@ -247,22 +273,10 @@ def live_traffic(shape, prec, r, timeout_s=170):
             files = glob.glob(os.path.join(out, "*", "*counter_collection.csv"))
             if not files:
                 return None, f"the {ctr} pass left no counter_collection.csv"
-            seen = set()
-            for row in csv.DictReader(open(files[0])):
-                k = row["Kernel_Name"]
-                acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
-                d = (row.get("Dispatch_Id"), k)
-                if d not in seen:
-                    seen.add(d)
-                    acc[k]["launches_" + ctr] += 1
+            pmc_accumulate(files[0], ctr, acc)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    kernels = {}
-    for k, v in acc.items():
-        nf, nw = v.get("launches_FETCH_SIZE", 0), v.get("launches_WRITE_SIZE", 0)
-        if nf and nw:
-            kernels[k] = {"launches": int(max(nf, nw)), "fetch_bytes_per_launch_raw": 1024.0 * v.get("FETCH_SIZE", 0.0) / nf,
-                          "write_bytes_per_launch": 1024.0 * v.get("WRITE_SIZE", 0.0) / nw}
+    kernels = pmc_per_launch(acc)
     return (kernels, time.time() - t0) if kernels else (None, "no kernel appeared in both passes")
 
 

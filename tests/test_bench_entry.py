@@ -184,6 +184,36 @@ def test_stdout_line_is_compact_and_carries_what_the_driver_reads():
     assert small["roofline"] and small["cpu_baseline"] and "top_kernels" not in small and "roofline_phase" not in small
 
 
+def test_live_pmc_passes_are_summed_per_kernel_and_priced_per_launch(tmp_path):
+    """roofline.traffic of the default run comes from two rocprofv3 --pmc passes the bench starts itself: their per-dispatch CSVs are
+    summed per kernel symbol, divided by the dispatches of the pass (KiB -> bytes), and a slot is priced 2 x FETCH_SIZE + WRITE_SIZE
+    (MI355X_MICROARCH.md: gfx950 counts wide coalesced reads at half their bytes)."""
+    import collections
+    sys.path.insert(0, ROOT)
+    import bench
+    name = "void k_ustep<float, 256, false, 1, false, 4, 1>(Shard<float>, Geo, int const*)"
+    head = "Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n"
+    rows = lambda ctr, vals, kname=name: "".join(f'{i},{i},1,1,1,1,51200,7,"{kname}",256,0,0,128,0,96,{ctr},{v},0,1\n' for i, v in enumerate(vals, 1))
+    (tmp_path / "f.csv").write_text(head + rows("FETCH_SIZE", [4096, 4096, 4096 + 8]) + rows("FETCH_SIZE", [1], "k_nop()"))
+    (tmp_path / "w.csv").write_text(head + rows("WRITE_SIZE", [10240, 10240]))
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    bench.pmc_accumulate(str(tmp_path / "f.csv"), "FETCH_SIZE", acc)
+    bench.pmc_accumulate(str(tmp_path / "w.csv"), "WRITE_SIZE", acc)
+    k = bench.pmc_per_launch(acc)
+    assert list(k) == [name]                                        # k_nop appeared in one pass only
+    assert k[name]["launches"] == 3 and k[name]["fetch_bytes_per_launch_raw"] == pytest.approx(1024 * (3 * 4096 + 8) / 3)
+    assert k[name]["write_bytes_per_launch"] == 1024 * 10240
+    assert bench.slot_kernel_match("ustep/256.1024#1", name, "f32") and not bench.slot_kernel_match("ustep/256.512", name, "f32")
+    prof = {"ustep/256.1024#1": (2.0, 5), "wall:ustep": (2.5, 5)}
+    run = dict(secs=0.03, inner={"cg_v": 200, "ls_v": 20, "cg_u": 290000, "ls_u": 120800}, prof=prof, steps=20, prof_period=16,
+               launches={"ustep/256.1024#1": 20, "wall:ustep": 20}, scope={"ustep/256.1024#1": (135301, 200), "wall:ustep": (-1, -1)},
+               shard=(0, 6040, 939809))
+    an = bench.analyse(run, None, dict(d1=6040, d2=3952, nnz=939809, r=100), "f32", 1, None, live=k)
+    rf = an["roofline"]
+    assert rf["traffic"] == int(2 * k[name]["fetch_bytes_per_launch_raw"] + k[name]["write_bytes_per_launch"]) and rf["traffic_source"].startswith("live")
+    assert rf["traffic_over_algorithmic"] == pytest.approx(rf["traffic"] / rf["algorithmic_bytes_per_launch"], abs=0.01)
+
+
 def test_uncounted_gather_figures_are_null_not_zero():
     """--no-rows switches the U step's row counter off: every figure derived from it must read null (unmeasured), never 0.0."""
     sys.path.insert(0, ROOT)
