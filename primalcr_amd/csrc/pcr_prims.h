@@ -57,6 +57,9 @@ struct Shard {
     // nearly-sorted fast path of the sorts (resort_window): half-width of the window a rating may have moved by (0 = always
     // the full bitonic network); prev_valid: sidx / slvl hold a valid permutation of every user (any earlier sorted state)
     int resort_d, prev_valid;
+    // k_prepare's per-user back-off: 1 = the user's last fast-path attempt failed (both tiers, then the network anyway: the
+    // long users of the first ~10 iterations) -> the next prepare sorts it with the network straight away and sets 2 = try again
+    unsigned char* rhint;
 };
 
 // ---------------------------------------------------------------------------------------

@@ -214,6 +214,7 @@ struct Solver final : pcr_solver {
     int spmm_chunk = 128;
     int sddmm_tile = 0;                           // ratings per lane group of k_sddmm (0 = not chosen yet)
     DBuf<uint16_t> d_lvl, d_slvl;
+    DBuf<unsigned char> d_rhint;                  // k_prepare's per-user fast-path back-off (Shard::rhint)
     DBuf<uint16_t> d_win;                          // window cache: 16-bit entries (two per 32-bit entry when a user has >= 65536 ratings)
     DBuf<T> d_ms, d_c, d_mcsr, d_b;
     DBuf<double> d_objp;
@@ -793,6 +794,9 @@ struct Solver final : pcr_solver {
         sh.ws = sh_ws_for_bins;
         sh.resort_d = std::max(0, std::min(tune.resort_window, 64));
         sh.prev_valid = 0;                                  // set once the first k_prepare of the solver's life has been queued
+        RC(d_rhint.alloc(std::max<int64_t>(nu, 1)));
+        HIPCHK(hipMemsetAsync(d_rhint.p, 0, std::max<int64_t>(nu, 1), st));
+        sh.rhint = d_rhint.p;
         {
             int64_t longest = 0;
             for (int64_t u = 0; u < nu; ++u) longest = std::max(longest, uptr[u + 1] - uptr[u]);
@@ -1125,13 +1129,14 @@ struct Solver final : pcr_solver {
     }
     int launch_prepare(const T* Vm) {
         RC(launch_sddmm(Vm, d_item.p, d_mcsr.p));
+        const Shard<T>& shp = sh;
         auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
             const int cap_pad = b.big ? host_pow2(b.cap) : b.cap, rsc = b.max_lev + 2;     // (LDS: the sort pads virtually)
             const size_t bigb = prepare_bytes<T>(b.cap, cap_pad, rsc, b.big ? 8 : 4);
             const size_t lds = small_common(b.block) + (b.big ? 0 : bigb);
             const int grid = b.big ? std::min(nus, scratch_blocks) : nus;
-#define LP(BL, BG) hipLaunchKernelGGL((k_prepare<T, BL, BG>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_mcsr.p, b.cap, cap_pad, rsc, d_scratch.p, scratch_stride, strict())
+#define LP(BL, BG) hipLaunchKernelGGL((k_prepare<T, BL, BG>), dim3(grid), dim3(BL), lds, q, shp, geo, b.d_users.p, nus, d_mcsr.p, b.cap, cap_pad, rsc, d_scratch.p, scratch_stride, strict())
             if (b.big) LP(512, true);
             else if (b.block == 64) LP(64, false);
             else if (b.block == 256) LP(256, false);
@@ -1150,7 +1155,7 @@ struct Solver final : pcr_solver {
             const size_t lds = std::max(wb * wpb, small_common(wbs) + prepare_bytes<T>(bb.cap, cpb, rsb, 4));
             {
                 ProfScope ps(this, "prepare/all", st, ba.nnz + bb.nnz, (int64_t)(na + nb));
-                hipLaunchKernelGGL((k_prepare_all<T, 512>), dim3(nb + cdiv(na, wpb)), dim3(512), lds, st, sh, ba.d_users.p, na, ba.cap, cpa, rsa, wb,
+                hipLaunchKernelGGL((k_prepare_all<T, 512>), dim3(nb + cdiv(na, wpb)), dim3(512), lds, st, shp, ba.d_users.p, na, ba.cap, cpa, rsa, wb,
                                    bb.d_users.p, nb, bb.cap, cpb, rsb, nb, d_mcsr.p, strict());
             }
             if (!pbins[2].users.empty()) { ProfScope ps(this, pname("prepare", pbins[2]), st, pbins[2].nnz, (int64_t)pbins[2].users.size()); fn(pbins[2], st); }

@@ -169,7 +169,12 @@ __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, cons
         const int npad = next_pow2(n);
         // start from the user's PREVIOUS order when there is one (any earlier sorted state: levels are static, so it is level-
         // grouped already, and from the third iteration on nearly (level, m)-sorted for the new scores too: resort_window)
-        const bool from_prev = !BIG && sizeof(T) == 4 && S.resort_d > 0 && S.prev_valid;
+        const bool may_prev = !BIG && sizeof(T) == 4 && S.resort_d > 0 && S.prev_valid;
+        // (a user whose last attempt failed both tiers -- the long users of the first ~10 iterations, whose order still moves -- is
+        // sorted by the network straight away this time, from the CSR order, and tries again next time: a failed attempt costs
+        // ~110 LDS operations per rating on top of the network.  ml1m: 1.432 -> 1.425 ms per step, inside the noise; kept for the
+        // shapes whose long users never settle)
+        const bool from_prev = may_prev && S.rhint[u] != 1;
 #pragma unroll 4
         for (int p = tid; p < n; p += BLOCK) {                       // (no padding: the sort's elements beyond n are virtual)
             if (from_prev) { const unsigned idx = (unsigned)S.sidx[s0 + p]; li[p] = LiOps<LI>::pack(S.slvl[s0 + p], idx); key[p] = m_in[s0 + idx]; }
@@ -188,6 +193,7 @@ __device__ __forceinline__ void prepare_body(char* smem, const Shard<T>& S, cons
                 resorted = resort_window<T, LI, BLOCK>(key, li, [&](int p) { return (int)LiOps<LI>::lev(li[p]); }, rs, n, reinterpret_cast<int*>(Sx),
                                                        reinterpret_cast<T*>(reinterpret_cast<int*>(Sx) + n), S.resort_d, reinterpret_cast<int*>(red));
         if (!resorted) bitonic_sort<T, LI, BLOCK, false, !BIG>(key, li, npad, n);
+        if (may_prev && tid == 0) S.rhint[u] = from_prev ? (resorted ? 0 : 1) : 2;
         PPROF(1);
         for (int p = tid; p < n; p += BLOCK) {
             const LI x = li[p];
