@@ -391,7 +391,7 @@ struct P2PComm {
     }
 
     void abort_peers() { if (ctl) ctl->error.store(1); }
-    // has a device-driven exchange of this rank run out of its poll budget?  (read after a stream synchronisation)
+    // has a device-driven exchange of this rank run into its deadline (or into a peer's poison)?  (read after a stream synchronisation)
     bool exchange_failed() { if (ll_err && *ll_err) { fail("a device-driven exchange timed out waiting for a peer rank"); return true; } return false; }
 
     // Closing rendezvous: the last all-reduce launched its reduce / gather kernel asynchronously after its last host barrier, so a
