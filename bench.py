@@ -639,7 +639,11 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
     if "f64" in runs and main_p == "f32":
         # the reference computes in fp64 throughout: the same K steps with fp64 storage, same clock, same barriers
         r64 = runs["f64"]
-        a64 = analyse(r64, r64["rows"], wl, "f64", N, f"{shape}:f64" if tkey else None)
+        live64 = None
+        if live:                                   # (the fp32 passes worked on this box: the same two passes for the fp64 leg)
+            live64, took = live_traffic(shape, "f64", r)
+            log(f"[traffic] live rocprofv3 --pmc passes, fp64 leg: " + (f"{took:.0f} s" if live64 else f"not available ({took}): stored passes used"))
+        a64 = analyse(r64, r64["rows"], wl, "f64", N, f"{shape}:f64" if tkey else None, live=live64)
         rec["f64"] = {"dtype": "f64", "ms_per_step": 1e3 * r64["secs"] / steps, "value": n_pairs * steps / r64["secs"], "cold_start": r64["cold"],
                       "unit": "pairs/s", "ndcg10_test": r64["te"][1], "pairwise_error_test": r64["te"][0],
                       "objective": r64["objs"][-1], "inner_per_step": {k: v / steps for k, v in r64["inner"].items()},
