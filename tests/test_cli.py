@@ -491,3 +491,31 @@ def test_gpus_option_snapshots_give_a_resume_point(tmp_path):
     c = rd("one.model")
     assert one.returncode == 0 and np.nanmax(np.abs(a[2:] - c[2:])) < 1e-9 * np.nanmax(np.abs(c[2:]))
 
+
+@pytest.mark.gpu
+def test_gpus_option_a_signal_to_the_parent_ends_the_whole_job(tmp_path):
+    """The parent of a --gpus job only waits; SIGTERM / SIGINT to it must reach the GPU workers (forward_signal), the parent must
+    reap them all and exit 1 without a model -- no worker may be left behind holding the GPU."""
+    import signal
+    import time
+    g, meta, d = golden_dir("mid5", tmp_path)
+    cmd = [TRAIN, "-k", str(int(g["r"])), "-l", repr(float(g["lam"])), "-t", "200000", "-p", "0", "--gpus", "2", "--devices", "0,0", "--comm", "p2p",
+           d, "m.model"]
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        p = subprocess.Popen(cmd, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        time.sleep(4.0)                                               # both workers are training by now (a run of minutes)
+        assert p.poll() is None, p.stderr.read()
+        kids = [int(x) for x in subprocess.run(["pgrep", "-P", str(p.pid)], capture_output=True, text=True).stdout.split()]
+        assert len(kids) == 2, kids
+        t0 = time.time()
+        p.send_signal(sig)
+        out, err = p.communicate(timeout=60)
+        assert p.returncode == 1, (p.returncode, err[-2000:])
+        assert time.time() - t0 < 30
+        assert "a GPU worker failed" in err
+        assert os.path.getsize(tmp_path / "m.model") == 0
+        for k in kids:                                               # reaped: neither running nor a zombie of ours
+            assert not os.path.exists(f"/proc/{k}"), k
+    ok = run([TRAIN, "-k", str(int(g["r"])), "-t", "2", "-p", "0", "--gpus", "2", "--devices", "0,0", "--comm", "p2p", d, "m.model"], tmp_path)
+    assert ok.returncode == 0, ok.stderr
+
