@@ -78,6 +78,7 @@ def lib():
     L.pcr_initial.argtypes = [_dp, i64, i64]
     L.pcr_initial_rows.argtypes = [_dp, i64, i64, i64, i64]
     L.pcr_dataset_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.pcr_dataset_load_mt.argtypes = [C.c_char_p, ci, C.POINTER(vp)]
     L.pcr_dataset_load_cached.argtypes = [C.c_char_p, ci, C.c_char_p, C.POINTER(vp)]
     L.pcr_dataset_load_cache.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.pcr_dataset_save_cache.argtypes = [vp, C.c_char_p]
@@ -215,7 +216,9 @@ class Dataset:
     def load(cls, path, cache=None, threads=0):
         """cache: path of the binary side-car (read if it matches the text files, else rebuilt)."""
         h = C.c_void_p()
-        if cache is None:
+        if cache is None and threads > 0:
+            _chk(lib().pcr_dataset_load_mt(os.fsencode(path), threads, C.byref(h)))
+        elif cache is None:
             _chk(lib().pcr_dataset_load(os.fsencode(path), C.byref(h)))
         else:
             _chk(lib().pcr_dataset_load_cached(os.fsencode(path), threads, os.fsencode(cache), C.byref(h)))

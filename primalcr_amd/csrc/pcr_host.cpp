@@ -7,6 +7,8 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <climits>
+#include <cstdint>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +24,18 @@ static thread_local std::string g_err;
 void pcr_set_error(const std::string& msg) { g_err = msg; }
 
 extern "C" const char* pcr_last_error(void) { return g_err.c_str(); }
+
+// No C++ exception may cross the C ABI: a header that promises 2^60 ratings, a meta file with a negative count or a machine
+// that is simply out of memory must come back as an error code, not as std::terminate (found by the malformed-input test,
+// tests/test_host_abi.py, which also runs under AddressSanitizer).
+template <class F>
+static int guarded(const char* what, F&& body) noexcept {
+    try { return body(); }
+    catch (const std::bad_alloc&) { try { pcr_set_error(std::string(what) + ": out of memory"); } catch (...) {} return PCR_ERR_NOMEM; }
+    catch (const std::exception& e) { try { pcr_set_error(std::string(what) + ": " + e.what()); } catch (...) {} return PCR_ERR_ARG; }
+    catch (...) { return PCR_ERR_ARG; }
+}
+static const int64_t kMaxDim = ((int64_t)1 << 31) - 2;             // ids are int32 throughout (the device solver's limit too)
 extern "C" const char* pcr_version(void) { return "primalcr-mi355x 0.1 (gfx950)"; }
 
 // pmf.h:27-48
@@ -126,20 +140,21 @@ extern "C" int pcr_dataset_from_triplets(int64_t d1, int64_t d2, int64_t nnz, co
         pcr_set_error("pcr_dataset_from_triplets: bad argument");
         return PCR_ERR_ARG;
     }
-    pcr_dataset* ds = new (std::nothrow) pcr_dataset();
-    if (!ds) { pcr_set_error("out of memory"); return PCR_ERR_NOMEM; }
-    int rc = build_train_csr(d1, d2, nnz, user, item, val, ds->train);
-    if (rc != PCR_OK) { delete ds; return rc; }
-    for (int64_t z = 0; z < tnnz; ++z)
-        if (titem[z] < 0 || titem[z] >= d2 || tuser[z] < 0) {
-            pcr_set_error("test rating " + std::to_string(z) + " has user/item id outside the meta dimensions");
-            delete ds;
-            return PCR_ERR_ARG;
-        }
-    build_test_csr(d1, d2, tnnz, tuser, titem, tval, ds->test);
-    ds->tnnz_file = tnnz;
-    *out = ds;
-    return PCR_OK;
+    if (d1 > kMaxDim || d2 > kMaxDim) { pcr_set_error("pcr_dataset_from_triplets: more than 2^31 - 2 users or items"); return PCR_ERR_UNSUPPORTED; }
+    return guarded("pcr_dataset_from_triplets", [&]() -> int {
+        std::unique_ptr<pcr_dataset> ds(new pcr_dataset());
+        int rc = build_train_csr(d1, d2, nnz, user, item, val, ds->train);
+        if (rc != PCR_OK) return rc;
+        for (int64_t z = 0; z < tnnz; ++z)
+            if (titem[z] < 0 || titem[z] >= d2 || tuser[z] < 0) {
+                pcr_set_error("test rating " + std::to_string(z) + " has user/item id outside the meta dimensions");
+                return PCR_ERR_ARG;
+            }
+        build_test_csr(d1, d2, tnnz, tuser, titem, tval, ds->test);
+        ds->tnnz_file = tnnz;
+        *out = ds.release();
+        return PCR_OK;
+    });
 }
 
 // The same data set from arrays that already ARE the reference's SparseMat layout (util.h:390-413: what convert() leaves,
@@ -166,18 +181,20 @@ extern "C" int pcr_dataset_from_csr(int64_t d1, int64_t d2, const int64_t* index
     }
     for (int64_t z = 0; z < tnnz; ++z)
         if (titem[z] < 0 || titem[z] >= d2) { pcr_set_error("pcr_dataset_from_csr: test item id outside [0, d2)"); return PCR_ERR_ARG; }
-    pcr_dataset* ds = new (std::nothrow) pcr_dataset();
-    if (!ds) { pcr_set_error("out of memory"); return PCR_ERR_NOMEM; }
-    ds->train.d1 = ds->test.d1 = d1; ds->train.d2 = ds->test.d2 = d2;
-    ds->train.index.assign(index, index + d1 + 1);
-    ds->train.item.assign(item, item + nnz);
-    ds->train.val.assign(val, val + nnz);
-    if (tindex) ds->test.index.assign(tindex, tindex + d1 + 1); else ds->test.index.assign(d1 + 1, 0);
-    ds->test.item.assign(titem, titem + tnnz);
-    ds->test.val.assign(tval, tval + tnnz);
-    ds->tnnz_file = tnnz;
-    *out = ds;
-    return PCR_OK;
+    if (d1 > kMaxDim || d2 > kMaxDim) { pcr_set_error("pcr_dataset_from_csr: more than 2^31 - 2 users or items"); return PCR_ERR_UNSUPPORTED; }
+    return guarded("pcr_dataset_from_csr", [&]() -> int {
+        std::unique_ptr<pcr_dataset> ds(new pcr_dataset());
+        ds->train.d1 = ds->test.d1 = d1; ds->train.d2 = ds->test.d2 = d2;
+        ds->train.index.assign(index, index + d1 + 1);
+        ds->train.item.assign(item, item + nnz);
+        ds->train.val.assign(val, val + nnz);
+        if (tindex) ds->test.index.assign(tindex, tindex + d1 + 1); else ds->test.index.assign(d1 + 1, 0);
+        ds->test.item.assign(titem, titem + tnnz);
+        ds->test.val.assign(tval, tval + tnnz);
+        ds->tnnz_file = tnnz;
+        *out = ds.release();
+        return PCR_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -234,7 +251,7 @@ static inline bool parse_one(const char*& p, const char* end, int32_t& u, int32_
         skip_ws();
         const char* s = p;
         long x = 0;
-        while (p < end && *p >= '0' && *p <= '9') { x = x * 10 + (*p - '0'); ++p; }
+        while (p < end && *p >= '0' && *p <= '9') { if (x < ((long)1 << 40)) x = x * 10 + (*p - '0'); ++p; }     // (saturates: an absurd token is an id out of range, not an overflow)
         if (p == s || (p < end && (*p == '.' || *p == '-' || *p == '+' || *p == 'e' || *p == 'E'))) { p = s; return false; }
         out = x;
         return true;
@@ -259,6 +276,8 @@ static inline bool parse_one(const char*& p, const char* end, int32_t& u, int32_
             if (nd + fd > 15 || (p < end && *p >= '0' && *p <= '9')) simple = false;
             else if (fd > 0) val = (double)(ip * (long)P10[fd] + fp) / P10[fd];
         }
+        // 1-based ids that do not fit int32 are malformed lines, not ids that wrap around into the valid range
+        if (a < 1 || b < 1 || a > (long)INT32_MAX || b > (long)INT32_MAX) { p = save; return false; }
         if (simple && (p >= end || *p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == 0)) {
             u = (int32_t)(a - 1); it = (int32_t)(b - 1); v = neg ? -val : val;
             return true;
@@ -282,6 +301,7 @@ static inline bool parse_one(const char*& p, const char* end, int32_t& u, int32_
     double dv = strtod(p, &e);
     if (e == p) return false;
     p = e;
+    if (i < INT32_MIN + 1 || j < INT32_MIN + 1 || i > (long)INT32_MAX || j > (long)INT32_MAX) return false;
     u = (int32_t)(i - 1); it = (int32_t)(j - 1); v = dv;
     return true;
 }
@@ -291,10 +311,10 @@ static inline bool parse_one(const char*& p, const char* end, int32_t& u, int32_
 // piece, then every piece parses into its slice of the output.
 static int parse_ratings(const std::string& path, int64_t nnz, std::vector<int32_t>& user,
                          std::vector<int32_t>& item, std::vector<double>& val, int threads) {
+    if (nnz < 0) { pcr_set_error(path + ": a negative rating count in meta"); return PCR_ERR_IO; }
     std::vector<char> buf;
     int rc = read_file(path, buf);
     if (rc != PCR_OK) return rc;
-    user.resize(nnz); item.resize(nnz); val.resize(nnz);
     const char* base = buf.data();
     const size_t len = buf.size() - 1;
     int T = std::max(1, std::min(threads, 64));
@@ -326,6 +346,7 @@ static int parse_ratings(const std::string& path, int64_t nnz, std::vector<int32
         pcr_set_error(path + ": expected " + std::to_string(nnz) + " ratings, found " + std::to_string(first[T]));
         return PCR_ERR_IO;
     }
+    user.resize(nnz); item.resize(nnz); val.resize(nnz);          // (only now: meta may promise any number)
     std::vector<int64_t> bad(T, -1);
     {
         std::vector<std::thread> th;
@@ -362,17 +383,20 @@ extern "C" int pcr_dataset_load_mt(const char* dir, int threads, pcr_dataset** o
     }
     if (fscanf(fp, "%ld %1023s", &tnnz, tname) == 2) have_test = true;   // third line optional (util.cpp:18)
     fclose(fp);
-    std::vector<int32_t> u, i, tu, ti;
-    std::vector<double> v, tv;
-    int rc = parse_ratings(d + "/" + name, nnz, u, i, v, threads);
-    if (rc != PCR_OK) return rc;
-    if (have_test) {
-        rc = parse_ratings(d + "/" + tname, tnnz, tu, ti, tv, threads);
+    if (m < 0 || n < 0 || m > kMaxDim || n > kMaxDim) { pcr_set_error(metap + ": user / item counts must lie in [0, 2^31 - 2]"); return PCR_ERR_IO; }
+    return guarded("pcr_dataset_load", [&]() -> int {
+        std::vector<int32_t> u, i, tu, ti;
+        std::vector<double> v, tv;
+        int rc = parse_ratings(d + "/" + name, nnz, u, i, v, threads);
         if (rc != PCR_OK) return rc;
-    } else {
-        tnnz = 0;
-    }
-    return pcr_dataset_from_triplets(m, n, nnz, u.data(), i.data(), v.data(), tnnz, tu.data(), ti.data(), tv.data(), out);
+        if (have_test) {
+            rc = parse_ratings(d + "/" + tname, tnnz, tu, ti, tv, threads);
+            if (rc != PCR_OK) return rc;
+        } else {
+            tnnz = 0;
+        }
+        return pcr_dataset_from_triplets(m, n, nnz, u.data(), i.data(), v.data(), tnnz, tu.data(), ti.data(), tv.data(), out);
+    });
 }
 
 // ---- binary side-car cache of the converted data set
@@ -429,7 +453,12 @@ int load_cache(const char* path, const int64_t want[6], pcr_dataset** out) {
     CacheHeader h;
     auto fail = [&](const char* why) { fclose(f); pcr_set_error(std::string(path) + ": " + why); return PCR_ERR_IO; };
     if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, kCacheMagic, 8) != 0) return fail("not a data set cache of this version");
-    if (h.d1 < 0 || h.d2 < 0 || h.nnz < 0 || h.tnnz < 0) return fail("corrupt header");
+    if (h.d1 < 0 || h.d2 < 0 || h.nnz < 0 || h.tnnz < 0 || h.d1 > kMaxDim || h.d2 > kMaxDim) return fail("corrupt header");
+    {   // the header must describe exactly this file before anything is allocated from it
+        struct stat sb;
+        const __int128 want_bytes = (__int128)sizeof(h) + 2 * (__int128)(h.d1 + 1) * 8 + (__int128)(h.nnz + h.tnnz) * 12;
+        if (fstat(fileno(f), &sb) != 0 || (__int128)sb.st_size != want_bytes) return fail("truncated or corrupt (size does not match the header)");
+    }
     if (want) for (int i = 0; i < 6; ++i) if (h.stamp[i] != want[i]) return fail("stale (the text files changed)");
     std::unique_ptr<pcr_dataset> ds(new pcr_dataset);
     ds->train.d1 = ds->test.d1 = h.d1; ds->train.d2 = ds->test.d2 = h.d2; ds->tnnz_file = h.tnnz_file;
@@ -438,7 +467,13 @@ int load_cache(const char* path, const int64_t want[6], pcr_dataset** out) {
         return fail("truncated");
     if (ds->train.index.front() != 0 || ds->train.index.back() != h.nnz || ds->test.index.front() != 0 || ds->test.index.back() != h.tnnz)
         return fail("corrupt row pointers");
+    for (int64_t u = 0; u < h.d1; ++u)
+        if (ds->train.index[u + 1] < ds->train.index[u] || ds->test.index[u + 1] < ds->test.index[u]) return fail("corrupt row pointers");
     for (int32_t j : ds->train.item) if (j < 0 || j >= h.d2) return fail("item id out of range");
+    for (int32_t j : ds->test.item) if (j < 0 || j >= h.d2) return fail("item id out of range");
+    for (int64_t u = 0; u < h.d1; ++u)
+        for (int64_t z = ds->train.index[u] + 1; z < ds->train.index[u + 1]; ++z)
+            if (ds->train.item[z] <= ds->train.item[z - 1]) return fail("items of a user not ascending");
     fclose(f);
     *out = ds.release();
     return PCR_OK;
@@ -448,13 +483,13 @@ int load_cache(const char* path, const int64_t want[6], pcr_dataset** out) {
 extern "C" int pcr_dataset_save_cache(const pcr_dataset* ds, const char* path) { return save_cache(ds, path, nullptr); }
 extern "C" int pcr_dataset_load_cache(const char* path, pcr_dataset** out) {
     if (!path || !out) { pcr_set_error("pcr_dataset_load_cache: bad argument"); return PCR_ERR_ARG; }
-    return load_cache(path, nullptr, out);
+    return guarded("pcr_dataset_load_cache", [&]() -> int { return load_cache(path, nullptr, out); });
 }
 extern "C" int pcr_dataset_load_cached(const char* dir, int threads, const char* cache, pcr_dataset** out) {
     if (!dir || !cache || !out) { pcr_set_error("pcr_dataset_load_cached: bad argument"); return PCR_ERR_ARG; }
     int64_t stamp[6];
     const bool have = dir_stamps(dir, stamp);
-    if (have && load_cache(cache, stamp, out) == PCR_OK) return PCR_OK;
+    if (have && guarded("pcr_dataset_load_cached", [&]() -> int { return load_cache(cache, stamp, out); }) == PCR_OK) return PCR_OK;
     int rc = pcr_dataset_load_mt(dir, threads, out);
     if (rc != PCR_OK) return rc;
     if (have) (void)save_cache(*out, cache, stamp);      // best effort: a read-only data directory is not an error
@@ -600,13 +635,19 @@ extern "C" int pcr_model_load(const char* path, int64_t* d1, int64_t* d2, int64_
     if (!fp) { pcr_set_error(std::string("can't open model file ") + path); return PCR_ERR_IO; }
     long hdr[2];
     int rc = PCR_OK;
+    struct stat sb;
+    const bool have_size = fstat(fileno(fp), &sb) == 0;
     do {
         if (fread(hdr, sizeof(long), 2, fp) != 2 || hdr[0] < 0 || hdr[1] < 0) { rc = PCR_ERR_IO; break; }
         long m1 = hdr[0], kk = hdr[1];
+        // (a corrupt header must not turn into a 2^60-element read or, in a caller that sizes its buffers from the query call, an
+        // allocation of that size: the first matrix has to fit the file)
+        if (!have_size || (__int128)m1 * kk * 8 + 32 > (__int128)sb.st_size) { rc = PCR_ERR_IO; break; }
         if (U) { if (fread(U, sizeof(double), (size_t)(m1 * kk), fp) != (size_t)(m1 * kk)) { rc = PCR_ERR_IO; break; } }
         else fseek(fp, (long)sizeof(double) * m1 * kk, SEEK_CUR);
-        if (fread(hdr, sizeof(long), 2, fp) != 2 || hdr[1] != kk) { rc = PCR_ERR_IO; break; }
+        if (fread(hdr, sizeof(long), 2, fp) != 2 || hdr[1] != kk || hdr[0] < 0) { rc = PCR_ERR_IO; break; }
         long m2 = hdr[0];
+        if ((__int128)(m1 + m2) * kk * 8 + 32 != (__int128)sb.st_size) { rc = PCR_ERR_IO; break; }
         if (V && fread(V, sizeof(double), (size_t)(m2 * kk), fp) != (size_t)(m2 * kk)) { rc = PCR_ERR_IO; break; }
         if (d1) *d1 = m1;
         if (d2) *d2 = m2;

@@ -1855,6 +1855,17 @@ struct Solver final : pcr_solver {
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
+// No C++ exception may cross the C ABI (a host allocation that fails while a 700 M-rating shard is being set up is an error
+// code, not std::terminate).
+template <class F>
+static int abi_guard(const char* what, F&& body) noexcept {
+    try { return body(); }
+    catch (const std::bad_alloc&) { try { pcr_set_error(std::string(what) + ": out of host memory"); } catch (...) {} return PCR_ERR_NOMEM; }
+    catch (const std::exception& e) { try { pcr_set_error(std::string(what) + ": " + e.what()); } catch (...) {} return PCR_ERR_ARG; }
+    catch (...) { return PCR_ERR_ARG; }
+}
+#define PCR_ABI(name, expr) return abi_guard(name, [&]() -> int { return (expr); })
+
 extern "C" {
 
 static int solver_create(const pcr_dataset* ds, const pcr_params* p, int rank, int nranks, int64_t shard_first, int64_t d1_total, pcr_solver** out) {
@@ -1863,22 +1874,19 @@ static int solver_create(const pcr_dataset* ds, const pcr_params* p, int rank, i
         pcr_set_error("wrong solver type (" + std::to_string(p->solver_type) + "): 1 = PrimalCR, 2 = PrimalCR++");
         return PCR_ERR_ARG;
     }
-    int rc;
-    if (p->precision == PCR_F64) {
-        auto* s = new Solver<double>();
-        rc = s->init(ds, p, rank, nranks, shard_first, d1_total);
-        if (rc != PCR_OK) { delete s; return rc; }
-        *out = s;
-    } else if (p->precision == PCR_F32) {
-        auto* s = new Solver<float>();
-        rc = s->init(ds, p, rank, nranks, shard_first, d1_total);
-        if (rc != PCR_OK) { delete s; return rc; }
-        *out = s;
-    } else {
-        pcr_set_error("precision must be PCR_F32 or PCR_F64");
-        return PCR_ERR_ARG;
-    }
-    return PCR_OK;
+    if (p->precision != PCR_F64 && p->precision != PCR_F32) { pcr_set_error("precision must be PCR_F32 or PCR_F64"); return PCR_ERR_ARG; }
+    return abi_guard("pcr_solver_create", [&]() -> int {
+        if (p->precision == PCR_F64) {
+            std::unique_ptr<Solver<double>> s(new Solver<double>());
+            RC(s->init(ds, p, rank, nranks, shard_first, d1_total));
+            *out = s.release();
+        } else {
+            std::unique_ptr<Solver<float>> s(new Solver<float>());
+            RC(s->init(ds, p, rank, nranks, shard_first, d1_total));
+            *out = s.release();
+        }
+        return PCR_OK;
+    });
 }
 int pcr_solver_create(const pcr_dataset* ds, const pcr_params* p, int rank, int nranks, pcr_solver** out) {
     return solver_create(ds, p, rank, nranks, -1, 0, out);
@@ -1899,11 +1907,11 @@ int pcr_comm_unique_id(void* id128) {
     return PCR_OK;
 }
 #define S_OR_ARG if (!s) { pcr_set_error("null solver"); return PCR_ERR_ARG; }
-int pcr_solver_comm_init(pcr_solver* s, const void* id128) { S_OR_ARG; return s->comm_init(id128); }
+int pcr_solver_comm_init(pcr_solver* s, const void* id128) { S_OR_ARG; PCR_ABI("pcr_solver_comm_init", s->comm_init(id128)); }
 int pcr_solver_comm_init_p2p(pcr_solver* s, const char* shm_name) {
     S_OR_ARG;
     if (!shm_name || shm_name[0] != '/') { pcr_set_error("pcr_solver_comm_init_p2p: the name must start with '/' (shm_open)"); return PCR_ERR_ARG; }
-    return s->comm_init_p2p(shm_name);
+    PCR_ABI("pcr_solver_comm_init_p2p", s->comm_init_p2p(shm_name));
 }
 int pcr_solver_comm_nranks(pcr_solver* s) { if (!s) return -1; return s->comm_nranks(); }
 int pcr_solver_counter(pcr_solver* s, const char* name, double* value) {
@@ -1924,21 +1932,21 @@ int pcr_solver_shard(const pcr_solver* s, int64_t* first_user, int64_t* n_users,
     if (nnz_local) *nnz_local = s->nnz_local;
     return PCR_OK;
 }
-int pcr_solver_set_factors(pcr_solver* s, const double* U, const double* V) { S_OR_ARG; return s->set_factors(U, V, false); }
-int pcr_solver_get_factors(pcr_solver* s, double* U, double* V) { S_OR_ARG; return s->get_factors(U, V, false); }
-int pcr_solver_set_factors_local(pcr_solver* s, const double* U_local, const double* V) { S_OR_ARG; return s->set_factors(U_local, V, true); }
-int pcr_solver_get_factors_local(pcr_solver* s, double* U_local, double* V) { S_OR_ARG; return s->get_factors(U_local, V, true); }
-int pcr_comp_m(pcr_solver* s, double* m_out) { S_OR_ARG; return s->comp_m(m_out); }
-int pcr_objective(pcr_solver* s, double* obj) { S_OR_ARG; return s->objective(obj); }
-int pcr_obtain_g(pcr_solver* s, double* g) { S_OR_ARG; return s->obtain_g(g); }
-int pcr_compute_Ha(pcr_solver* s, const double* a, double* Ha) { S_OR_ARG; return s->compute_Ha(a, Ha); }
-int pcr_solve_delta(pcr_solver* s, const double* g, double* delta, int* it) { S_OR_ARG; return s->solve_delta(g, delta, it); }
-int pcr_update_V(pcr_solver* s, double* now_obj, int* info) { S_OR_ARG; return leave_on_error(s, s->update_V(now_obj, info)); }
-int pcr_update_U(pcr_solver* s, double* now_obj, int64_t* info) { S_OR_ARG; return leave_on_error(s, s->update_U(now_obj, info)); }
-int pcr_evaluate(pcr_solver* s, int which, int ndcg_k, double* e, double* n) { S_OR_ARG; return s->evaluate(which, ndcg_k, e, n); }
-int pcr_train(pcr_solver* s, pcr_log_fn log, void* ctx, pcr_iter_stats* hist) { S_OR_ARG; return leave_on_error(s, s->train(log, ctx, hist)); }
+int pcr_solver_set_factors(pcr_solver* s, const double* U, const double* V) { S_OR_ARG; PCR_ABI("pcr_solver_set_factors", s->set_factors(U, V, false)); }
+int pcr_solver_get_factors(pcr_solver* s, double* U, double* V) { S_OR_ARG; PCR_ABI("pcr_solver_get_factors", s->get_factors(U, V, false)); }
+int pcr_solver_set_factors_local(pcr_solver* s, const double* U_local, const double* V) { S_OR_ARG; PCR_ABI("pcr_solver_set_factors_local", s->set_factors(U_local, V, true)); }
+int pcr_solver_get_factors_local(pcr_solver* s, double* U_local, double* V) { S_OR_ARG; PCR_ABI("pcr_solver_get_factors_local", s->get_factors(U_local, V, true)); }
+int pcr_comp_m(pcr_solver* s, double* m_out) { S_OR_ARG; PCR_ABI("pcr_comp_m", s->comp_m(m_out)); }
+int pcr_objective(pcr_solver* s, double* obj) { S_OR_ARG; PCR_ABI("pcr_objective", s->objective(obj)); }
+int pcr_obtain_g(pcr_solver* s, double* g) { S_OR_ARG; PCR_ABI("pcr_obtain_g", s->obtain_g(g)); }
+int pcr_compute_Ha(pcr_solver* s, const double* a, double* Ha) { S_OR_ARG; PCR_ABI("pcr_compute_Ha", s->compute_Ha(a, Ha)); }
+int pcr_solve_delta(pcr_solver* s, const double* g, double* delta, int* it) { S_OR_ARG; PCR_ABI("pcr_solve_delta", s->solve_delta(g, delta, it)); }
+int pcr_update_V(pcr_solver* s, double* now_obj, int* info) { S_OR_ARG; PCR_ABI("pcr_update_V", leave_on_error(s, s->update_V(now_obj, info))); }
+int pcr_update_U(pcr_solver* s, double* now_obj, int64_t* info) { S_OR_ARG; PCR_ABI("pcr_update_U", leave_on_error(s, s->update_U(now_obj, info))); }
+int pcr_evaluate(pcr_solver* s, int which, int ndcg_k, double* e, double* n) { S_OR_ARG; PCR_ABI("pcr_evaluate", s->evaluate(which, ndcg_k, e, n)); }
+int pcr_train(pcr_solver* s, pcr_log_fn log, void* ctx, pcr_iter_stats* hist) { S_OR_ARG; PCR_ABI("pcr_train", leave_on_error(s, s->train(log, ctx, hist))); }
 int pcr_solver_sync(pcr_solver* s) { S_OR_ARG; return s->sync(); }
-int pcr_iterate(pcr_solver* s, int n, pcr_iter_stats* out) { S_OR_ARG; return leave_on_error(s, s->iterate_abi(n, out)); }
+int pcr_iterate(pcr_solver* s, int n, pcr_iter_stats* out) { S_OR_ARG; PCR_ABI("pcr_iterate", leave_on_error(s, s->iterate_abi(n, out))); }
 
 int pcr_profile_enable(pcr_solver* s, int on) { S_OR_ARG; s->prof_on = on != 0; s->prof_period = on > 1 ? on : 1; if (on) s->prof_prewarm(4096); return PCR_OK; }
 int pcr_profile_reset(pcr_solver* s) {
@@ -1992,6 +2000,7 @@ int pcr_predict(const double* U, int64_t d1, const double* V, int64_t d2, int64_
     if (!U || !V || k < 1 || n < 0 || (n > 0 && (!user || !item || !pred))) { pcr_set_error("pcr_predict: bad argument"); return PCR_ERR_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { pcr_set_error("no HIP device available"); return PCR_ERR_DEVICE; }
+    return abi_guard("pcr_predict", [&]() -> int {
     HIPCHK(hipSetDevice(device));
     for (int64_t z = 0; z < n; ++z)
         if (user[z] < 0 || user[z] >= d1 || item[z] < 0 || item[z] >= d2) { pcr_set_error("pair " + std::to_string(z) + " outside the model"); return PCR_ERR_ARG; }
@@ -2014,6 +2023,7 @@ int pcr_predict(const double* U, int64_t d1, const double* V, int64_t d2, int64_
         HIPCHK(hipMemcpy(pred, dP.p, n * sizeof(double), hipMemcpyDeviceToHost));
     }
     return PCR_OK;
+    });
 }
 
 }  // extern "C"

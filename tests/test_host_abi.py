@@ -65,6 +65,83 @@ def test_loader_errors(tmp_path):
         pcr.Dataset.from_triplets(2, 2, [0, 5], [0, 1], [1.0, 2.0])   # id outside the dimensions
 
 
+def test_loader_survives_malformed_input(tmp_path):
+    """Seeded garbage through the text loader, the cache reader and the model reader (the reference segfaults or reads
+    uninitialised memory on most of these, util.cpp:6-25, :56-79): every case must come back as an error code or as a data
+    set that passes its own consistency checks -- never a crash.  Under tests/test_sanitizers.py the same cases run against
+    the AddressSanitizer / UBSan build, where an out-of-bounds read would abort the run."""
+    rng = np.random.default_rng(11)
+    good_lines = [f"{u + 1} {i + 1} {1 + (u * 7 + i) % 5}" for u in range(6) for i in range(0, 9, 2)]
+    def attempt(meta, train, test=None, threads=1):
+        d = tmp_path / f"case{attempt.n}"; attempt.n += 1
+        d.mkdir()
+        (d / "meta").write_bytes(meta)
+        (d / "training.ratings").write_bytes(train)
+        if test is not None:
+            (d / "test.ratings").write_bytes(test)
+        try:
+            ds = pcr.Dataset.load(str(d), threads=threads)
+        except pcr.PcrError:
+            return None
+        d1, d2, nnz, tnnz = ds.dims()
+        idx, item, val = ds.csr(0)
+        assert idx[0] == 0 and idx[-1] == nnz == len(item) == len(val) and (np.diff(idx) >= 0).all()
+        assert nnz == 0 or (item.min() >= 0 and item.max() < d2)
+        return ds
+    attempt.n = 0
+    body = ("\n".join(good_lines) + "\n").encode()
+    n = len(good_lines)
+    assert attempt(f"6 9\n{n} training.ratings\n".encode(), body) is not None                       # the well-formed case loads
+    cases = [
+        (b"", body), (b"6\n", body), (b"6 9\n", body), (b"six nine\n30 training.ratings\n", body),
+        (b"-6 9\n30 training.ratings\n", body), (b"6 9\n-30 training.ratings\n", body),
+        (b"6 9\n999999999999 training.ratings\n", body),                                               # claims far more lines than the file has
+        (f"6 9\n{n} training.ratings\n".encode(), b""), (f"6 9\n{n} training.ratings\n".encode(), body[: len(body) // 2]),
+        (f"6 9\n{n} training.ratings\n".encode(), body.replace(b"1 1 ", b"0 1 ", 1)),                  # user id 0 (ids are 1-based)
+        (f"6 9\n{n} training.ratings\n".encode(), body.replace(b"6 9 ", b"7 9 ", 1)),                  # user id beyond d1
+        (f"6 9\n{n} training.ratings\n".encode(), body.replace(b" 9 ", b" 10 ", 1)),                  # item id beyond d2
+        (f"6 9\n{n} training.ratings\n".encode(), body.replace(b"1 1 ", b"1 -1 ", 1)),
+        (f"6 9\n{n} training.ratings\n".encode(), body.replace(b"\n", b"\n\n\x00\n", 3)),
+        (f"6 9\n{n} training.ratings\n".encode(), body.replace(b"1 1 1", b"1 1 one")),
+        (f"6 9\n{n} training.ratings\n".encode(), b"9" * 100000 + b"\n" + body),                     # one absurd token
+        (f"6 9\n{n} training.ratings\n".encode(), body + body[:40]),                                   # a duplicate (user, item)
+        (f"6 9\n{n} training.ratings\n5 test.ratings\n".encode(), body, b"1 1 3\n"),                # test file shorter than announced
+        (f"6 9\n{n} training.ratings\n2 test.ratings\n".encode(), body, b"3 1 3\n1 1 3\n"),        # test file not sorted by user (util.cpp:259-261)
+        (f"2147483648 9\n{n} training.ratings\n".encode(), body), (f"6 4294967297\n{n} training.ratings\n".encode(), body),
+    ]
+    for threads in (1, 3):
+        for meta, train, *rest in cases:
+            attempt(meta, train, rest[0] if rest else None, threads)
+        for _ in range(40):                                                                              # random byte edits of the good files
+            t = bytearray(body)
+            for _ in range(int(rng.integers(1, 6))):
+                t[int(rng.integers(0, len(t)))] = int(rng.integers(0, 256))
+            attempt(f"6 9\n{n} training.ratings\n".encode(), bytes(t), None, threads)
+    # the two binary readers: truncated and bit-flipped files
+    ds = attempt(f"6 9\n{n} training.ratings\n".encode(), body)
+    cache = tmp_path / "c.bin"
+    ds.save_cache(str(cache))
+    raw = cache.read_bytes()
+    U, V = rng.normal(size=(6, 3)), rng.normal(size=(9, 3))
+    pcr.model_save(str(tmp_path / "m.model"), U, V)
+    mraw = (tmp_path / "m.model").read_bytes()
+    for blob, path, reader in ((raw, tmp_path / "c2.bin", pcr.Dataset.load_cache), (mraw, tmp_path / "m2.model", pcr.model_load)):
+        for cut in (0, 1, 7, 8, 15, 16, 24, len(blob) // 2, len(blob) - 1):
+            path.write_bytes(blob[:cut])
+            try:
+                reader(str(path))
+            except pcr.PcrError:
+                pass
+        for _ in range(60):
+            b = bytearray(blob)
+            b[int(rng.integers(0, min(len(b), 64)))] ^= 1 << int(rng.integers(0, 8))                    # the headers: sizes, counts, magic
+            path.write_bytes(bytes(b))
+            try:
+                reader(str(path))
+            except (pcr.PcrError, MemoryError):
+                pass
+
+
 def test_model_file_roundtrip_and_reference_bytes(tmp_path):
     g, meta = load_golden("edge5")
     U, V = g["cli_U_s2"], g["cli_V_s2"]
