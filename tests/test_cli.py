@@ -519,3 +519,33 @@ def test_gpus_option_a_signal_to_the_parent_ends_the_whole_job(tmp_path):
     ok = run([TRAIN, "-k", str(int(g["r"])), "-t", "2", "-p", "0", "--gpus", "2", "--devices", "0,0", "--comm", "p2p", d, "m.model"], tmp_path)
     assert ok.returncode == 0, ok.stderr
 
+
+@pytest.mark.gpu
+def test_gpus_option_with_more_ranks_than_users_that_have_ratings(tmp_path):
+    """One user holds nearly every rating: the nnz-balanced partition gives two of the four workers NO users.  They still take part
+    in every exchange (contributing zeros) and the job's model equals the one-process model to summation-order rounding."""
+    rng = np.random.default_rng(0)
+    d1, d2 = 6, 300
+    lens = np.array([250, 0, 3, 0, 0, 12])
+    user = np.repeat(np.arange(d1), lens)
+    item = np.concatenate([np.sort(rng.choice(d2, n, replace=False)) for n in lens])
+    val = rng.integers(1, 6, len(user)).astype(np.float64)
+    tu = np.array([0, 2, 5]); ti = np.array([1, 2, 3]); tv = np.array([3.0, 4.0, 2.0])
+    d = synth.write_dir(synth.Ratings(d1, d2, user, item, val, tu, ti, tv), str(tmp_path / "data"))
+    base = [TRAIN, "-k", "6", "-l", "2.5", "-t", "3", "--f64"]
+    one = run(base + [d, "one.model"], tmp_path)
+    four = run(base + ["--gpus", "4", "--devices", "0,0,0,0", "--comm", "p2p", d, "four.model"], tmp_path)
+    assert one.returncode == 0 and four.returncode == 0, four.stderr
+    shards = re.findall(r"^\[rank (\d)\] device 0: users \[(\d+), (\d+)\), (\d+) ratings$", four.stderr, re.M)
+    assert len(shards) == 4 and sum(1 for _, a, b, _ in shards if a == b) >= 1          # at least one worker without users
+    a = np.frombuffer(open(tmp_path / "one.model", "rb").read(), np.float64)
+    b = np.frombuffer(open(tmp_path / "four.model", "rb").read(), np.float64)
+    assert a.shape == b.shape and np.nanmax(np.abs(a[2:] - b[2:])) < 1e-9 * np.nanmax(np.abs(a[2:]))
+    la = [l for l in one.stdout.split("\n") if l.startswith(("Iter", "(T"))]; lb = [l for l in four.stdout.split("\n") if l.startswith(("Iter", "(T"))]
+    assert len(la) == len(lb) == 4 + 8
+    for x, y in zip(la, lb):
+        fx = [float(v) for v in re.findall(NUM, x)]; fy = [float(v) for v in re.findall(NUM, y)]
+        if x.startswith("Iter"):
+            fx, fy = fx[:1] + fx[2:], fy[:1] + fy[2:]
+        assert np.allclose(fx, fy, rtol=2e-5, atol=2e-6, equal_nan=True), (x, y)
+

@@ -184,6 +184,44 @@ def test_real_valued_levels_and_zero_model(oracle):
     assert s.objective() == float(oracle.count_pairs(X)) == float(ds.count_pairs())
 
 
+@pytest.mark.parametrize("nranks", [2, 4, 5])
+def test_ranks_with_empty_shards(nranks):
+    """More ranks than users with ratings (one user holds nearly everything): the nnz-balanced partition hands some ranks an
+    EMPTY user range -- zero users, zero ratings, every launch of theirs a grid of nothing.  They must create, run every entry
+    point and contribute exact zeros: the partial gradients still add up to the one-rank gradient, and with the two-process CLI
+    the job still trains (pcrpp.cpp:825-833 is the loop being sharded)."""
+    rng = np.random.default_rng(0)
+    d1, d2, r, lam = 5, 300, 8, 3.0
+    lens = np.array([250, 0, 3, 0, 0])
+    user = np.repeat(np.arange(d1), lens)
+    item = np.concatenate([rng.choice(d2, n, replace=False) for n in lens])
+    val = rng.integers(1, 6, len(user)).astype(np.float64)
+    ds = pcr.Dataset.from_triplets(d1, d2, user, item, val)
+    bounds = pcr.partition_users(np.concatenate([[0], np.cumsum(lens)]), nranks)
+    assert bounds[0] == 0 and bounds[-1] == d1 and (np.diff(bounds) >= 0).all()
+    if nranks > 2:
+        assert (np.diff(bounds) == 0).any()
+    par = dict(k=r, precision=pcr.PCR_F64, **{"lambda": lam})
+    U0, V0 = pcr.initial(d1, r), pcr.initial(d2, r)
+    one = pcr.Solver(ds, pcr.Parameter(**par))
+    one.set_factors(U0, V0); one.comp_m(want=False)
+    g1 = one.obtain_g(); one.update_U(); U1, _ = one.get_factors()
+    g_sum, U_sh = 0.0, U0.copy()
+    for q in range(nranks):
+        s = pcr.Solver(ds, pcr.Parameter(**par), rank=q, nranks=nranks)
+        assert (s.first_user, s.n_users) == (bounds[q], bounds[q + 1] - bounds[q])
+        s.set_local_only(True)
+        s.set_factors(U0, V0)
+        m = s.comp_m()
+        assert len(m) == s.nnz_local
+        g_sum = g_sum + s.obtain_g()
+        s.update_U()
+        Uq, _ = s.get_factors()
+        U_sh[s.first_user:s.first_user + s.n_users] = Uq[s.first_user:s.first_user + s.n_users]
+        s.close()
+    assert rel(g_sum, g1) < 1e-12 and rel(U_sh, U1) < 1e-12
+
+
 @pytest.mark.parametrize("nranks", [2, 3])
 def test_user_sharding_on_one_gpu(oracle, nranks):
     """The N-rank user sharding verified in ONE process on one GPU (shard-local mode, host-side sums
