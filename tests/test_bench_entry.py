@@ -78,6 +78,12 @@ def test_two_ranks_on_one_gpu_equal_one_rank():
     assert line["steps"] == steps and line["warmup"] == warmup
     assert line["shards"] == [[0, users, nnz], [users, users, nnz]]
     assert line["roofline"] and line["roofline"]["binding"]["level"] == "l2-gather"
+    # what the exchange steps cost, for the day a scaling curve has to be decomposed: 1 gradient + 10 Hessian-vector all-reduces of
+    # the d2 x ld vector per step, plus the objective's scalar blocks
+    ex = line["exchange"]
+    assert ex["vector_bytes"] == 3952 * 100 * 4 and ex["vector_allreduces_per_step"] == 1 + line["inner_per_step"]["cg_v"] and ex["allreduces_per_step"] >= ex["vector_allreduces_per_step"] + 2
+    assert 0 < ex["allreduce_us_avg"] < 5000 and 0 < ex["share_of_step"] < 1 and ex["us_per_step"] == pytest.approx(ex["allreduce_us_avg"] * ex["allreduces_per_step"], rel=0.02)
+    assert len(json.dumps(line, separators=(",", ":"))) < 4096 and line["cpu_baseline"] is None and line["full_record"]
     # the same 2 x 2000 users in ONE solver
     blocks = [synth.generate("ml1m", seed=synth.SEED + q, d1=users, nnz=nnz, item_seed=synth.SEED if q else None) for q in range(2)]
     cat = lambda f: np.concatenate([getattr(blocks[0], f), getattr(blocks[1], f)])
