@@ -6,6 +6,7 @@
 #include "pcr_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <climits>
 #include <cstdint>
@@ -18,7 +19,10 @@
 #include <numeric>
 #include <random>
 #include <thread>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 static thread_local std::string g_err;
 void pcr_set_error(const std::string& msg) { g_err = msg; }
@@ -82,53 +86,197 @@ extern "C" int pcr_initial_rows(double* X, int64_t n, int64_t k, int64_t row0, i
 // CSR conversion
 // ------------------------------------------------------------------------------------------
 
-// util.h:223-247 sorts entries by (row, col); util.cpp:229-243 walks them user by user:
-// items ascending inside a user.  Counting sort by user, then a per-user sort by item.
+// fn(t, lo, hi) over T contiguous pieces of [0, n), one std::thread each (T = 1: on the calling thread)
+template <class F>
+static void run_pieces(int64_t n, int T, F&& fn) {
+    T = (int)std::max<int64_t>(1, std::min<int64_t>(T, n));
+    if (T == 1) { fn(0, (int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back([&, t]() { fn(t, n * t / T, n * (t + 1) / T); });
+    for (auto& x : th) x.join();
+}
+static int pieces_for(int64_t n, int threads) { return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(threads, 64), n / 65536 + 1)); }
+
+// index[u] = number of entries whose key is below u, for a NON-DECREASING key sequence key[0, n) with values in [0, d1):
+// every piece writes the index entries of the keys that first appear in it (each entry is written exactly once).
+static void index_of_sorted_keys(const int32_t* key, int64_t n, int64_t d1, int64_t* index, int T) {
+    if (n == 0) { std::fill(index, index + d1 + 1, (int64_t)0); return; }
+    run_pieces(n, T, [&](int, int64_t lo, int64_t hi) {
+        int64_t prev = lo == 0 ? -1 : key[lo - 1];
+        for (int64_t z = lo; z < hi; ++z) {
+            const int64_t k = key[z];
+            if (k != prev) { for (int64_t u = prev + 1; u <= k; ++u) index[u] = z; prev = k; }
+        }
+        if (hi == n) for (int64_t u = prev + 1; u <= d1; ++u) index[u] = n;
+    });
+}
+
+// util.h:223-247 sorts entries by (row, col); util.cpp:229-243 walks them user by user: items ascending inside a user.
+// `threads` host threads throughout:
+//   * the usual case -- the file is already ordered by (user, item), as the reference's own data sets and the generators'
+//     are -- is detected piece by piece during the range check and needs no data movement at all: the parsed item / value
+//     arrays ARE the CSR (they are adopted when the caller hands them over in X, copied in parallel otherwise) and the row
+//     pointers come from the first occurrence of every user;
+//   * anything else: entries are scattered into user-range buckets (per piece and bucket counts -> offsets, file order kept
+//     inside a bucket), then every bucket -- on its own thread -- does its counting sort by user and, where a user's items are
+//     not ascending, a stable sort by item (equal (user, item) pairs keep their file order).
+// adopt = item / val point at X.item / X.val (sized nnz) already.
 static int build_train_csr(int64_t d1, int64_t d2, int64_t nnz, const int32_t* user, const int32_t* item,
-                           const double* val, PcrCsr& X) {
+                           const double* val, PcrCsr& X, int threads, bool adopt) {
     X.d1 = d1; X.d2 = d2;
-    X.index.assign(d1 + 1, 0);
-    for (int64_t z = 0; z < nnz; ++z) {
-        if (user[z] < 0 || user[z] >= d1 || item[z] < 0 || item[z] >= d2) {
-            pcr_set_error("rating " + std::to_string(z) + " has user/item id outside the meta dimensions");
+    X.index.resize((size_t)d1 + 1);
+    const int T = pieces_for(nnz, threads);
+    struct Piece { int64_t bad = -1; bool sorted = true; };
+    std::vector<Piece> pc((size_t)T);
+    run_pieces(nnz, T, [&](int t, int64_t lo, int64_t hi) {
+        Piece& P = pc[(size_t)t];
+        int64_t pu = lo > 0 ? user[lo - 1] : -1, pi = lo > 0 ? item[lo - 1] : -1;      // (the pair before the piece: the seam counts too)
+        for (int64_t z = lo; z < hi; ++z) {
+            const int64_t u = user[z], i = item[z];
+            if (u < 0 || u >= d1 || i < 0 || i >= d2) { P.bad = z; return; }
+            if (u < pu || (u == pu && i < pi)) P.sorted = false;
+            pu = u; pi = i;
+        }
+    });
+    bool sorted = true;
+    for (const Piece& P : pc) {
+        if (P.bad >= 0) {
+            int64_t first_bad = P.bad;
+            for (const Piece& Q : pc) if (Q.bad >= 0) first_bad = std::min(first_bad, Q.bad);
+            pcr_set_error("rating " + std::to_string(first_bad) + " has user/item id outside the meta dimensions");
             return PCR_ERR_ARG;
         }
-        X.index[user[z] + 1]++;
+        sorted = sorted && P.sorted;
     }
-    for (int64_t u = 0; u < d1; ++u) X.index[u + 1] += X.index[u];
-    X.item.resize(nnz); X.val.resize(nnz);
-    std::vector<int64_t> cur(X.index.begin(), X.index.end() - 1);
-    std::vector<int64_t> src(nnz);
-    for (int64_t z = 0; z < nnz; ++z) src[cur[user[z]]++] = z;
-    for (int64_t u = 0; u < d1; ++u) {
-        int64_t a = X.index[u], b = X.index[u + 1];
-        bool sorted = true;
-        for (int64_t q = a + 1; q < b && sorted; ++q) sorted = item[src[q - 1]] <= item[src[q]];
-        if (!sorted)
-            std::stable_sort(src.begin() + a, src.begin() + b, [&](int64_t x, int64_t y) { return item[x] < item[y]; });
-        for (int64_t q = a; q < b; ++q) { X.item[q] = item[src[q]]; X.val[q] = val[src[q]]; }
+    if (sorted) {
+        index_of_sorted_keys(user, nnz, d1, X.index.data(), T);
+        if (!adopt) {
+            X.item.resize((size_t)nnz); X.val.resize((size_t)nnz);
+            run_pieces(nnz, T, [&](int, int64_t lo, int64_t hi) {
+                std::copy(item + lo, item + hi, X.item.data() + lo);
+                std::copy(val + lo, val + hi, X.val.data() + lo);
+            });
+        }
+        return PCR_OK;
     }
+    // ---- general path
+    const int64_t NB = std::max<int64_t>(1, std::min<int64_t>(d1, (int64_t)T * 8));   // user-range buckets (more than threads: balance)
+    const int64_t bw = (d1 + NB - 1) / NB;
+    std::vector<int64_t> cnt((size_t)T * NB, 0);
+    run_pieces(nnz, T, [&](int t, int64_t lo, int64_t hi) {
+        int64_t* c = cnt.data() + (size_t)t * NB;
+        for (int64_t z = lo; z < hi; ++z) c[user[z] / bw]++;
+    });
+    std::vector<int64_t> bstart((size_t)NB + 1, 0);
+    for (int64_t b = 0; b < NB; ++b) {
+        int64_t acc = bstart[b];
+        for (int t = 0; t < T; ++t) { const int64_t c = cnt[(size_t)t * NB + b]; cnt[(size_t)t * NB + b] = acc; acc += c; }
+        bstart[b + 1] = acc;
+    }
+    pcr_vec<int32_t> bu((size_t)nnz), bi((size_t)nnz);
+    pcr_vec<double> bv((size_t)nnz);
+    run_pieces(nnz, T, [&](int t, int64_t lo, int64_t hi) {
+        int64_t* c = cnt.data() + (size_t)t * NB;
+        for (int64_t z = lo; z < hi; ++z) {
+            const int64_t q = c[user[z] / bw]++;
+            bu[q] = user[z]; bi[q] = item[z]; bv[q] = val[z];
+        }
+    });
+    pcr_vec<int32_t> oi((size_t)nnz);
+    pcr_vec<double> ov((size_t)nnz);
+    std::atomic<int64_t> next{0};
+    auto bucket_work = [&]() {
+        std::vector<int64_t> cur;
+        std::vector<std::pair<int32_t, double>> tmp;
+        for (;;) {
+            const int64_t b = next.fetch_add(1);
+            if (b >= NB) break;
+            const int64_t ulo = b * bw, uhi = std::min(d1, ulo + bw), a = bstart[b], e = bstart[b + 1];
+            if (ulo >= uhi) continue;
+            cur.assign((size_t)(uhi - ulo) + 1, 0);
+            for (int64_t z = a; z < e; ++z) cur[(size_t)(bu[z] - ulo) + 1]++;
+            int64_t acc = a;                                             // entries of users below ulo = the bucket's start
+            for (int64_t u = ulo; u < uhi; ++u) { const int64_t c = cur[(size_t)(u - ulo) + 1]; X.index[u] = acc; cur[(size_t)(u - ulo)] = acc; acc += c; }
+            for (int64_t z = a; z < e; ++z) { const int64_t q = cur[(size_t)(bu[z] - ulo)]++; oi[q] = bi[z]; ov[q] = bv[z]; }
+            for (int64_t u = ulo; u < uhi; ++u) {
+                const int64_t ua = X.index[u], ub = u + 1 < uhi ? X.index[u + 1] : e;
+                bool asc = true;
+                for (int64_t q = ua + 1; q < ub && asc; ++q) asc = oi[q - 1] <= oi[q];
+                if (asc) continue;
+                tmp.resize((size_t)(ub - ua));
+                for (int64_t q = ua; q < ub; ++q) tmp[(size_t)(q - ua)] = {oi[q], ov[q]};
+                std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<int32_t, double>& x, const std::pair<int32_t, double>& y) { return x.first < y.first; });
+                for (int64_t q = ua; q < ub; ++q) { oi[q] = tmp[(size_t)(q - ua)].first; ov[q] = tmp[(size_t)(q - ua)].second; }
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(bucket_work);
+        bucket_work();
+        for (auto& x : th) x.join();
+    }
+    for (int64_t u = NB * bw; u < d1; ++u) X.index[u] = nnz;              // (none: NB * bw >= d1)
+    X.index[d1] = nnz;
+    X.item.swap(oi); X.val.swap(ov);
     return PCR_OK;
 }
 
-// util.cpp:250-274: the test file is assumed user-sorted; the scan stops assigning at the first
-// entry whose user id exceeds the cursor, so out-of-order tails are dropped -- mirrored.
+// util.cpp:250-274: the test file is assumed user-sorted; the reference's cursor walks the users 0, 1, ... and appends entries
+// while their user id is not above the cursor -- so an entry lands in the row of the LARGEST user id seen so far (itself
+// included), and the scan ends for good at the first id that is not a user (>= d1): that entry and everything behind it are
+// dropped.  Mirrored, in parallel: per-piece maxima -> carried-in running maximum -> row of every entry -> row pointers as for
+// sorted keys.  adopt = item / val point at X.item / X.val (sized nnz); they are cut at the end of the scan.
 static void build_test_csr(int64_t d1, int64_t d2, int64_t nnz, const int32_t* user, const int32_t* item,
-                           const double* val, PcrCsr& X) {
+                           const double* val, PcrCsr& X, int threads, bool adopt) {
     X.d1 = d1; X.d2 = d2;
-    X.index.assign(d1 + 1, 0);
-    X.item.clear(); X.val.clear();
-    X.item.reserve(nnz); X.val.reserve(nnz);
-    int64_t cc = 0;
-    for (int64_t j = 0; j < d1; ++j) {
-        X.index[j] = cc;
-        for (; cc < nnz; ++cc) {
-            if (user[cc] > j) break;
-            X.item.push_back(item[cc]);
-            X.val.push_back(val[cc]);
+    X.index.resize((size_t)d1 + 1);
+    const int T = pieces_for(nnz, threads);
+    std::vector<int64_t> pmax((size_t)T + 1, -1);
+    run_pieces(nnz, T, [&](int t, int64_t lo, int64_t hi) {
+        int64_t m = -1;
+        for (int64_t z = lo; z < hi; ++z) m = std::max<int64_t>(m, user[z]);
+        pmax[(size_t)t + 1] = m;
+    });
+    pmax[0] = 0;                                                          // the cursor starts at user 0
+    for (int t = 0; t < T; ++t) pmax[(size_t)t + 1] = std::max(pmax[(size_t)t], pmax[(size_t)t + 1]);
+    pcr_vec<int32_t> row((size_t)nnz);
+    std::vector<int64_t> stop((size_t)T, nnz);
+    run_pieces(nnz, T, [&](int t, int64_t lo, int64_t hi) {
+        int64_t m = pmax[(size_t)t];
+        for (int64_t z = lo; z < hi; ++z) {
+            m = std::max<int64_t>(m, user[z]);
+            if (m >= d1) { stop[(size_t)t] = z; for (; z < hi; ++z) row[z] = 0; return; }
+            row[z] = (int32_t)m;
         }
+    });
+    int64_t keep = nnz;
+    for (int t = 0; t < T; ++t) keep = std::min(keep, stop[(size_t)t]);
+    index_of_sorted_keys(row.data(), keep, d1, X.index.data(), T);
+    if (!adopt) {
+        X.item.resize((size_t)keep); X.val.resize((size_t)keep);
+        run_pieces(keep, T, [&](int, int64_t lo, int64_t hi) {
+            std::copy(item + lo, item + hi, X.item.data() + lo);
+            std::copy(val + lo, val + hi, X.val.data() + lo);
+        });
+    } else {
+        X.item.resize((size_t)keep); X.val.resize((size_t)keep);
     }
-    X.index[d1] = cc;
+}
+
+static int check_test_ids(int64_t d2, int64_t tnnz, const int32_t* tuser, const int32_t* titem, int threads) {
+    const int T = pieces_for(tnnz, threads);
+    std::vector<int64_t> bad((size_t)T, -1);
+    run_pieces(tnnz, T, [&](int t, int64_t lo, int64_t hi) {
+        for (int64_t z = lo; z < hi; ++z)
+            if (titem[z] < 0 || titem[z] >= d2 || tuser[z] < 0) { bad[(size_t)t] = z; return; }
+    });
+    for (int64_t b : bad)
+        if (b >= 0) {
+            pcr_set_error("test rating " + std::to_string(b) + " has user/item id outside the meta dimensions");
+            return PCR_ERR_ARG;
+        }
+    return PCR_OK;
 }
 
 extern "C" int pcr_dataset_from_triplets(int64_t d1, int64_t d2, int64_t nnz, const int32_t* user,
@@ -143,14 +291,12 @@ extern "C" int pcr_dataset_from_triplets(int64_t d1, int64_t d2, int64_t nnz, co
     if (d1 > kMaxDim || d2 > kMaxDim) { pcr_set_error("pcr_dataset_from_triplets: more than 2^31 - 2 users or items"); return PCR_ERR_UNSUPPORTED; }
     return guarded("pcr_dataset_from_triplets", [&]() -> int {
         std::unique_ptr<pcr_dataset> ds(new pcr_dataset());
-        int rc = build_train_csr(d1, d2, nnz, user, item, val, ds->train);
+        const int threads = pcr_host_threads();
+        int rc = build_train_csr(d1, d2, nnz, user, item, val, ds->train, threads, false);
         if (rc != PCR_OK) return rc;
-        for (int64_t z = 0; z < tnnz; ++z)
-            if (titem[z] < 0 || titem[z] >= d2 || tuser[z] < 0) {
-                pcr_set_error("test rating " + std::to_string(z) + " has user/item id outside the meta dimensions");
-                return PCR_ERR_ARG;
-            }
-        build_test_csr(d1, d2, tnnz, tuser, titem, tval, ds->test);
+        rc = check_test_ids(d2, tnnz, tuser, titem, threads);
+        if (rc != PCR_OK) return rc;
+        build_test_csr(d1, d2, tnnz, tuser, titem, tval, ds->test, threads, false);
         ds->tnnz_file = tnnz;
         *out = ds.release();
         return PCR_OK;
@@ -229,19 +375,49 @@ int pcr_tune_int(const char* key, int dflt) {
 // text loader (util.cpp:6-25, util.h:118-131, util.h:360-371)
 // ------------------------------------------------------------------------------------------
 
-static int read_file(const std::string& path, std::vector<char>& buf) {
-    FILE* fp = fopen(path.c_str(), "rb");
-    if (!fp) { pcr_set_error("can't open " + path + ": " + strerror(errno)); return PCR_ERR_IO; }
-    fseek(fp, 0, SEEK_END);
-    long sz = ftell(fp);
-    fseek(fp, 0, SEEK_SET);
-    buf.resize((size_t)sz + 1);
-    size_t got = fread(buf.data(), 1, (size_t)sz, fp);
-    fclose(fp);
-    buf[got] = 0;
-    buf.resize(got + 1);
-    return PCR_OK;
-}
+// A rating file as one read-only byte range: mmap for regular files (no copy, no zero-filled staging buffer; the parser
+// threads fault their own pieces in), a heap buffer for anything that cannot be mapped (pipes, /proc, empty files).
+struct TextFile {
+    const char* p = nullptr;
+    size_t len = 0;
+    void* map = nullptr;
+    size_t map_len = 0;
+    pcr_vec<char> heap;
+    ~TextFile() { if (map) munmap(map, map_len); }
+    int open(const std::string& path) {
+        const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+        if (fd < 0) { pcr_set_error("can't open " + path + ": " + strerror(errno)); return PCR_ERR_IO; }
+        struct stat sb;
+        if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+            void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                (void)madvise(m, (size_t)sb.st_size, MADV_WILLNEED);
+                map = m; map_len = (size_t)sb.st_size; p = static_cast<const char*>(m); len = map_len;
+                ::close(fd);
+                return PCR_OK;
+            }
+        }
+        size_t cap = (size_t)1 << 20, got = 0;
+        heap.resize(cap);
+        for (;;) {
+            const ssize_t n = ::read(fd, heap.data() + got, cap - got);
+            if (n < 0) { if (errno == EINTR) continue; ::close(fd); pcr_set_error("can't read " + path + ": " + strerror(errno)); return PCR_ERR_IO; }
+            if (n == 0) break;
+            got += (size_t)n;
+            if (got == cap) { cap *= 2; heap.resize(cap); }
+        }
+        ::close(fd);
+        p = heap.data(); len = got;
+        return PCR_OK;
+    }
+};
+
+// strtol / strtod need a terminated string and the mapped file has none: the (rare) libc path parses a bounded copy.
+struct SlowCopy {
+    char buf[512];
+    size_t n;
+    SlowCopy(const char* p, const char* end) { n = std::min<size_t>(sizeof(buf) - 1, (size_t)(end - p)); memcpy(buf, p, n); buf[n] = 0; }
+};
 
 // One rating "user item value" (util.h:126, util.h:367).  Fast path for the common "digits digits
 // [-]digits[.digits]" shape, strtol/strtod for anything else (exponents, inf, ...).
@@ -283,82 +459,98 @@ static inline bool parse_one(const char*& p, const char* end, int32_t& u, int32_
             return true;
         }
         p = s;
+        SlowCopy c(p, end);
         char* e;
-        double dv = strtod(p, &e);
-        if (e == p) { p = save; return false; }
-        p = e;
+        double dv = strtod(c.buf, &e);
+        if (e == c.buf || (size_t)(e - c.buf) == sizeof(c.buf) - 1) { p = save; return false; }     // (a token that fills the copy is no rating)
+        p += e - c.buf;
         u = (int32_t)(a - 1); it = (int32_t)(b - 1); v = dv;
         return true;
     }
     p = save;                                           // signs / odd formats in the ids: the libc path
+    SlowCopy c(p, end);
     char* e;
-    long i = strtol(p, &e, 10);
-    if (e == p) return false;
-    p = e;
-    long j = strtol(p, &e, 10);
-    if (e == p) return false;
-    p = e;
-    double dv = strtod(p, &e);
-    if (e == p) return false;
-    p = e;
+    const char* q = c.buf;
+    long i = strtol(q, &e, 10);
+    if (e == q) return false;
+    q = e;
+    long j = strtol(q, &e, 10);
+    if (e == q) return false;
+    q = e;
+    double dv = strtod(q, &e);
+    if (e == q || (size_t)(e - c.buf) == sizeof(c.buf) - 1) return false;
+    p += e - c.buf;
     if (i < INT32_MIN + 1 || j < INT32_MIN + 1 || i > (long)INT32_MAX || j > (long)INT32_MAX) return false;
     u = (int32_t)(i - 1); it = (int32_t)(j - 1); v = dv;
     return true;
 }
 
 // "%d %d %lf" per entry, 1-based ids (util.h:126,131; util.h:367-368); exactly nnz entries are read.
-// Parsed by `threads` host threads: the buffer is cut at line boundaries, lines are counted per
-// piece, then every piece parses into its slice of the output.
-static int parse_ratings(const std::string& path, int64_t nnz, std::vector<int32_t>& user,
-                         std::vector<int32_t>& item, std::vector<double>& val, int threads) {
+// Parsed by `threads` host threads: the file is cut at line boundaries, the non-blank lines of every piece are counted
+// (one vectorisable pass; a piece that contains a line ending in white space is recounted exactly), then every piece parses
+// into its slice of the (uninitialised) output arrays.
+static int64_t nonblank_lines(const char* base, size_t a, size_t b) {
+    // fast count: newlines, + 1 for an unterminated last line; exact unless some newline follows white space or another
+    // newline (blank lines, "\r\n", trailing blanks) -- `odd` counts those, and any of them sends the piece to the exact loop
+    int64_t nl = 0, odd = 0;
+    if (b > a) { nl = base[a] == '\n'; odd = nl; }                        // (a newline at the start of a piece: a blank line)
+    for (size_t q0 = a + 1; q0 < b; q0 += 1 << 15) {                      // (blocks with 32-bit counters and no loop-carried state: vectorises)
+        const size_t q1 = std::min(b, q0 + ((size_t)1 << 15));
+        const unsigned char* s = reinterpret_cast<const unsigned char*>(base);
+        unsigned bn = 0, bo = 0;
+        for (size_t q = q0; q < q1; ++q) {
+            const unsigned isnl = s[q] == '\n', pws = (s[q - 1] == '\n') | (s[q - 1] == ' ') | (s[q - 1] == '\t') | (s[q - 1] == '\r');
+            bn += isnl;
+            bo += isnl & pws;
+        }
+        nl += bn; odd += bo;
+    }
+    if (odd == 0) return nl + (b > a && base[b - 1] != '\n' ? 1 : 0);
+    int64_t n = 0; bool content = false;
+    for (size_t q = a; q < b; ++q) {
+        if (base[q] == '\n') { n += content; content = false; }
+        else if (base[q] != ' ' && base[q] != '\t' && base[q] != '\r') content = true;
+    }
+    return n + (content ? 1 : 0);
+}
+
+static int parse_ratings(const std::string& path, int64_t nnz, pcr_vec<int32_t>& user,
+                         pcr_vec<int32_t>& item, pcr_vec<double>& val, int threads) {
     if (nnz < 0) { pcr_set_error(path + ": a negative rating count in meta"); return PCR_ERR_IO; }
-    std::vector<char> buf;
-    int rc = read_file(path, buf);
+    TextFile tf;
+    int rc = tf.open(path);
     if (rc != PCR_OK) return rc;
-    const char* base = buf.data();
-    const size_t len = buf.size() - 1;
+    const char* base = tf.p;
+    const size_t len = tf.len;
     int T = std::max(1, std::min(threads, 64));
     if (len < (size_t)1 << 20) T = 1;
     std::vector<size_t> cut(T + 1, len);
     cut[0] = 0;
     for (int t = 1; t < T; ++t) {
-        size_t c = len * t / T;
+        size_t c = std::max(cut[t - 1], len * t / T);
         while (c < len && base[c] != '\n') ++c;
         cut[t] = c < len ? c + 1 : len;
     }
-    auto nonblank_lines = [&](size_t a, size_t b) {
-        int64_t n = 0; bool content = false;
-        for (size_t q = a; q < b; ++q) {
-            if (base[q] == '\n') { n += content; content = false; }
-            else if (base[q] != ' ' && base[q] != '\t' && base[q] != '\r') content = true;
-        }
-        return n + (content ? 1 : 0);
-    };
     std::vector<int64_t> first(T + 1, 0);
     {
         std::vector<int64_t> cnt(T, 0);
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t) th.emplace_back([&, t]() { cnt[t] = nonblank_lines(cut[t], cut[t + 1]); });
-        for (auto& x : th) x.join();
+        run_pieces(T, T, [&](int, int64_t lo, int64_t hi) { for (int64_t t = lo; t < hi; ++t) cnt[t] = nonblank_lines(base, cut[t], cut[t + 1]); });
         for (int t = 0; t < T; ++t) first[t + 1] = first[t] + cnt[t];
     }
     if (first[T] < nnz) {
         pcr_set_error(path + ": expected " + std::to_string(nnz) + " ratings, found " + std::to_string(first[T]));
         return PCR_ERR_IO;
     }
-    user.resize(nnz); item.resize(nnz); val.resize(nnz);          // (only now: meta may promise any number)
+    user.resize((size_t)nnz); item.resize((size_t)nnz); val.resize((size_t)nnz);          // (only now: meta may promise any number)
     std::vector<int64_t> bad(T, -1);
-    {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t)
-            th.emplace_back([&, t]() {
-                const char* p = base + cut[t];
-                const char* end = base + cut[t + 1];
-                for (int64_t z = first[t]; z < first[t + 1] && z < nnz; ++z)
-                    if (!parse_one(p, end, user[z], item[z], val[z])) { bad[t] = z; return; }
-            });
-        for (auto& x : th) x.join();
-    }
+    run_pieces(T, T, [&](int, int64_t lo, int64_t hi) {
+        for (int64_t t = lo; t < hi; ++t) {
+            const char* p = base + cut[t];
+            const char* end = base + cut[t + 1];
+            for (int64_t z = first[t]; z < first[t + 1] && z < nnz; ++z)
+                if (!parse_one(p, end, user[z], item[z], val[z])) { bad[t] = z; break; }
+        }
+    });
     for (int t = 0; t < T; ++t)
         if (bad[t] >= 0) { pcr_set_error(path + ": malformed rating line " + std::to_string(bad[t] + 1)); return PCR_ERR_IO; }
     return PCR_OK;
@@ -385,17 +577,27 @@ extern "C" int pcr_dataset_load_mt(const char* dir, int threads, pcr_dataset** o
     fclose(fp);
     if (m < 0 || n < 0 || m > kMaxDim || n > kMaxDim) { pcr_set_error(metap + ": user / item counts must lie in [0, 2^31 - 2]"); return PCR_ERR_IO; }
     return guarded("pcr_dataset_load", [&]() -> int {
-        std::vector<int32_t> u, i, tu, ti;
-        std::vector<double> v, tv;
-        int rc = parse_ratings(d + "/" + name, nnz, u, i, v, threads);
+        // item / value arrays are parsed straight into the data set's CSR storage: for a file ordered by (user, item) they are
+        // the CSR as they stand (build_train_csr adopts them)
+        std::unique_ptr<pcr_dataset> ds(new pcr_dataset());
+        pcr_vec<int32_t> u, tu;
+        int rc = parse_ratings(d + "/" + name, nnz, u, ds->train.item, ds->train.val, threads);
         if (rc != PCR_OK) return rc;
+        rc = build_train_csr(m, n, nnz, u.data(), ds->train.item.data(), ds->train.val.data(), ds->train, threads, true);
+        if (rc != PCR_OK) return rc;
+        pcr_vec<int32_t>().swap(u);
         if (have_test) {
-            rc = parse_ratings(d + "/" + tname, tnnz, tu, ti, tv, threads);
+            rc = parse_ratings(d + "/" + tname, tnnz, tu, ds->test.item, ds->test.val, threads);
+            if (rc != PCR_OK) return rc;
+            rc = check_test_ids(n, tnnz, tu.data(), ds->test.item.data(), threads);
             if (rc != PCR_OK) return rc;
         } else {
             tnnz = 0;
         }
-        return pcr_dataset_from_triplets(m, n, nnz, u.data(), i.data(), v.data(), tnnz, tu.data(), ti.data(), tv.data(), out);
+        build_test_csr(m, n, tnnz, tu.data(), ds->test.item.data(), ds->test.val.data(), ds->test, threads, true);
+        ds->tnnz_file = tnnz;
+        *out = ds.release();
+        return PCR_OK;
     });
 }
 
@@ -429,8 +631,8 @@ bool dir_stamps(const std::string& d, int64_t stamp[6]) {
     if (have_test && !file_stamp(d + "/" + tname, &stamp[4], &stamp[5])) return false;
     return true;
 }
-template <class X> bool put(FILE* f, const std::vector<X>& v) { return v.empty() || fwrite(v.data(), sizeof(X), v.size(), f) == v.size(); }
-template <class X> bool get(FILE* f, std::vector<X>& v, size_t n) { v.resize(n); return n == 0 || fread(v.data(), sizeof(X), n, f) == n; }
+template <class V> bool put(FILE* f, const V& v) { return v.empty() || fwrite(v.data(), sizeof(v[0]), v.size(), f) == v.size(); }
+template <class V> bool get(FILE* f, V& v, size_t n) { v.resize(n); return n == 0 || fread(v.data(), sizeof(v[0]), n, f) == n; }
 
 int save_cache(const pcr_dataset* ds, const char* path, const int64_t stamp[6]) {
     if (!ds || !path) { pcr_set_error("pcr_dataset_save_cache: bad argument"); return PCR_ERR_ARG; }

@@ -2,18 +2,33 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "primalcr.h"
+
+// std::vector whose resize(n) leaves the new elements UNINITIALISED: the loader's nnz-sized arrays are written exactly once, by the
+// threads that parse / scatter into them (a zero-fill of 8.4 GB on one thread is seconds at the Yahoo!Music shape, and it
+// would first-touch every page on the calling thread's NUMA node).
+template <class T>
+struct PcrNoInit : std::allocator<T> {
+    template <class U> struct rebind { using other = PcrNoInit<U>; };
+    PcrNoInit() = default;
+    template <class U> PcrNoInit(const PcrNoInit<U>&) {}
+    template <class U, class... A> void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using pcr_vec = std::vector<T, PcrNoInit<T>>;
 
 // user-major CSR in the reference's SparseMat layout (util.h:390-413); `item` is
 // SparseMat::rows, the user id per rating (SparseMat::cols) is implied by `index`.
 struct PcrCsr {
     int64_t d1 = 0, d2 = 0;
     std::vector<int64_t> index;   // d1 + 1
-    std::vector<int32_t> item;    // nnz
-    std::vector<double> val;      // nnz
+    pcr_vec<int32_t> item;        // nnz
+    pcr_vec<double> val;          // nnz
     int64_t nnz() const { return index.empty() ? 0 : index.back(); }
 };
 

@@ -235,3 +235,64 @@ extern "C" int pcr_synth_fill(const pcr_synth_params* p, int64_t u0, int64_t u1,
     for (auto& t : pool) t.join();
     return 0;
 }
+
+// The reference's rating-file format (util.h:118-131: one "user item rating" per line, 1-based ids) from a CSR, written by
+// `threads` formatting threads: every thread formats a contiguous user range into its own buffer, buffers go to the file in
+// user order.  Integer-valued ratings are printed as integers ("5"), real-valued ones with 17 significant digits (round trip).
+// user_base = 0-based id of the CSR's first user in the file.  Returns 0, or -1 on an I/O error.
+#include <cstdio>
+#include <string>
+extern "C" int pcr_synth_write_text(const char* path, int64_t nu, int64_t user_base, const int64_t* index, const int32_t* item,
+                                    const double* val, int threads) {
+    if (!path || nu < 0 || !index || (index[nu] > 0 && (!item || !val))) return -1;
+    FILE* f = fopen(path, "wb");
+    if (!f) return -1;
+    if (threads <= 0) threads = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    const int64_t nnz = index[nu];
+    const int64_t per_round = (int64_t)4 << 20;                  // ratings formatted per round and thread
+    bool ok = true;
+    auto put_uint = [](char* p, uint64_t x) {
+        char tmp[24]; int n = 0;
+        do { tmp[n++] = (char)('0' + x % 10); x /= 10; } while (x);
+        for (int i = 0; i < n; ++i) p[i] = tmp[n - 1 - i];
+        return p + n;
+    };
+    for (int64_t u_lo = 0; u_lo < nu && ok;) {
+        // this round's user ranges: about per_round ratings per thread
+        std::vector<int64_t> cut(1, u_lo);
+        for (int t = 0; t < threads && cut.back() < nu; ++t) {
+            const int64_t target = index[cut.back()] + per_round;
+            int64_t u = (int64_t)(std::upper_bound(index + cut.back(), index + nu + 1, target) - index);
+            cut.push_back(std::min(nu, std::max(cut.back() + 1, u - 1)));
+        }
+        const int parts = (int)cut.size() - 1;
+        std::vector<std::string> out((size_t)parts);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < parts; ++t)
+            pool.emplace_back([&, t]() {
+                std::string& s = out[(size_t)t];
+                s.resize((size_t)(index[cut[t + 1]] - index[cut[t]]) * 48 + 64);
+                char* p = &s[0];
+                for (int64_t u = cut[t]; u < cut[t + 1]; ++u)
+                    for (int64_t z = index[u]; z < index[u + 1]; ++z) {
+                        p = put_uint(p, (uint64_t)(user_base + u + 1)); *p++ = ' ';
+                        p = put_uint(p, (uint64_t)item[z] + 1); *p++ = ' ';
+                        const double v = val[z];
+                        if (v == std::floor(v) && std::fabs(v) < 1e15) {
+                            if (v < 0) *p++ = '-';
+                            p = put_uint(p, (uint64_t)std::fabs(v));
+                        } else {
+                            p += snprintf(p, 32, "%.17g", v);
+                        }
+                        *p++ = '\n';
+                    }
+                s.resize((size_t)(p - &s[0]));
+            });
+        for (auto& th : pool) th.join();
+        for (int t = 0; t < parts && ok; ++t) ok = out[(size_t)t].empty() || fwrite(out[(size_t)t].data(), 1, out[(size_t)t].size(), f) == out[(size_t)t].size();
+        u_lo = cut.back();
+    }
+    (void)nnz;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? 0 : -1;
+}

@@ -237,6 +237,7 @@ def _slib():
         L = C.CDLL(path)
         L.pcr_synth_counts.argtypes = [C.POINTER(_SynthParams), C.c_void_p, C.c_void_p]
         L.pcr_synth_fill.argtypes = [C.POINTER(_SynthParams), C.c_int64, C.c_int64] + [C.c_void_p] * 6 + [C.c_int]
+        L.pcr_synth_write_text.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _synth_lib = L
     return _synth_lib
 
@@ -285,8 +286,30 @@ def _write_ratings(path, user, item, val, real_valued):
             f.write("\n")
 
 
+def write_dir_fast(r: CsrRatings, path: str, train_name="training.ratings", test_name="test.ratings", threads=0):
+    """write_dir for a CsrRatings through the C++ writer (100 M ratings in seconds): same files, byte for byte."""
+    os.makedirs(path, exist_ok=True)
+    L = _slib()
+    index, tindex = np.ascontiguousarray(r.index, np.int64), np.ascontiguousarray(r.tindex, np.int64)
+    item, val = np.ascontiguousarray(r.item, np.int32), np.ascontiguousarray(r.val, np.float64)
+    titem, tval = np.ascontiguousarray(r.titem, np.int32), np.ascontiguousarray(r.tval, np.float64)
+    if L.pcr_synth_write_text(os.fsencode(os.path.join(path, train_name)), r.d1, 0, index.ctypes.data, item.ctypes.data,
+                              val.ctypes.data, threads) != 0:
+        raise OSError(f"could not write {path}/{train_name}")
+    with open(os.path.join(path, "meta"), "w") as f:
+        f.write(f"{r.d1} {r.d2}\n{int(index[-1])} {train_name}\n")
+        if int(tindex[-1]) > 0:
+            if L.pcr_synth_write_text(os.fsencode(os.path.join(path, test_name)), r.d1, 0, tindex.ctypes.data, titem.ctypes.data,
+                                      tval.ctypes.data, threads) != 0:
+                raise OSError(f"could not write {path}/{test_name}")
+            f.write(f"{int(tindex[-1])} {test_name}\n")
+    return path
+
+
 def write_dir(r: Ratings, path: str, train_name="training.ratings", test_name="test.ratings"):
     """Write ``meta`` + rating files in the reference's data-dir format."""
+    if hasattr(r, "index"):
+        return write_dir_fast(r, path, train_name, test_name)
     os.makedirs(path, exist_ok=True)
     real_valued = bool(np.any(r.val != np.rint(r.val)))
     _write_ratings(os.path.join(path, train_name), r.user, r.item, r.val, real_valued)

@@ -303,3 +303,108 @@ def test_cxx_generator_is_range_and_thread_independent():
     assert np.array_equal(part.titem, R.titem[R.tindex[1000]:R.tindex[1500]])
     ds = pcr.Dataset.from_ratings(R)
     assert ds.dims() == (3000, 17770, 400_000, 30_000)
+
+
+def _write_lines(path, user, item, val):
+    with open(path, "w") as f:
+        f.write("".join(f"{u + 1} {i + 1} {int(v)}\n" for u, i, v in zip(user.tolist(), item.tolist(), val.tolist())))
+
+
+@pytest.mark.parametrize("order", ["sorted", "shuffled", "users_reversed"])
+def test_parallel_loader_paths_match_the_reference_convert(order, tmp_path):
+    """The multi-threaded loader (mmap, pieces cut at line boundaries, adopted arrays for (user, item)-ordered files, bucketed
+    counting sort otherwise, running-maximum rows of the test set) against the UNMODIFIED reference's load() + convert()
+    (util.cpp:6-25, util.h:197-271, util.cpp:219-274 through oracle/_ref/libpcrref.so) on files large enough that several pieces
+    are really cut (> 1 MB), incl. an unsorted test file with an id beyond d1 in the middle (util.cpp:259-261: the scan ends there)."""
+    from oracle.oracle_py import RefShim
+    if not RefShim.available():
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    R = synth.generate_fast("netflix", d1=1500, d2=900, nnz=150_000, n_test=40, seed=5)
+    user, item, val = R.user.astype(np.int64), R.item.astype(np.int64), R.val
+    rng = np.random.default_rng(3)
+    if order == "shuffled":
+        p = rng.permutation(len(user)); user, item, val = user[p], item[p], val[p]
+    elif order == "users_reversed":                       # every piece sorted inside, the seams out of order
+        p = np.argsort(-user, kind="stable"); user, item, val = user[p], item[p], val[p]
+    d = tmp_path / "data"; d.mkdir()
+    _write_lines(d / "training.ratings", user, item, val)
+    tuser, titem, tval = R.tuser.astype(np.int64).copy(), R.titem.astype(np.int64), R.tval
+    # the test file: mostly user-sorted, a few entries out of order (they join the row of the largest id seen so far) ...
+    for z in rng.choice(len(tuser) // 2, 25, replace=False):
+        tuser[z] = max(0, tuser[z] - int(rng.integers(1, 40)))
+    tuser[len(tuser) * 3 // 4] = R.d1 + 5                 # ... and an id that is no user: the reference's scan stops here
+    _write_lines(d / "test.ratings", tuser, titem, tval)
+    (d / "meta").write_text(f"{R.d1} {R.d2}\n{len(user)} training.ratings\n{len(tuser)} test.ratings\n")
+    assert os.path.getsize(d / "training.ratings") > (1 << 20)
+    X, XT = RefShim().load_dir(str(d))
+    assert XT.nnz < len(tuser) and XT.nnz >= len(tuser) * 3 // 4
+    for threads in (1, 3, 8):
+        ds = pcr.Dataset.load(str(d), threads=threads)
+        idx, it, v = ds.csr(0)
+        assert np.array_equal(idx, X.idx) and np.array_equal(it, X.item) and np.array_equal(v, X.val), (order, threads)
+        tidx, tit, tv = ds.csr(1)
+        assert np.array_equal(tidx, XT.idx) and np.array_equal(tit, XT.item) and np.array_equal(tv, XT.val), (order, threads)
+    ds3 = pcr.Dataset.from_triplets(R.d1, R.d2, user, item, val, np.minimum(tuser, R.d1 + 5), titem, tval)
+    idx, it, v = ds3.csr(0)
+    assert np.array_equal(idx, X.idx) and np.array_equal(it, X.item) and np.array_equal(v, X.val)
+    tidx, tit, tv = ds3.csr(1)
+    assert np.array_equal(tidx, XT.idx) and np.array_equal(tit, XT.item) and np.array_equal(tv, XT.val)
+
+
+def test_loader_blank_lines_crlf_and_missing_final_newline(tmp_path):
+    """Line counting of the pieces: blank lines, "\\r\\n", trailing blanks and an unterminated last line must not shift entries
+    between the pieces (every piece is told how many ratings precede it)."""
+    R = synth.generate_fast("netflix", d1=1200, d2=700, nnz=120_000, n_test=2, seed=9)
+    user, item, val = R.user.astype(np.int64), R.item.astype(np.int64), R.val
+    lines = [f"{u + 1} {i + 1} {int(v)}" for u, i, v in zip(user.tolist(), item.tolist(), val.tolist())]
+    rng = np.random.default_rng(2)
+    want = pcr.Dataset.from_triplets(R.d1, R.d2, user, item, val).csr(0)
+    for style in ("crlf", "blank", "trailing", "no_final_newline"):
+        out = list(lines)
+        if style == "crlf":
+            body = "\r\n".join(out) + "\r\n"
+        elif style == "blank":
+            for z in sorted(rng.choice(len(out), 300, replace=False).tolist(), reverse=True):
+                out.insert(z, "" if z % 2 else "   \t")
+            body = "\n\n" + "\n".join(out) + "\n\n\n"
+        elif style == "trailing":
+            body = "\n".join(x + ("  " if n % 7 == 0 else "") for n, x in enumerate(out)) + "\n"
+        else:
+            body = "\n".join(out)
+        d = tmp_path / style; d.mkdir()
+        (d / "training.ratings").write_text(body, newline="")
+        (d / "meta").write_text(f"{R.d1} {R.d2}\n{len(lines)} training.ratings\n")
+        assert len(body) > (1 << 20)
+        for threads in (1, 5):
+            got = pcr.Dataset.load(str(d), threads=threads).csr(0)
+            assert all(np.array_equal(a, b) for a, b in zip(got, want)), (style, threads)
+
+
+def test_loader_scales_with_its_thread_count(tmp_path):
+    """SURVEY 8f-2 "parallel text parse": the -n option of omp-pmf-train must buy something.  4 M ratings (53 MB of text): best of
+    three at 1 thread against best of three at 8 -- asserted loosely (1.5 x; measured here: 4 x, tools/exp_loader.py)."""
+    cores = len(os.sched_getaffinity(0))
+    if cores < 4:
+        pytest.skip("needs at least 4 cores")
+    import time
+    R = synth.generate_fast("netflix", d1=19200, nnz=4_000_000)
+    d = synth.write_dir(R, str(tmp_path / "data"))
+    def load(threads):
+        t = time.perf_counter()
+        ds = pcr.Dataset.load(d, threads=threads)
+        return time.perf_counter() - t, ds
+    # This VM hands a process that suddenly wants 8 CPUs one CPU's worth for about the first second (8 spinning threads take
+    # 8 x the time of one, then ramp up -- measured with a bare std::thread loop, NOTES.md): keep the multi-threaded demand up
+    # until the loads stop getting faster, then take the best of three of each.
+    n = min(8, cores)
+    t_end, prev = time.perf_counter() + 4.0, 1e9
+    while time.perf_counter() < t_end:
+        cur, _ = load(n)
+        if cur > 0.8 * prev and cur < 0.6 * load(1)[0]:
+            break
+        prev = cur
+    t8, ds8 = min((load(n) for _ in range(3)), key=lambda x: x[0])
+    t1, ds1 = min((load(1) for _ in range(3)), key=lambda x: x[0])
+    assert all(np.array_equal(a, b) for a, b in zip(ds1.csr(0), ds8.csr(0)))
+    assert np.array_equal(ds8.csr(0)[1], R.item)
+    assert t1 / t8 >= 1.5, (t1, t8)
