@@ -4,9 +4,10 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 without a launcher: the N ranks are started as CHILD processes (python -m torch.distributed.run
---nproc-per-node N ... bench.py, 127.0.0.1 rendezvous) before this process imports torch or touches a
-GPU, and rank 0's JSON line is relayed; started under torch.distributed.run it is one of the ranks.
+N > 1 without a launcher: the N ranks are started as direct CHILD processes (RANK / WORLD_SIZE / MASTER_* in
+their environment, 127.0.0.1 rendezvous) before this process imports torch or touches a GPU, and rank 0's
+JSON line is relayed; started under torch.distributed.run it is one of the ranks.  A rank that stops -- exit
+code, signal, exception -- is named on stderr, takes the job down, and the last stdout line is {"error": ...}.
 
 A "step" is one outer iteration of pcrpp() (pcrpp.cpp:873-881): one truncated-Newton step on V
 (gradient, <=10 CG Hessian-vector products, line search) and one Newton step per user on U -- the
@@ -165,7 +166,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(R, n_pairs, r, lam, sample_ratings=2_000_000, single_thread=True):
+def cpu_baseline(R, n_pairs, r, lam, sample_ratings=2_000_000, single_thread=True, data_dir=None):
     """Reference OpenMP path on this host (kind "reference"), else the C restatement (kind "port").
     BASELINE.md 3.3: timed at -n <all cores of this box's share> AND at -n 1.
     Bounded: data sets beyond `sample_ratings` ratings are timed on a prefix of their users (same shape, fewer users)."""
@@ -192,7 +193,8 @@ def cpu_baseline(R, n_pairs, r, lam, sample_ratings=2_000_000, single_thread=Tru
             log(f"[cpu_baseline] reference omp-pmf-train -n {threads}: {times[-1]:.2f}s for {iters} iteration(s) (wall {time.time() - t0:.1f}s)")
             return times[-1]
         with tempfile.TemporaryDirectory() as td:
-            d = synth.write_dir(R, os.path.join(td, "data"))
+            # (data_dir: the text directory of the WHOLE set, already written by the caller -- used when nothing was cut)
+            d = data_dir if (data_dir and sample_note == "the full data set") else synth.write_dir(R, os.path.join(td, "data"))
             it_all, it_one = 2, 1
             secs = ref_run(cores, it_all, d, td)
             secs1 = ref_run(1, it_one, d, td) if single_thread else None
@@ -213,6 +215,64 @@ def cpu_baseline(R, n_pairs, r, lam, sample_ratings=2_000_000, single_thread=Tru
     pairs = orc.count_pairs(X)
     return {"value": pairs / secs, "unit": "pairs/s", "cores": 1, "kind": "port",
             "sample": f"C restatement, first {nu} users ({int(keep.sum())} ratings, {pairs} pairs), 1 iteration = {secs:.2f} s"}
+
+
+def cli_leg(data_dir, r, lam, iters=10, ref_iters=None, ref_predict=1, threads=None, extra=(), timeout_s=1500, run_reference=True):
+    """The drop-in CLI end to end (the reference's user-facing unit, pmf-train.cpp:247-314): `omp-pmf-train -k r -l lam -t iters
+    data_dir model` with the reference's defaults otherwise (-p 1: both evaluations after every iteration), as a child process in
+    a scratch directory, wall-clocked from before the fork to after the exit, with the product's own phase split (--timing: load /
+    init / create / train / iter / eval / write); then the UNMODIFIED reference binary (oracle/_ref/omp-pmf-train -n <cores>) on the
+    same directory, same clock.  ref_iters / ref_predict bound the reference's run on large shapes (stated in the record)."""
+    import shutil
+    from oracle import oracle_py
+    ours = os.path.join(ROOT, "primalcr_amd", "bin", "omp-pmf-train")
+    cores = threads or host_cores()
+    out = {"command": f"omp-pmf-train -k {r} -l {lam:g} -t {iters} -n {cores} --timing <dir> <model>  (defaults otherwise: -s 2 -p 1)"}
+
+    def last_metrics(text):
+        te = re.findall(r"^\(Testing\) pairwise error is (\S+) and ndcg is (\S+)", text, re.M)
+        ob = re.findall(r"^Iter (\d+) time (\S+) obj (\S+)", text, re.M)
+        return {"ndcg10_test": float(te[-1][1]) if te else None, "pairwise_error_test": float(te[-1][0]) if te else None,
+                "iterations": int(ob[-1][0]) if ob else None, "iter_time_s": float(ob[-1][1]) if ob else None,
+                "objective": float(ob[-1][2]) if ob else None}
+    td = tempfile.mkdtemp(prefix="pcr_cli_", dir="/tmp")
+    try:
+        t0 = time.perf_counter()
+        p = subprocess.run([ours, "-k", str(r), "-l", repr(lam), "-t", str(iters), "-n", str(cores), "--timing", *extra, data_dir,
+                            os.path.join(td, "ours.model")], cwd=td, capture_output=True, text=True, timeout=timeout_s)
+        out["wall_s"] = time.perf_counter() - t0
+        if p.returncode != 0:
+            out["error"] = f"omp-pmf-train exited with {p.returncode}: {p.stderr.strip()[-300:]}"
+            return out
+        m = re.search(r"^\[timing\] (.*)$", p.stderr, re.M)
+        ph = {k: float(v) for k, v in (kv.split("=") for kv in m.group(1).split())} if m else {}
+        out.update({k: ph.get(k) for k in ("load_s", "init_s", "create_s", "train_s", "iter_s", "eval_s", "write_s")})
+        out["process_s"] = ph.get("wall_s")              # main() start to end; wall_s - process_s = fork / exec / library + code-object load / exit
+        out["model_bytes"] = os.path.getsize(os.path.join(td, "ours.model"))
+        out.update(last_metrics(p.stdout))
+        if ph:
+            big = max(("load_s", "init_s", "create_s", "iter_s", "eval_s", "write_s"), key=lambda k: ph.get(k, 0.0))
+            out["largest_phase"] = big
+        if run_reference and os.path.exists(oracle_py.REF_TRAIN):
+            ri = ref_iters or iters
+            t0 = time.perf_counter()
+            q = subprocess.run([oracle_py.REF_TRAIN, "-k", str(r), "-l", repr(lam), "-t", str(ri), "-p", str(ref_predict), "-n", str(cores), data_dir,
+                                os.path.join(td, "ref.model")], cwd=td, capture_output=True, text=True, timeout=timeout_s)
+            rw = time.perf_counter() - t0
+            if q.returncode == 0:
+                rm = last_metrics(q.stdout)
+                out["reference"] = dict(rm, wall_s=rw, cores=cores,
+                                        command=f"oracle/_ref/omp-pmf-train -k {r} -l {lam:g} -t {ri} -p {ref_predict} -n {cores} (the unmodified reference)")
+                out["reference_wall_s"] = rw
+                if ri == iters and ref_predict == 1:
+                    out["speedup_wall"] = rw / out["wall_s"]
+                    if rm["ndcg10_test"] is not None and out.get("ndcg10_test") is not None:
+                        out["ndcg10_test_minus_reference"] = out["ndcg10_test"] - rm["ndcg10_test"]
+            else:
+                out["reference"] = {"error": f"exited with {q.returncode}: {q.stderr.strip()[-200:]}"}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    return out
 
 
 def pmc_accumulate(csv_path, ctr, acc):
@@ -258,7 +318,7 @@ def live_traffic(shape, prec, r, timeout_s=170):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--shape", shape,
-                   "--precision", prec, "--rank-k", str(r), "--steps", "10", "--warmup", "5", "--no-cpu", "--no-f64", "--no-netflix", "--no-rows",
+                   "--precision", prec, "--rank-k", str(r), "--steps", "10", "--warmup", "5", "--no-cpu", "--no-cli", "--no-f64", "--no-netflix", "--no-rows",
                    "--no-profile", "--no-live-traffic", "--full-record", os.path.join(tmp, "child.json")]
             p = subprocess.Popen(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
                                  text=True, start_new_session=True)
@@ -342,6 +402,8 @@ def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name
             s.comm_init_p2p(shm_name + ("_64" if prec == pcr.PCR_F64 else "_32") + ("c" if count_rows else ""))
         else:
             s.comm_init(job.bcast(pcr.comm_unique_id() if rank == 0 else None))
+        if s.comm_nranks() != N:                 # "RCCL saw N ranks": nothing is timed on a communicator of another size
+            raise RuntimeError(f"the {args.comm} communicator reports {s.comm_nranks()} ranks, the job has {N}")
     # the reference's init stream (util.cpp:80): this rank's rows of initial(d1, k), and V = initial(d2, k)
     s.set_factors_local(pcr.initial_rows(total, r, first, s.n_users), pcr.initial(d2, r))
 
@@ -390,10 +452,18 @@ def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name
     launches = {name: s.profile_launches(name) for name in prof}
     scope = {name: s.profile_scope(name) for name in prof}
     s.profile(False)
+    # what the event pairs cost the timed region: the same K steps once more, straight after, without them (same clock)
+    noev = None
+    if profile and prof_period:
+        barrier()
+        t1 = time.perf_counter()
+        s.iterate(steps)
+        barrier()
+        noev = job.allmax(time.perf_counter() - t1)
     rows_by_class = s.class_row_gathers() if count_rows else {}
     te_err, te_ndcg = s.evaluate(1, 10)
     tr_err, tr_ndcg = s.evaluate(0, 10)
-    out = dict(secs=secs, objs=objs, inner=inner, prof=prof, launches=launches, scope=scope, prof_period=prof_period, cold=cold,
+    out = dict(secs=secs, secs_noevents=noev, objs=objs, inner=inner, prof=prof, launches=launches, scope=scope, prof_period=prof_period, cold=cold,
                u_rows=s.counter("ustep_row_gathers") - rows0, rows_by_class=rows_by_class, steps=steps,
                te=(te_err, te_ndcg), tr=(tr_err, tr_ndcg), comm_nranks=s.comm_nranks(), shard=(s.first_user, s.n_users, s.nnz_local))
     s.close()
@@ -569,7 +639,7 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False, live=No
 
 
 def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=("f32", "f64"), profile=True, cpu=True,
-            cpu_sample=2_000_000, cpu_single=True, verbose=False):
+            cpu_sample=2_000_000, cpu_single=True, verbose=False, cli=None):
     """Generate this rank's shard of `shape`, run the timed legs, return rank 0's record (None on the other ranks)."""
     import primalcr_amd as pcr
     from primalcr_amd import synth
@@ -622,6 +692,9 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
     value = n_pairs * steps / secs
     rec = {
         "value": value, "unit": "pairs/s", "ms_per_step": 1e3 * secs / steps, "s_per_iter": secs / steps, "steps": steps, "warmup": warmup,
+        # the timed region carries the HIP-event pairs the roofline's durations come from; the same K steps straight after, without them:
+        "ms_per_step_noevents": None if not run.get("secs_noevents") else 1e3 * run["secs_noevents"] / steps,
+        "profile_overhead_pct": None if not run.get("secs_noevents") else 100.0 * (secs / run["secs_noevents"] - 1.0),
         "dtype": main_p, "scaling": scaling,
         "workload": f"{note}; {total} users x {R.d2} items, {nnz_job} ratings, {n_pairs} ordered pairs; 1 step = 1 outer "
                     f"iteration (V step + U step)",
@@ -644,7 +717,8 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
             live64, took = live_traffic(shape, "f64", r)
             log(f"[traffic] live rocprofv3 --pmc passes, fp64 leg: " + (f"{took:.0f} s" if live64 else f"not available ({took}): stored passes used"))
         a64 = analyse(r64, r64["rows"], wl, "f64", N, f"{shape}:f64" if tkey else None, live=live64)
-        rec["f64"] = {"dtype": "f64", "ms_per_step": 1e3 * r64["secs"] / steps, "value": n_pairs * steps / r64["secs"], "cold_start": r64["cold"],
+        rec["f64"] = {"dtype": "f64", "ms_per_step": 1e3 * r64["secs"] / steps,
+                      "ms_per_step_noevents": None if not r64.get("secs_noevents") else 1e3 * r64["secs_noevents"] / steps, "value": n_pairs * steps / r64["secs"], "cold_start": r64["cold"],
                       "unit": "pairs/s", "ndcg10_test": r64["te"][1], "pairwise_error_test": r64["te"][0],
                       "objective": r64["objs"][-1], "inner_per_step": {k: v / steps for k, v in r64["inner"].items()},
                       "roofline": a64["roofline"], "roofline_phase": a64["roofline_phase"], "roofline_iteration": a64["roofline_iteration"],
@@ -654,15 +728,33 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
                               "('within fp32 tolerance')"}
         rec["f64_minus_f32"] = {"ndcg10_test": r64["te"][1] - run["te"][1], "pairwise_error_test": r64["te"][0] - run["te"][0],
                                 "objective_rel": r64["objs"][-1] / objs[-1] - 1}
-    if cpu and N == 1:
-        rec["cpu_baseline"] = cpu_baseline(R, n_pairs, r, lam, cpu_sample, cpu_single)
-        rec["speedup_vs_cpu_baseline"] = value / rec["cpu_baseline"]["value"]
-    else:
-        rec["cpu_baseline"] = None
+    rec["cpu_baseline"] = None
+    if N == 1 and (cpu or cli is not None):
+        import shutil
+        td = tempfile.mkdtemp(prefix="pcr_data_", dir="/tmp")
+        try:
+            data_dir = None
+            if cli is not None or R.nnz <= cpu_sample:                   # the workload as the reference's text directory (meta + rating files)
+                t0 = time.time()
+                data_dir = synth.write_dir(R, os.path.join(td, "data"))
+                log(f"[data] text directory written in {time.time() - t0:.1f}s")
+            if cpu:
+                rec["cpu_baseline"] = cpu_baseline(R, n_pairs, r, lam, cpu_sample, cpu_single, data_dir)
+                rec["speedup_vs_cpu_baseline"] = value / rec["cpu_baseline"]["value"]
+                if "f64" in rec:
+                    rec["f64"]["speedup_vs_cpu_baseline"] = rec["f64"]["value"] / rec["cpu_baseline"]["value"]
+            if cli is not None:
+                rec["cli"] = cli_leg(data_dir, r, lam, **cli)
+                c = rec["cli"]
+                log("[cli] omp-pmf-train end to end: " + (c.get("error") or
+                    f"{c['wall_s']:.2f}s wall (load {c['load_s']:.2f} init {c['init_s']:.2f} create {c['create_s']:.2f} iterations {c['iter_s']:.3f} "
+                    f"evaluation {c['eval_s']:.2f} write {c['write_s']:.2f}); reference {c.get('reference_wall_s')}"))
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
     return rec
 
 
-LINE_CAP = 4096        # bytes: the driver keeps ~8.6 KB of stdout; round 3's 45 KB line came back unparsed
+LINE_CAP = 5120        # bytes: the driver keeps ~8.6 KB of stdout; round 3's 45 KB line came back unparsed
 
 
 def _r(x, n=4):
@@ -700,6 +792,12 @@ def _cpu(cb):
     return o
 
 
+def _sample_short(sample):
+    """What a bounded cpu_baseline was timed on, in a dozen words."""
+    m = re.search(r"its first (\d+) users \((\d+) ratings", sample or "")
+    return f"first {m.group(1)} users ({m.group(2)} ratings) of the shape" if m else ((sample or "")[:80] or None)
+
+
 def _phases(rp):
     o = {}
     for k, v in (rp or {}).items():
@@ -708,7 +806,7 @@ def _phases(rp):
     return o or None
 
 
-def _top_kernels(kernels, n=5):
+def _top_kernels(kernels, n=3):
     top = sorted((kernels or {}).items(), key=lambda kv: -kv[1].get("gpu_time_share", 0))[:n]
     return [{"slot": k, "avg_us": v["avg_us"], "share": v["gpu_time_share"], "frac": v["frac_hbm_peak"],
              "traffic_x": v.get("traffic_over_algorithmic")} for k, v in top] or None
@@ -745,12 +843,23 @@ def compact_line(full, full_record_path=None):
                       "ceiling_GBs": ga.get("ceiling_GBs"), "frac": ga.get("frac"), "u_side_counted": ga.get("u_side_counted", True)} if ga else None
     line["roofline_phase"] = _phases(g("roofline_phase"))
     line["top_kernels"] = _top_kernels(g("kernels"))
+    line["profile_overhead_pct"] = _r(g("profile_overhead_pct"), 3)
     f64 = g("f64")
     if f64:
-        rf = f64.get("roofline") or {}
+        # the reference's arithmetic type: the like-for-like leg carries the same blocks as the headline (two numbers per phase)
+        rf = _roof(f64.get("roofline")) or {}
+        for drop in ("bound", "peak", "unit", "launches_timed", "share_of_gpu_time"):
+            rf.pop(drop, None)
+        if rf.get("binding"):
+            rf["binding"] = {"level": rf["binding"].get("level"), "frac": rf["binding"].get("frac")}
+        it64 = f64.get("roofline_iteration") or {}
         line["f64"] = {"ms_per_step": _r(f64["ms_per_step"], 6), "value": _r(f64["value"], 7), "ndcg10_test": _r(f64.get("ndcg10_test"), 6),
                        "ms_per_step_first5": _r((f64.get("cold_start") or {}).get("ms_per_step"), 5),
-                       "roofline": {"kernel": rf.get("kernel"), "frac": rf.get("frac"), "avg_launch_us": rf.get("avg_launch_us")} if rf else None,
+                       "speedup_vs_cpu_baseline": _r(f64.get("speedup_vs_cpu_baseline")),
+                       "roofline": rf or None,
+                       "roofline_phase": {k: {"wall_us": v.get("wall_us_per_step"), "frac": v.get("frac")}
+                                          for k, v in (f64.get("roofline_phase") or {}).items()} or None,
+                       "roofline_iteration_frac": it64.get("frac"),
                        "gather_frac": (f64.get("gather") or {}).get("frac")}
     nf = g("netflix")
     if nf:
@@ -760,17 +869,28 @@ def compact_line(full, full_record_path=None):
                            "ndcg10_test": _r(nf.get("ndcg10_test"), 6), "pairwise_error_test": _r(nf.get("pairwise_error_test"), 6),
                            "roofline": {"kernel": rf.get("kernel"), "frac": rf.get("frac"), "avg_launch_us": rf.get("avg_launch_us"),
                                         "traffic_over_algorithmic": rf.get("traffic_over_algorithmic")} if rf else None,
+                           "roofline_iteration_frac": (nf.get("roofline_iteration") or {}).get("frac"),
                            "gather": {"level": (nf.get("gather") or {}).get("level"), "frac": (nf.get("gather") or {}).get("frac")},
                            "f64_ms_per_step": _r(nf64.get("ms_per_step"), 6),
+                           # (timed on a user prefix of the shape: compare pairs/s, not s_per_iter with ms_per_step)
                            "cpu_baseline": {"value": _r(ncb.get("value"), 6), "cores": ncb.get("cores"), "kind": ncb.get("kind"),
-                                            "s_per_iter": _r(ncb.get("s_per_iter"), 5)} if ncb else None}
+                                            "s_per_iter": _r(ncb.get("s_per_iter"), 5),
+                                            "sample": _sample_short(ncb.get("sample"))} if ncb else None,
+                           "speedup_vs_cpu_baseline": _r(nf.get("speedup_vs_cpu_baseline"))}
+    cli = g("cli")
+    if cli:
+        ref = cli.get("reference") or {}
+        line["cli"] = {k: _r(cli.get(k), 4) for k in ("wall_s", "load_s", "init_s", "create_s", "train_s", "iter_s", "eval_s", "write_s",
+                                                      "reference_wall_s", "speedup_wall", "largest_phase")}
+        line["cli"].update({"ndcg10_test": _r(cli.get("ndcg10_test"), 6), "reference_ndcg10_test": _r(ref.get("ndcg10_test"), 6),
+                            "error": cli.get("error")})
     line["full_record"] = full_record_path
     # the cap: drop optional blocks (least important first) rather than ever print a line the driver cannot keep
     size = lambda: len(json.dumps(line, separators=(",", ":")))
     if size() >= LINE_CAP and len(cfg.get("workload") or "") > 240:
         cfg["workload"] = cfg["workload"][:240]
     for victim in ("top_kernels", "roofline_phase", "shards", "inner_per_step", "gather", "roofline_iteration", "cold_start", "exchange",
-                   "netflix", "f64"):
+                   "cli", "netflix", "f64"):
         if size() < LINE_CAP:
             break
         line.pop(victim, None)
@@ -783,16 +903,74 @@ def free_port():
         return s.getsockname()[1]
 
 
+def error_line(msg, **extra):
+    """The stdout line of a run that failed: a driver that reads the last line sees WHY there is no measurement."""
+    print(json.dumps(dict({"error": msg, "metric": "pairwise-comparisons/sec", "value": None}, **extra), separators=(",", ":")), flush=True)
+
+
 def spawn_ranks(N):
-    """--gpus N > 1 without a launcher: start the ranks as child processes of THIS one -- which has not imported torch and
-    never touches a GPU -- and relay what rank 0 prints (the children inherit stdout / stderr).  Never an exec."""
+    """--gpus N > 1 without a launcher: start the N ranks as DIRECT child processes of this one -- which has not imported torch
+    and never touches a GPU -- with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, and relay
+    what rank 0 prints (the children inherit stdout / stderr).  Never an exec.
+
+    No torch.distributed.run in between: its agent process imports torch and opens the device too, so an N-rank job was N + 1
+    processes on the card -- which is what ended round 4's 6-rank rehearsal on the one-GPU box without a word (the pool's process
+    guard allows 6 and kills the whole command; NOTES.md, round 5).  Every way a rank can stop is reported: exit code or signal on
+    stderr, the other ranks are taken down, and the last stdout line is {"error": ...}."""
+    import signal
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL / the peer-to-peer exchange across processes need it here
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // N)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={N}", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    log(f"[bench] --gpus {N}: launching {N} ranks: {' '.join(cmd[1:9])} bench.py ...")
-    return subprocess.run(cmd, env=env).returncode
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(N), LOCAL_WORLD_SIZE=str(N))
+    log(f"[bench] --gpus {N}: starting {N} ranks (direct children, rendezvous 127.0.0.1:{env['MASTER_PORT']})")
+    kids = []
+    for q in range(N):
+        kids.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                     env=dict(env, RANK=str(q), LOCAL_RANK=str(q), GROUP_RANK="0")))
+    stop = {"sig": None}
+
+    def on_signal(sig, _frame):                  # the parent's own SIGTERM / SIGINT goes to the ranks: nobody is left on the GPU
+        stop["sig"] = sig
+        for k in kids:
+            if k.poll() is None:
+                k.send_signal(signal.SIGTERM)
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+    failed, t_last, t_kill = None, time.time(), None
+    try:
+        while any(k.poll() is None for k in kids):
+            for q, k in enumerate(kids):
+                rc = k.poll()
+                if rc is not None and rc != 0 and failed is None:
+                    why = f"killed by signal {-rc} ({signal.Signals(-rc).name})" if rc < 0 else f"exited with code {rc}"
+                    failed = (q, rc, why)
+                    log(f"[bench] rank {q} {why} (pid {k.pid}): stopping the other ranks")
+                    for o in kids:
+                        if o.poll() is None:
+                            o.send_signal(signal.SIGTERM)
+                    t_kill = time.time() + 15.0
+            if failed and t_kill and time.time() > t_kill:
+                for o in kids:
+                    if o.poll() is None:
+                        log(f"[bench] rank pid {o.pid} ignored SIGTERM for 15 s: SIGKILL")
+                        o.kill()
+            if time.time() - t_last > 60.0:      # a heartbeat: a long multi-rank run is not mistaken for a hung one
+                t_last = time.time()
+                log(f"[bench] waiting for ranks {[q for q, k in enumerate(kids) if k.poll() is None]}")
+            time.sleep(0.05)
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    if failed is None:
+        for q, k in enumerate(kids):             # (a rank that failed after the loop's last look)
+            if k.returncode != 0:
+                failed = (q, k.returncode, f"exited with code {k.returncode}" if k.returncode > 0 else f"killed by signal {-k.returncode}")
+                break
+    if stop["sig"] is not None and failed is None:
+        failed = (-1, 128 + stop["sig"], f"the launcher received signal {stop['sig']}")
+    if failed:
+        error_line(f"rank {failed[0]} {failed[2]}; see stderr", n_gpus=N, rank=failed[0], returncode=failed[1])
+        return 1
+    return 0
 
 
 def main():
@@ -819,6 +997,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-f64", action="store_true", help="skip the second timed run in the reference's arithmetic type")
     ap.add_argument("--no-netflix", action="store_true", help="skip the Netflix-shaped sub-record of the default N = 1 run")
+    ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end leg of the default N = 1 run: the drop-in omp-pmf-train (-t 10, "
+                                                          "defaults) and the reference binary on the workload's text directory, wall-clocked")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-rows", action="store_true", help="skip the diagnostic replay that counts the rows the U step gathers (profiler passes)")
     ap.add_argument("--profile-period", type=int, default=0,
@@ -831,6 +1011,8 @@ def main():
                          "(default N = 1 ml1m run only; the stored passes of profiles/ are used instead)")
     ap.add_argument("--full-line", action="store_true", help="developer tools only: print the full record as the stdout line (tens of KB)")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--fault", default=None, help="test hook, 'rank:signal' or 'rank:exit:code': that rank ends itself that way before it touches "
+                                                  "a GPU (the launcher must name it, stop the others and print an error line)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -839,6 +1021,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     N = world
+    if args.fault and int(args.fault.split(":")[0]) == rank:
+        f = args.fault.split(":")
+        if f[1] == "exit":
+            os._exit(int(f[2]))
+        os.kill(os.getpid(), int(f[1]))
+        time.sleep(30)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the training path)")
@@ -865,8 +1053,9 @@ def main():
     job = Job(args, torch, dist, rank, N, device)
     r, lam = args.rank_k or (200 if args.shape == "yahoo" else 100), args.lam
     precisions = (args.precision,) if (args.no_f64 or args.precision == "f64") else ("f32", "f64")
+    default_run = (N == 1 and args.shape == "ml1m" and args.users is None and args.nnz is None and args.rank_k is None and args.precision == "f32")
     rec = measure(job, args.shape, r, lam, args.steps, args.warmup, args.users, args.nnz, precisions, not args.no_profile,
-                  not args.no_cpu, verbose=args.verbose)
+                  not args.no_cpu, verbose=args.verbose, cli={} if (default_run and not args.no_cli) else None)
     # configs[3] in the driver's line: the default N = 1 run also times a few steps of the Netflix-shaped set (north star "Target")
     nf = None
     if (N == 1 and args.shape == "ml1m" and not args.no_netflix and args.users is None and args.nnz is None and args.rank_k is None
@@ -900,5 +1089,28 @@ def main():
         dist.barrier(); dist.destroy_process_group()
 
 
+def guarded_main():
+    """Every way a rank can stop says why: `[rank q] ...` with the traceback on stderr, a non-zero exit code, and -- on rank 0,
+    whose stdout is the one a driver reads -- {"error": ...} as the last stdout line."""
+    rank = os.environ.get("RANK", "0")
+    try:
+        main()
+    except SystemExit as e:
+        if e.code not in (None, 0) and not isinstance(e.code, int):
+            log(f"[rank {rank}] {e.code}")
+            if rank == "0":
+                error_line(str(e.code), rank=0)
+            sys.exit(1)
+        raise
+    except BaseException as e:                   # (KeyboardInterrupt / SIGTERM-as-exception included)
+        import traceback
+        log(f"[rank {rank}] failed: {type(e).__name__}: {e}")
+        traceback.print_exc()
+        if rank == "0":
+            error_line(f"{type(e).__name__}: {e}"[:500], rank=0)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(1)                              # (not sys.exit: a rank blocked peers' collectives must not wait in atexit handlers)
+
+
 if __name__ == "__main__":
-    main()
+    guarded_main()

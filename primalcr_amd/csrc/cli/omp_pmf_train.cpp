@@ -21,6 +21,9 @@
 //   --comm rccl|p2p   exchange step: ncclAllReduce over RCCL (default) or the direct peer-to-peer reduce-scatter /
 //                     all-gather of pcr_solver_comm_init_p2p
 //   --tune key=value  a launch knob of pcr_tune() (repeatable)
+//   --timing          one "[timing] load_s=... init_s=... create_s=... train_s=... iter_s=... eval_s=... write_s=... wall_s=..." line
+//                     on stderr at the end: where the run's wall time went (iter_s = the reference's own "Iter k time" clock,
+//                     pcrpp.cpp:874-881; eval_s = train_s - iter_s; wall_s = from the first line of main to the last)
 #include <atomic>
 #include <cerrno>
 #include <cstdio>
@@ -31,6 +34,7 @@
 #include <fstream>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <sys/mman.h>
@@ -61,7 +65,8 @@ static void exit_with_help() {
         "    --gpus n : shard the users over n GPUs of this node, one worker process per GPU (default 1)\n"
         "    --devices a,b,.. : HIP device of every rank (default 0..n-1)\n"
         "    --comm rccl|p2p : all-reduce through RCCL (default) or direct peer-to-peer buffers\n"
-        "    --tune key=value : launch knob (pcr_tune)\n");
+        "    --tune key=value : launch knob (pcr_tune)\n"
+        "    --timing : print the phases of the run's wall time on stderr\n");
     exit(1);
 }
 
@@ -94,11 +99,31 @@ static void write_outputs(const pcr_params& param, const std::string& model, con
                           int64_t d1, int64_t d2) {
     const int k = param.k;
     std::string suffix = param.solver_type == PCR_SOLVER_PCR ? std::to_string(static_cast<int>(param.lambda)) : "";
+    // Same bytes as the reference's `f << M[a][b]` (an ofstream at its default precision = "%g"), formatted by up to 16 threads
+    // into per-thread buffers that go to the file in row order: 48 M numbers (the Netflix shape's U) are seconds, not a minute.
     auto dump = [&](const char* name, const std::vector<double>& M, int64_t rows) {
         std::cout << name << " matrix of size " << rows << ", " << k << std::endl;
-        std::ofstream f(std::string(name) + suffix + ".txt");
-        for (int64_t a = 0; a < rows; ++a)
-            for (int b = 0; b < k; ++b) { f << M[a * k + b]; f << (b < k - 1 ? " " : "\n"); }
+        FILE* f = fopen((std::string(name) + suffix + ".txt").c_str(), "wb");
+        if (!f) return;
+        const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), rows * k / 65536 + 1));
+        const int64_t rows_per_round = std::max<int64_t>(1, ((int64_t)1 << 20) / std::max(1, k));      // ~1 M numbers (16 MB of text at most) per thread and round
+        for (int64_t r0 = 0; r0 < rows; r0 += rows_per_round * T) {
+            std::vector<std::string> out((size_t)T);
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t)
+                th.emplace_back([&, t]() {
+                    const int64_t a0 = std::min(rows, r0 + rows_per_round * t), a1 = std::min(rows, a0 + rows_per_round);
+                    std::string& o = out[(size_t)t];
+                    o.resize((size_t)(a1 - a0) * (size_t)k * 16 + 16);
+                    char* p = &o[0];
+                    for (int64_t a = a0; a < a1; ++a)
+                        for (int b = 0; b < k; ++b) { p += snprintf(p, 16, "%g", M[a * k + b]); *p++ = b < k - 1 ? ' ' : '\n'; }
+                    o.resize((size_t)(p - &o[0]));
+                });
+            for (auto& x : th) x.join();
+            for (int t = 0; t < T; ++t) if (!out[(size_t)t].empty()) fwrite(out[(size_t)t].data(), 1, out[(size_t)t].size(), f);
+        }
+        fclose(f);
     };
     dump("U", U, d1);
     dump("V", V, d2);
@@ -295,6 +320,11 @@ static int train_multi(const pcr_dataset* ds, const pcr_params& param, int gpus,
 }
 
 int main(int argc, char** argv) {
+    const auto t_main = std::chrono::steady_clock::now();
+    auto t_lap = t_main;
+    auto lap = [&]() { const auto n = std::chrono::steady_clock::now(); const double d = std::chrono::duration<double>(n - t_lap).count(); t_lap = n; return d; };
+    bool timing = false;
+    double load_s = 0, init_s = 0, create_s = 0, train_s = 0, iter_s = 0, write_s = 0;
     pcr_params param;
     pcr_params_default(&param);
     std::string init_model, cache, comm_kind = "rccl";
@@ -304,6 +334,7 @@ int main(int argc, char** argv) {
     for (i = 1; i < argc; i++) {                       // pmf-train.cpp:36-108
         if (argv[i][0] != '-') break;
         if (!strcmp(argv[i], "--f64")) { param.precision = PCR_F64; continue; }
+        if (!strcmp(argv[i], "--timing")) { timing = true; continue; }
         if (++i >= argc) exit_with_help();
         if (!strcmp(argv[i - 1], "--device")) { param.device = atoi(argv[i]); continue; }
         if (!strcmp(argv[i - 1], "--init-model")) { init_model = argv[i]; continue; }
@@ -361,8 +392,10 @@ int main(int argc, char** argv) {
     fclose(fp);
 
     pcr_dataset* ds = nullptr;
+    (void)lap();
     if ((cache.empty() ? pcr_dataset_load_mt(input.c_str(), param.threads, &ds)
                        : pcr_dataset_load_cached(input.c_str(), param.threads, cache.c_str(), &ds)) != PCR_OK) die("load");
+    load_s = lap();
     // (every way out of main from here on releases the data set and the solver: found by LeakSanitizer on the failure paths)
     struct Holder { pcr_dataset* ds; pcr_solver* s; ~Holder() { if (s) pcr_solver_destroy(s); if (ds) pcr_dataset_free(ds); } } hold{ds, nullptr};
     int64_t d1, d2, nnz, tnnz;
@@ -381,6 +414,7 @@ int main(int argc, char** argv) {
         }
         if (pcr_model_load(init_model.c_str(), &m1, &m2, &kk, U.data(), V.data()) != PCR_OK) die("init-model");
     }
+    init_s = lap();
     std::cout << "the rank is " << k << std::endl;
     std::cout << "the number of rows is " << d1 << " and the number of cols is " << d2 << std::endl;
     if (param.solver_type == PCR_SOLVER_PCRPP) { std::cout << nnz << std::endl; std::cout << "starts!" << std::endl; }
@@ -390,25 +424,41 @@ int main(int argc, char** argv) {
         fprintf(stderr, "--gpus must be 1..16, --comm rccl or p2p, --devices one ordinal per rank\n");
         return 1;
     }
+    auto report = [&]() {
+        if (!timing) return;
+        fprintf(stderr, "[timing] load_s=%.4f init_s=%.4f create_s=%.4f train_s=%.4f iter_s=%.4f eval_s=%.4f write_s=%.4f wall_s=%.4f\n", load_s, init_s,
+                create_s, train_s, iter_s, std::max(0.0, train_s - iter_s), write_s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count());
+    };
     if (gpus > 1) {
+        (void)lap();
         const int rc = train_multi(ds, param, gpus, devices, comm_kind, U, V, d1, d2, snapshot_every, model);
         if (rc != 0) return rc;
+        train_s = lap();                                  // (workers: solver creation + training + deposit; rank 0 prints its own split)
         write_outputs(param, model, U, V, d1, d2);
+        write_s = lap();
+        report();
         return 0;
     }
     auto t0 = std::chrono::steady_clock::now();
+    (void)lap();
     pcr_solver* s = nullptr;
     if (!devices.empty()) param.device = devices[0];
     if (pcr_solver_create(ds, &param, 0, 1, &s) != PCR_OK) { fprintf(stderr, "solver: %s\n", pcr_last_error()); return 1; }
     hold.s = s;
     auto fail = [](const char* what) { fprintf(stderr, "%s: %s\n", what, pcr_last_error()); return 1; };
     if (pcr_solver_set_factors(s, U.data(), V.data()) != PCR_OK) return fail("set_factors");
+    create_s = lap();
     SnapCtx snap{s, snapshot_every, model, d1, d2, k, &U, &V, false};
-    if (pcr_train(s, snapshot_every > 0 ? snap_log : nullptr, &snap, nullptr) != PCR_OK) return fail("train");
+    std::vector<pcr_iter_stats> hist((size_t)std::max(0, param.maxiter) + 1);
+    if (pcr_train(s, snapshot_every > 0 ? snap_log : nullptr, &snap, hist.data()) != PCR_OK) return fail("train");
     if (snap.failed) return 1;
+    train_s = lap();
+    iter_s = hist.back().seconds;                         // cumulative, the clock scope of pcrpp.cpp:874-881
     if (pcr_solver_get_factors(s, U.data(), V.data()) != PCR_OK) return fail("get_factors");
     printf("Wall-time: %lg secs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 
     write_outputs(param, model, U, V, d1, d2);
+    write_s = lap();
+    report();
     return 0;
 }

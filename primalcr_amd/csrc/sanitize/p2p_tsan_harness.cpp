@@ -8,7 +8,8 @@
 //   1. N ranks rendezvous (rank 0 deliberately late, a stale block of a "crashed job" left under the name), run 200 scalar and
 //      vector all-reduces on the host-synchronised path (four barriers each), finalize, destroy;
 //   2. the same with one rank reporting an error mid-way: every other rank must leave its barrier with an error, none may hang;
-//   3. a rank that never shows up: the others time out of the rendezvous.
+//   3. a rank that never shows up: the others time out of the rendezvous;
+//   4. 8 ranks (the target machine) and 16 (the control block's table size) through scenario 1; 17 ranks are refused.
 // Exit code 0 and no "WARNING: ThreadSanitizer" on stderr = clean (tests/test_sanitizers.py).
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -95,6 +96,16 @@ int main() {
     if (run_job("/pcr_tsan_h2", 3, 1, -1, 20.0) != 3) bad |= 2;            // rank 1 fails: all three leave with an error
     if (run_job("/pcr_tsan_h3", 3, -1, 2, 1.0) != 2) bad |= 4;             // rank 2 never comes: the others time out
     shm_unlink("/pcr_tsan_h3");
+    // the target machine's rank count, and the table's limit (PCR_P2P_MAXR): posted[] / handle[] / the barrier counter at 8 and 16
+    if (run_job("/pcr_tsan_h4", 8, -1, -1, 60.0) != 800) bad |= 8;
+    if (run_job("/pcr_tsan_h5", PCR_P2P_MAXR, -1, -1, 60.0) != 100 * PCR_P2P_MAXR) bad |= 16;
+    {   // one more rank than the table holds: refused by every rank, nobody waits
+        std::atomic<int> refused{0};
+        std::vector<std::thread> th;
+        for (int r = 0; r < 2; ++r) th.emplace_back([&, r]() { P2PComm c; c.timeout_s = 2.0; if (!c.init("/pcr_tsan_h6", r, PCR_P2P_MAXR + 1, 10, 4, 0)) refused++; });
+        for (auto& t : th) t.join();
+        if (refused.load() != 2) bad |= 32;
+    }
     fprintf(stderr, bad ? "[harness] FAILED (%d)\n" : "[harness] all scenarios behaved\n", bad);
     return bad ? 1 : 0;
 }
