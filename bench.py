@@ -452,6 +452,10 @@ def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name
     launches = {name: s.profile_launches(name) for name in prof}
     scope = {name: s.profile_scope(name) for name in prof}
     s.profile(False)
+    rows_by_class = s.class_row_gathers() if count_rows else {}
+    te_err, te_ndcg = s.evaluate(1, 10)           # the quality after warmup + steps iterations (before the replay below)
+    tr_err, tr_ndcg = s.evaluate(0, 10)
+    comm_n, shard_now = s.comm_nranks(), (s.first_user, s.n_users, s.nnz_local)
     # what the event pairs cost the timed region: the same K steps once more, straight after, without them (same clock)
     noev = None
     if profile and prof_period:
@@ -460,12 +464,9 @@ def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name
         s.iterate(steps)
         barrier()
         noev = job.allmax(time.perf_counter() - t1)
-    rows_by_class = s.class_row_gathers() if count_rows else {}
-    te_err, te_ndcg = s.evaluate(1, 10)
-    tr_err, tr_ndcg = s.evaluate(0, 10)
     out = dict(secs=secs, secs_noevents=noev, objs=objs, inner=inner, prof=prof, launches=launches, scope=scope, prof_period=prof_period, cold=cold,
                u_rows=s.counter("ustep_row_gathers") - rows0, rows_by_class=rows_by_class, steps=steps,
-               te=(te_err, te_ndcg), tr=(tr_err, tr_ndcg), comm_nranks=s.comm_nranks(), shard=(s.first_user, s.n_users, s.nnz_local))
+               te=(te_err, te_ndcg), tr=(tr_err, tr_ndcg), comm_nranks=comm_n, shard=shard_now)
     s.close()
     return out
 
