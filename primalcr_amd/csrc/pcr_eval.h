@@ -264,6 +264,19 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_fin4(const double* __restrict_
 }
 
 // pmf-predict.cpp:58-63: pred[z] = U[user[z]] . V[item[z]]; G lanes per pair
+// gain[z] = gain of the rating's level (util.cpp:519: pow(2, v) - 1, evaluated once per (user, level) on the host and looked up
+// here): one wave per user, coalesced over its ratings.  lgain uses the slots of run_start (run_ofs[u] + level).
+__global__ __launch_bounds__(256) void k_gain_from_levels(const int64_t* __restrict__ uptr, const uint16_t* __restrict__ lvl,
+                                                          const int64_t* __restrict__ runofs, const double* __restrict__ lgain,
+                                                          double* __restrict__ gain, int64_t nu) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); u < nu; u += (int64_t)gridDim.x * 4) {
+        const int64_t a = uptr[u], b = uptr[u + 1];
+        const double* g = lgain + runofs[u];
+        for (int64_t z = a + lane; z < b; z += 64) gain[z] = g[lvl[z]];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_predict(const T* __restrict__ U, const T* __restrict__ Vm, const int32_t* __restrict__ user,
                                                  const int32_t* __restrict__ item, int64_t n, Geo geo, double* __restrict__ pred) {

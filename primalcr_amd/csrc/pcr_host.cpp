@@ -735,33 +735,65 @@ int pcr_host_threads() {
     return (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 }
 
-// Three passes, the outer two over user ranges in parallel: (1) per user the sorted distinct keys -- collected by insertion into a
-// small vector (rating sets have a handful of levels; a user with more than 64 distinct values falls back to sort + unique) --
-// and each rating's level; (2) prefix sums of the per-user level counts; (3) the cumulative per-level counts.
+// Three passes, the outer two over user ranges in parallel: (1) per user the sorted distinct keys and each rating's level;
+// (2) prefix sums of the per-user level counts; (3) the cumulative per-level counts and the level keys.
+// Pass 1 per user: rating sets have a handful of integer levels, so when the rounded keys of a user span fewer than 64 integers
+// (and, for PrimalCR's raw keys, every rating IS an integer) the level of a rating is a popcount in a 64-bit presence mask -- two
+// streaming passes over the ratings, no searching; otherwise insertion into a small sorted vector (<= 64 distinct values), else
+// sort + unique.
 int pcr_build_levels(const PcrCsr& X, int64_t u0, int64_t u1, int solver_type, PcrLevels& out, std::string& err) {
     const int64_t z0 = X.index[u0], z1 = X.index[u1], nu = u1 - u0;
-    out.level.assign((size_t)(z1 - z0), 0);
+    out.level.resize((size_t)(z1 - z0));
     out.run_ofs.assign((size_t)(nu + 1), 0);
     out.run_start.clear();
+    out.lev_val.clear();
     out.max_levels = 0;
     const int nth = pcr_host_threads();
     std::vector<int64_t> bad(nth, -1);
     std::vector<int> maxlev(nth, 0);
+    std::vector<char> allint(nth, 1);
     const bool pp = solver_type == PCR_SOLVER_PCRPP;
+    // per user: the presence mask + its base (fast path) or nothing (mask 0: general path, redone in pass 3 for the keys)
+    std::vector<uint64_t> umask((size_t)nu, 0);
+    std::vector<int64_t> ubase((size_t)nu, 0);
+    const double* val = X.val.data();
     pcr_parallel_ranges(nu, nth, [&](int t, int64_t lo, int64_t hi) {
         std::vector<double> uniq, keys;
         for (int64_t ui = lo; ui < hi; ++ui) {
             const int64_t a = X.index[u0 + ui], b = X.index[u0 + ui + 1];
+            if (b == a) { out.run_ofs[ui + 1] = 1; continue; }
+            long kmin = LONG_MAX, kmax = LONG_MIN;
+            bool ints = true;
+            for (int64_t z = a; z < b; ++z) {
+                const double v = val[z];
+                const long k = lround(v);
+                kmin = std::min(kmin, k); kmax = std::max(kmax, k);
+                ints = ints && (double)k == v;
+            }
+            if (!ints) allint[t] = 0;
+            if ((pp || ints) && kmax - kmin < 64 && kmin > LONG_MIN / 2 && kmax < LONG_MAX / 2) {
+                uint64_t m = 0;
+                for (int64_t z = a; z < b; ++z) m |= (uint64_t)1 << (lround(val[z]) - kmin);
+                for (int64_t z = a; z < b; ++z) {
+                    const int sh = (int)(lround(val[z]) - kmin);
+                    out.level[z - z0] = (uint16_t)__builtin_popcountll(m & (((uint64_t)1 << sh) - 1));
+                }
+                const int T = __builtin_popcountll(m);
+                umask[ui] = m; ubase[ui] = kmin;
+                maxlev[t] = std::max(maxlev[t], T);
+                out.run_ofs[ui + 1] = T + 1;
+                continue;
+            }
             uniq.clear();
             bool small = true;
             for (int64_t z = a; z < b && small; ++z) {
-                const double k = pp ? (double)lround(X.val[z]) : X.val[z];
+                const double k = pp ? (double)lround(val[z]) : val[z];
                 auto it = std::lower_bound(uniq.begin(), uniq.end(), k);
                 if (it == uniq.end() || *it != k) { if (uniq.size() >= 64) small = false; else uniq.insert(it, k); }
             }
             if (!small) {
                 keys.resize((size_t)(b - a));
-                for (int64_t z = a; z < b; ++z) keys[z - a] = pp ? (double)lround(X.val[z]) : X.val[z];
+                for (int64_t z = a; z < b; ++z) keys[z - a] = pp ? (double)lround(val[z]) : val[z];
                 uniq = keys;
                 std::sort(uniq.begin(), uniq.end());
                 uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
@@ -771,24 +803,34 @@ int pcr_build_levels(const PcrCsr& X, int64_t u0, int64_t u1, int solver_type, P
             maxlev[t] = std::max(maxlev[t], T);
             out.run_ofs[ui + 1] = T + 1;
             for (int64_t z = a; z < b; ++z) {
-                const double k = pp ? (double)lround(X.val[z]) : X.val[z];
+                const double k = pp ? (double)lround(val[z]) : val[z];
                 out.level[z - z0] = (uint16_t)(std::lower_bound(uniq.begin(), uniq.end(), k) - uniq.begin());
             }
         }
     });
+    out.integer_valued = true;
     for (int t = 0; t < nth; ++t) {
         if (bad[t] >= 0) { err = "user " + std::to_string(bad[t]) + " has more than 65535 distinct rating levels"; return PCR_ERR_UNSUPPORTED; }
         out.max_levels = std::max(out.max_levels, maxlev[t]);
+        out.integer_valued = out.integer_valued && allint[t];
     }
     for (int64_t ui = 0; ui < nu; ++ui) out.run_ofs[ui + 1] += out.run_ofs[ui];
     out.run_start.assign((size_t)out.run_ofs[nu], 0);
+    out.lev_val.assign((size_t)out.run_ofs[nu], 0.0);
     pcr_parallel_ranges(nu, nth, [&](int, int64_t lo, int64_t hi) {
         for (int64_t ui = lo; ui < hi; ++ui) {
             const int64_t a = X.index[u0 + ui], b = X.index[u0 + ui + 1];
             int32_t* rs = out.run_start.data() + out.run_ofs[ui];
+            double* lvv = out.lev_val.data() + out.run_ofs[ui];
             const int T = (int)(out.run_ofs[ui + 1] - out.run_ofs[ui]) - 1;
             for (int64_t z = a; z < b; ++z) rs[out.level[z - z0] + 1]++;
             for (int l = 0; l < T; ++l) rs[l + 1] += rs[l];
+            if (umask[ui]) {
+                int l = 0;
+                for (uint64_t m = umask[ui]; m; m &= m - 1) lvv[l++] = (double)(ubase[ui] + __builtin_ctzll(m));
+            } else {
+                for (int64_t z = a; z < b; ++z) lvv[out.level[z - z0]] = pp ? (double)lround(val[z]) : val[z];
+            }
         }
     });
     return PCR_OK;

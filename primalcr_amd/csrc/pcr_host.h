@@ -45,7 +45,9 @@ struct PcrLevels {
     std::vector<uint16_t> level;      // nnz
     std::vector<int64_t> run_ofs;     // d1 + 1
     std::vector<int32_t> run_start;   // sum_u (T_u + 1)
+    std::vector<double> lev_val;      // same slots as run_start: the key of level l of user u at run_ofs[u] + l (slot T_u unused)
     int max_levels = 0;
+    bool integer_valued = true;       // every rating of the range equals its own lround(): raw levels = rounded levels
 };
 int pcr_build_levels(const PcrCsr& X, int64_t u0, int64_t u1, int solver_type, PcrLevels& out, std::string& err);
 

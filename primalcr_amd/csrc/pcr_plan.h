@@ -11,7 +11,7 @@
 
 struct SpmmPlanIn {
     const std::vector<int64_t>& uptr;     // user-major CSR of the shard
-    const std::vector<int32_t>& item;
+    const int32_t* item;                  // (the data set's own array: no copy)
     int64_t nu, nnz, d2;
     int ld, G, ncu;                       // padded row length, lanes per row, CUs of the device
     size_t esz;                           // bytes per stored element
@@ -28,7 +28,7 @@ struct SpmmPlan {
 
 static inline void build_spmm_plan(const SpmmPlanIn& in, SpmmPlan& P) {
     const std::vector<int64_t>& uptr = in.uptr;
-    const std::vector<int32_t>& item = in.item;
+    const int32_t* item = in.item;
     const int64_t nu = in.nu, nnz_local = in.nnz, d2 = in.d2;
     const struct { int ld, G; } geo{in.ld, in.G};
     const int ncu = in.ncu;

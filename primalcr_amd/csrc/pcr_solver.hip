@@ -65,6 +65,11 @@ struct DBuf {
         if (!h.empty()) HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(X), hipMemcpyHostToDevice));
         return PCR_OK;
     }
+    int upload_n(const X* h, size_t count) {
+        RC(alloc(count));
+        if (count) HIPCHK(hipMemcpy(p, h, count * sizeof(X), hipMemcpyHostToDevice));
+        return PCR_OK;
+    }
     void free() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
     DBuf() = default;
     DBuf(const DBuf&) = delete;
@@ -240,7 +245,15 @@ struct Solver final : pcr_solver {
         int max_raw_levels = 0;
         std::vector<Bin> bins;
         std::vector<int64_t> h_uptr;
-        std::vector<double> h_val;
+        std::vector<double> h_val;        // only for a set with more than 64 raw levels per user (real-valued ratings)
+        // at most 64 raw levels: the level tables (count and gain per (user, level), slots as run_start) -- and on the device either
+        // the set's own level arrays or, for the training set, the solver's
+        std::vector<int64_t> h_runofs;
+        std::vector<int32_t> h_cnt;
+        std::vector<double> h_lgain;
+        const uint16_t* elvl_p = nullptr;
+        const int64_t* erunofs_p = nullptr;
+        const int32_t* erunstart_p = nullptr;
         int idcg_k = -1;
     } ev[2];
     DBuf<double> d_out4;
@@ -457,26 +470,40 @@ struct Solver final : pcr_solver {
     }
 
     // ------------------------------------------------------------------------------ setup
+    // users by rating count, longest first, ties in user order (what a stable sort by descending length gives): a counting sort,
+    // once per CSR -- every class layout below is then one pass over this list
+    static void length_order(const std::vector<int64_t>& uptr, int64_t nu, std::vector<int32_t>& order) {
+        order.resize((size_t)nu);
+        int64_t maxlen = 0;
+        for (int64_t u = 0; u < nu; ++u) maxlen = std::max(maxlen, uptr[u + 1] - uptr[u]);
+        if (maxlen > ((int64_t)1 << 24)) {
+            for (int64_t u = 0; u < nu; ++u) order[u] = (int32_t)u;
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return (uptr[a + 1] - uptr[a]) > (uptr[b + 1] - uptr[b]); });
+            return;
+        }
+        std::vector<int64_t> start((size_t)maxlen + 2, 0);
+        for (int64_t u = 0; u < nu; ++u) start[(size_t)(maxlen - (uptr[u + 1] - uptr[u])) + 1]++;
+        for (int64_t l = 0; l <= maxlen; ++l) start[(size_t)l + 1] += start[(size_t)l];
+        for (int64_t u = 0; u < nu; ++u) order[(size_t)start[(size_t)(maxlen - (uptr[u + 1] - uptr[u]))]++] = (int32_t)u;
+    }
     static void make_bins(const std::vector<int64_t>& uptr, int64_t nu, const std::vector<int64_t>* runofs, std::vector<Bin>& out,
+                          const std::vector<int32_t>& order,
                           const std::vector<int>& limits = {BIN_LIMIT[0], BIN_LIMIT[1], BIN_LIMIT[2]},
                           const std::vector<int>& blocks = {BIN_BLOCK[0], BIN_BLOCK[1], BIN_BLOCK[2], BIN_BLOCK[3]}) {
         const int nb = (int)limits.size() + 1;
         out.clear();
         out.resize(nb);
         for (int b = 0; b < nb; ++b) { out[b].block = blocks[b]; out[b].big = (b == nb - 1); out[b].limit = b < nb - 1 ? limits[b] : 0; }
-        for (int64_t u = 0; u < nu; ++u) {
+        for (int64_t q = 0; q < nu; ++q) {       // longest first: the tail of a launch is made of short users
+            const int32_t u = order[(size_t)q];
             int64_t len = uptr[u + 1] - uptr[u];
             int b = 0;
             while (b < nb - 1 && len > limits[b]) ++b;
-            out[b].users.push_back((int32_t)u);
+            out[b].users.push_back(u);
             out[b].nnz += len;
             out[b].cap = std::max<int>(out[b].cap, (int)len);
             if (runofs) out[b].max_lev = std::max<int>(out[b].max_lev, (int)((*runofs)[u + 1] - (*runofs)[u]) - 1);
         }
-        for (auto& bn : out)   // longest first: the tail of the launch is made of short users
-            std::stable_sort(bn.users.begin(), bn.users.end(), [&](int32_t a, int32_t b2) {
-                return (uptr[a + 1] - uptr[a]) > (uptr[b2 + 1] - uptr[b2]);
-            });
     }
 
     // shard_first >= 0: `ds` holds ONLY this rank's users (renumbered from 0) -- users [shard_first, shard_first + ds.d1) of a
@@ -547,7 +574,7 @@ struct Solver final : pcr_solver {
         // ---- host-side shard preparation
         std::vector<int64_t> uptr(nu + 1);
         for (int64_t u = 0; u <= nu; ++u) uptr[u] = X.index[ds_u0 + u] - z0;
-        std::vector<int32_t> item(X.item.begin() + z0, X.item.begin() + z1);
+        const int32_t* item = X.item.data() + z0;            // (the data set's own array: uploaded from where it lies)
         PcrLevels lv;
         std::string err;
         phase("copy CSR");
@@ -571,7 +598,9 @@ struct Solver final : pcr_solver {
         if (tune.sddmm_csc >= 0) sddmm_csc = tune.sddmm_csc != 0;
         std::vector<int32_t>&cpos = P.cpos, &cuser = P.cuser, &crow = P.crow, &ruser = P.ruser;
         phase("tile-major CSC, slab plan");
-        make_bins(uptr, nu, &lv.run_ofs, bins);
+        std::vector<int32_t> by_len;
+        length_order(uptr, nu, by_len);
+        make_bins(uptr, nu, &lv.run_ofs, bins, by_len);
         for (auto& b : bins) RC(b.d_users.upload(b.users, st));
         // sweep / prepare classes: class 0 = one wave per user, class 1 = one 512-thread workgroup, class 2 = global scratch.
         // The sweeps keep 12 B per rating in LDS.  Where to cut between "a wave per user, eight users per workgroup" and "a
@@ -581,9 +610,8 @@ struct Solver final : pcr_solver {
         // 20.4-22.7 us per sweep, 320: 19.4, 384: 20.1-21.0, 512: 25.9; 10 M-rating Netflix-shaped slice 256: 181, 512: 163).
         int sweep_wave_cap = 256;
         {
-            std::vector<int64_t> lens(nu);
-            for (int64_t u = 0; u < nu; ++u) lens[u] = uptr[u + 1] - uptr[u];
-            std::sort(lens.begin(), lens.end());
+            std::vector<int64_t> lens(nu);               // ascending
+            for (int64_t q = 0; q < nu; ++q) { const int32_t u = by_len[(size_t)(nu - 1 - q)]; lens[q] = uptr[u + 1] - uptr[u]; }
             const int64_t max_lds = std::upper_bound(lens.begin(), lens.end(), (int64_t)4096) - lens.begin();     // users that fit LDS
             const int64_t cap_b = max_lds > 0 ? lens[max_lds - 1] : 0;
             double best = 0.0;
@@ -599,10 +627,10 @@ struct Solver final : pcr_solver {
             }
         }
         if (tune.debug) fprintf(stderr, "[pcr] sweep wave cap %d\n", sweep_wave_cap);
-        make_bins(uptr, nu, &lv.run_ofs, sbins, {std::min(sweep_wave_cap, 4095), 4096}, {64, 512, 512});
+        make_bins(uptr, nu, &lv.run_ofs, sbins, by_len, {std::min(sweep_wave_cap, 4095), 4096}, {64, 512, 512});
         for (auto& b : sbins) RC(b.d_users.upload(b.users, st));
         const int prep_wave_cap = 256;
-        make_bins(uptr, nu, &lv.run_ofs, pbins, {prep_wave_cap, 4096}, {64, 512, 512});
+        make_bins(uptr, nu, &lv.run_ofs, pbins, by_len, {prep_wave_cap, 4096}, {64, 512, 512});
         for (auto& b : pbins) RC(b.d_users.upload(b.users, st));
         // (measured, ml1m: 1024-thread teams make both launches slower -- k_vsweep_all 23 -> 31 us, k_prepare_all 99 -> 133 us:
         // sixteen one-wave users per workgroup cost more occupancy than the longest user's chain gains -- so 512 stays)
@@ -658,7 +686,7 @@ struct Solver final : pcr_solver {
         ucap.push_back(1024); ublk.push_back(512);
         if (many(n_mid)) { ucap.push_back(2048); ublk.push_back(512); }
         ucap.push_back(4096); ublk.push_back(512); ublk.push_back(512);
-        make_bins(uptr, nu, &lv.run_ofs, ubins, ucap, ublk);
+        make_bins(uptr, nu, &lv.run_ofs, ubins, by_len, ucap, ublk);
         for (size_t q = 0; q < ngram; ++q) ubins[q].gram = true;
         // Workgroup clusters trade throughput for latency: only the longest users of the shard (the critical path, more than
         // 1024 ratings) get them, ncu/(4K) users (all their workgroups fit the chip at once, see below) -- ONE extra class
@@ -775,7 +803,7 @@ struct Solver final : pcr_solver {
         }
 
         phase("length classes");
-        RC(d_uptr.upload(uptr, st)); RC(d_item.upload(item, st)); RC(d_lvl.upload(lv.level, st));
+        RC(d_uptr.upload(uptr, st)); RC(d_item.upload_n(item, (size_t)nnz_local)); RC(d_lvl.upload(lv.level, st));
         {   // static CSC entry -> CSR position map (the inverse of cpos)
             std::vector<int32_t> c2r(nnz_local);
             pcr_parallel_ranges(nnz_local, pcr_host_threads(), [&](int, int64_t lo, int64_t hi) { for (int64_t z = lo; z < hi; ++z) c2r[cpos[z]] = (int32_t)z; });
@@ -807,6 +835,12 @@ struct Solver final : pcr_solver {
 
         phase("uploads, state arrays");
         // ---- eval sets (train shard, test shard)
+        // The evaluator compares RAW ratings (util.cpp:471): per user the dense rank of the raw value (elvl + run tables), the gain
+        // 2^v - 1 per rating (util.cpp:519) and, per ndcg_k, the ideal DCG.  With at most 64 raw levels per user (every rating
+        // scale in use) all of it derives from the per-user LEVEL TABLES: the gain of a rating is the gain of its level --
+        // pow() runs once per (user, level) on the host, the per-rating array is filled on the device -- and the ideal DCG walks
+        // the level counts from the top; neither the 8-byte ratings nor a per-rating gain array cross PCIe.  The training set
+        // reuses the solver's own level arrays when its raw levels are the rounded ones (integer ratings, or PrimalCR).
         for (int w = 0; w < 2; ++w) {
             const PcrCsr& E = w == 0 ? ds->train : ds->test;
             EvalSet& es = ev[w];
@@ -814,45 +848,62 @@ struct Solver final : pcr_solver {
             es.nnz = b - a;
             es.h_uptr.resize(nu + 1);
             for (int64_t u = 0; u <= nu; ++u) es.h_uptr[u] = E.index[ds_u0 + u] - a;
-            es.h_val.assign(E.val.begin() + a, E.val.begin() + b);
-            if (w == 1) {
-                std::vector<int32_t> it(E.item.begin() + a, E.item.begin() + b);
-                RC(es.uptr.upload(es.h_uptr, st)); RC(es.item.upload(it, st));
+            if (w == 1) { RC(es.uptr.upload(es.h_uptr, st)); RC(es.item.upload_n(E.item.data() + a, (size_t)es.nnz)); }
+            RC(es.idcg.alloc(nu));
+            const bool same = w == 0 && (prm.solver_type == PCR_SOLVER_PCR || lv.integer_valued);
+            PcrLevels rl_own;
+            std::string e2;
+            const PcrLevels* rl = same ? &lv : &rl_own;
+            const bool have_levels = same || pcr_build_levels(E, ds_u0, ds_u0 + nu, PCR_SOLVER_PCR, rl_own, e2) == PCR_OK;
+            std::vector<int32_t> order_own;
+            if (w == 1) length_order(es.h_uptr, nu, order_own);
+            const std::vector<int32_t>& order = w == 0 ? by_len : order_own;
+            if (have_levels) {
+                es.max_raw_levels = rl->max_levels;
+                if (same) { es.elvl_p = d_lvl.p; es.erunofs_p = d_runofs.p; es.erunstart_p = d_runstart.p; }       // (uploaded with the shard)
+                else {
+                    RC(es.elvl.upload(rl->level, st)); RC(es.erunofs.upload(rl->run_ofs, st)); RC(es.erunstart.upload(rl->run_start, st));
+                    es.elvl_p = es.elvl.p; es.erunofs_p = es.erunofs.p; es.erunstart_p = es.erunstart.p;
+                }
+                make_bins(es.h_uptr, nu, &rl->run_ofs, es.bins, order);
+            } else {
+                es.max_raw_levels = 1 << 30;
+                make_bins(es.h_uptr, nu, nullptr, es.bins, order);
             }
-            RC(es.val.upload(es.h_val, st));
-            std::vector<double> gain(es.nnz);
-            {   // util.cpp:519: pow(2, v) - 1 -- through a table of the same expression for small integer ratings (bitwise the same value)
-                double tab[64];
-                for (int i = 0; i < 64; ++i) tab[i] = pow(2.0, (double)i) - 1.0;
-                pcr_parallel_ranges(es.nnz, pcr_host_threads(), [&](int, int64_t lo, int64_t hi) {
-                    for (int64_t z = lo; z < hi; ++z) {
-                        const double v = es.h_val[z];
-                        const int iv = (v >= 0.0 && v < 64.0) ? (int)v : -1;
-                        gain[z] = (iv >= 0 && (double)iv == v) ? tab[iv] : pow(2.0, v) - 1.0;
+            if (es.max_raw_levels <= 64) {
+                // level tables: per (user, level) the count and the gain (pow(2, v) - 1 with the host's libm, as the reference computes it)
+                es.h_runofs = rl->run_ofs;
+                es.h_cnt.resize(rl->run_start.size());
+                es.h_lgain.resize(rl->run_start.size());
+                pcr_parallel_ranges(nu, pcr_host_threads(), [&](int, int64_t lo, int64_t hi) {
+                    for (int64_t u = lo; u < hi; ++u) {
+                        const int64_t o = rl->run_ofs[u], Tn = rl->run_ofs[u + 1] - o - 1;
+                        for (int64_t l = 0; l < Tn; ++l) {
+                            es.h_cnt[o + l] = rl->run_start[o + l + 1] - rl->run_start[o + l];
+                            es.h_lgain[o + l] = pow(2.0, rl->lev_val[o + l]) - 1.0;
+                        }
+                        es.h_cnt[o + Tn] = 0; es.h_lgain[o + Tn] = 0.0;
                     }
                 });
-            }
-            RC(es.gain.upload(gain, st));
-            RC(es.idcg.alloc(nu));
-            {
-                // levels of the RAW ratings (the evaluator compares doubles, util.cpp:471).  For the training set they are the
-                // solver's own levels when those are raw already (PrimalCR) or when every rating is an integer (lround changes nothing)
-                bool same = w == 0 && prm.solver_type == PCR_SOLVER_PCR;
-                if (w == 0 && !same) {
-                    same = true;
-                    for (int64_t z = 0; z < es.nnz && same; ++z) same = es.h_val[z] == (double)lround(es.h_val[z]);
+                DBuf<double> d_lgain;
+                RC(d_lgain.upload(es.h_lgain, st));
+                RC(es.gain.alloc((size_t)es.nnz));
+                if (es.nnz > 0) {
+                    const int64_t* up = w == 0 ? d_uptr.p : es.uptr.p;
+                    hipLaunchKernelGGL(k_gain_from_levels, dim3((unsigned)std::min<int64_t>(65535 * 16, cdiv(nu, 4))), dim3(256), 0, st, up, es.elvl_p, es.erunofs_p,
+                                       d_lgain.p, es.gain.p, nu);
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipStreamSynchronize(st));              // (d_lgain goes out of scope)
                 }
-                PcrLevels rl_own;
-                std::string e2;
-                const PcrLevels* rl = same ? &lv : &rl_own;
-                if (same || pcr_build_levels(E, ds_u0, ds_u0 + nu, PCR_SOLVER_PCR, rl_own, e2) == PCR_OK) {
-                    es.max_raw_levels = rl->max_levels;
-                    RC(es.elvl.upload(rl->level, st)); RC(es.erunofs.upload(rl->run_ofs, st)); RC(es.erunstart.upload(rl->run_start, st));
-                    make_bins(es.h_uptr, nu, &rl->run_ofs, es.bins);
-                } else {
-                    es.max_raw_levels = 1 << 30;
-                    make_bins(es.h_uptr, nu, nullptr, es.bins);
-                }
+            } else {
+                // more raw levels than the level-table form of the evaluator takes (real-valued ratings): the ratings themselves
+                es.h_val.assign(E.val.begin() + a, E.val.begin() + b);
+                RC(es.val.upload(es.h_val, st));
+                std::vector<double> gain(es.nnz);
+                pcr_parallel_ranges(es.nnz, pcr_host_threads(), [&](int, int64_t lo, int64_t hi) {
+                    for (int64_t z = lo; z < hi; ++z) gain[z] = pow(2.0, es.h_val[z]) - 1.0;                  // util.cpp:519
+                });
+                RC(es.gain.upload(gain, st));
             }
             for (auto& bn : es.bins) RC(bn.d_users.upload(bn.users, st));
         }
@@ -1648,6 +1699,21 @@ struct Solver final : pcr_solver {
             std::vector<double> idcg(n_users), disc(ndcg_k);
             for (int k = 1; k <= ndcg_k; ++k) disc[k - 1] = 1.0 / log2((double)k + 1.0);
             // (only the ndcg_k largest ratings of a user enter: a partial sort, users side by side on the host threads)
+            if (es.max_raw_levels <= 64) {
+                // the ndcg_k largest ratings of a user = its levels from the top, each as often as it occurs (equal ratings have
+                // equal gains: the order among them does not matter) -- the same terms in the same order as util.cpp:505-524
+                pcr_parallel_ranges(n_users, pcr_host_threads(), [&](int, int64_t lo, int64_t hi) {
+                    for (int64_t u = lo; u < hi; ++u) {
+                        const int64_t o = es.h_runofs[u], Tn = es.h_runofs[u + 1] - o - 1;
+                        const int64_t nowk = std::min<int64_t>(ndcg_k, es.h_uptr[u + 1] - es.h_uptr[u]);
+                        double m = 0.0;
+                        int64_t k = 1;
+                        for (int64_t l = Tn - 1; l >= 0 && k <= nowk; --l)
+                            for (int32_t c = 0; c < es.h_cnt[o + l] && k <= nowk; ++c, ++k) m += es.h_lgain[o + l] / log2((double)k + 1.0);
+                        idcg[u] = m;
+                    }
+                });
+            } else
             pcr_parallel_ranges(n_users, pcr_host_threads(), [&](int, int64_t lo, int64_t hi) {
                 std::vector<double> tmp;
                 for (int64_t u = lo; u < hi; ++u) {
@@ -1674,15 +1740,15 @@ struct Solver final : pcr_solver {
                 if (fast_eval && b.big) {                // ... users beyond 4096 ratings: the same in a global-scratch slice
                     const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
                     const size_t lds2 = small_common(512) + carve_bytes(rsc, 4);
-                    hipLaunchKernelGGL((k_eval2<T, 512, true>), dim3(std::min(nus, scratch_blocks)), dim3(512), lds2, q, up, it, es.elvl.p, es.erunofs.p,
-                                       es.erunstart.p, es.gain.p, es.idcg.p, es.disc.p, ndcg_k, b.d_users.p, nus, d_U.p, d_V.p, geo, d_out4.p, b.cap, cap_pad,
+                    hipLaunchKernelGGL((k_eval2<T, 512, true>), dim3(std::min(nus, scratch_blocks)), dim3(512), lds2, q, up, it, es.elvl_p, es.erunofs_p,
+                                       es.erunstart_p, es.gain.p, es.idcg.p, es.disc.p, ndcg_k, b.d_users.p, nus, d_U.p, d_V.p, geo, d_out4.p, b.cap, cap_pad,
                                        rsc, d_scratch.p, scratch_stride);
                     return;
                 }
                 if (fast_eval && !b.big) {               // O(len T log len): sort by (raw level, score)
                     const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
                     const size_t lds2 = small_common(b.block) + eval2_bytes<T>(b.cap, cap_pad, rsc);
-#define LE2(BL) hipLaunchKernelGGL((k_eval2<T, BL>), dim3(nus), dim3(BL), lds2, q, up, it, es.elvl.p, es.erunofs.p, es.erunstart.p, es.gain.p, es.idcg.p, es.disc.p, ndcg_k, b.d_users.p, nus, d_U.p, d_V.p, geo, d_out4.p, b.cap, cap_pad, rsc)
+#define LE2(BL) hipLaunchKernelGGL((k_eval2<T, BL>), dim3(nus), dim3(BL), lds2, q, up, it, es.elvl_p, es.erunofs_p, es.erunstart_p, es.gain.p, es.idcg.p, es.disc.p, ndcg_k, b.d_users.p, nus, d_U.p, d_V.p, geo, d_out4.p, b.cap, cap_pad, rsc)
                     if (b.block == 64) LE2(64); else if (b.block == 256) LE2(256); else LE2(512);
 #undef LE2
                     return;
