@@ -1,6 +1,7 @@
-// pcr_plan.h -- host-side plan of the item-major SpMM (k_spmm / k_spmm_fin, pcr_vside.h): the tile-major CSC of a shard, its
-// chunks, the (chunk, item) incidences with their static item-major slab rows, the item ranges and the workgroup -> chunk map that
-// binds a user tile to its XCD(s).  No GPU calls; included by pcr_solver.hip, which uploads the arrays.
+// pcr_plan.h -- host side of the plan of the item-major SpMM (k_spmm / k_spmm_fin, pcr_vside.h): the user tiles, the chunk lists,
+// the item ranges and the workgroup -> chunk map that binds a user tile to its XCD(s) -- everything that follows from the row
+// pointers and a few cut positions.  The nnz-sized part (the tile-major CSC itself, the new-item flags, the (chunk, item)
+// incidences with their static item-major slab rows) is built ON THE DEVICE from the uploaded CSR: pcr_plan_dev.h.  No GPU calls here.
 // Replaces the scatter of pcrpp.cpp:240-243 / :323-327 (one `omp atomic` per scalar) by a static plan built once per data set.
 #pragma once
 #include <algorithm>
@@ -26,7 +27,140 @@ struct SpmmPlan {
     size_t slab_rows = 0;
 };
 
-static inline void build_spmm_plan(const SpmmPlanIn& in, SpmmPlan& P) {
+// ---- the plan in three host steps around the device build (pcr_plan_dev.h) -------------------------------------------------------
+// 1. plan_tiles: chunk length, user tiles (tile_u), item ranges -- from the row pointers alone
+static inline void plan_tiles(const SpmmPlanIn& in, SpmmPlan& P, std::vector<int64_t>& tile_u) {
+    const std::vector<int64_t>& uptr = in.uptr;
+    const int64_t nu = in.nu, nnz_local = in.nnz, d2 = in.d2;
+    const struct { int ld, G; } geo{in.ld, in.G};
+    const int ncu = in.ncu;
+    const struct { int spmm_chunk, spmm_tiles, allreduce_chunks; } tune{in.tune_chunk, in.tune_tiles, in.tune_ranges};
+    int& spmm_chunk = P.chunk;
+    int& n_rng = P.n_rng;
+    auto& rng_item = P.rng_item;
+    // Tile-major CSC of the shard (pcr_kernels.h, k_spmm): users are cut into tiles of about equal rating count whose
+    // rows of U take at most 1.25 MB (measured on a 48 k x 17.8 k, 10 M shape: 1.2 MB tiles 379 us, 2.4 MB tiles 595 us =
+    // untiled, 0.6 MB tiles 411 us: the tile shares the XCD's 4 MB L2 with the streamed ids, c and the slab stores);
+    // inside a tile the entries are ordered by item, then user.
+    {
+        // chunk = ratings one lane group walks (one slab row per item it meets).  128 on large shards; a shard whose
+        // workgroups all fit on the chip at once (6 per CU at 80 VGPRs) gets the smallest chunk that still fits in one
+        // round -- more, shorter chains: ml1m 96 instead of 128, k_spmm 32.3 -> 30.3 us, 1.69 -> 1.66 ms per iteration
+        // (64: 33.3 us, a second round; 192: 40.3 us)
+        {
+            const int64_t groups_at_once = (int64_t)ncu * 6 * (256 / geo.G);
+            const int64_t fit = cdiv(std::max<int64_t>(nnz_local, 1), groups_at_once);
+            spmm_chunk = (int)std::min<int64_t>(128, std::max<int64_t>(64, (fit + 31) / 32 * 32));
+        }
+        if (tune.spmm_chunk > 0) spmm_chunk = std::max(8, tune.spmm_chunk);
+        const size_t row_bytes = (size_t)geo.ld * in.esz;
+        int64_t tile_users_max = std::max<int64_t>(64, (int64_t)((5u << 18) / row_bytes));
+        // Small shards: what a tile re-reads is its rows of U and its slice of c (4-byte gathers through the static map); 2, 4 or 8
+        // tiles -- each bound to 4, 2 or 1 XCDs -- whichever is the fewest that keeps that under 2 MB per tile.  Every (tile, item)
+        // pair costs a slab row, so fewer tiles is less slab: ml1m 4 tiles, 25 k rows = 10 MB written by k_spmm and read back by
+        // k_spmm_fin instead of 41 k rows = 16 MB at 8 tiles (k_spmm_fin 9.6 -> 8.3 us, k_spmm unchanged; 2 tiles: 7.8 / +0.7 us).
+        int64_t small_tiles = std::min<int64_t>(8, nu / 256);
+        if (small_tiles >= 2) {
+            const double reread = (double)nu * row_bytes + (double)nnz_local * in.esz;
+            small_tiles = reread / 2 <= 2e6 ? 2 : reread / 4 <= 2e6 ? 4 : 8;
+            small_tiles = std::min<int64_t>(small_tiles, nu / 256 >= 8 ? 8 : nu / 256 >= 4 ? 4 : 2);
+        }
+        int64_t ntiles = std::max<int64_t>(cdiv(nu, tile_users_max), small_tiles);
+        // ... but every (tile, item) pair with a rating costs a partial row in the slab: on a very wide, sparse item side
+        // (Yahoo-shaped: 136 k items) 1.25 MB tiles would hold ~5 ratings per pair and the slab would outweigh the
+        // gather.  Keep at least 16 ratings per pair on average (ml1m 32, Netflix shape 37: unaffected).
+        ntiles = std::min<int64_t>(ntiles, std::max<int64_t>(8, nnz_local / (16 * std::max<int64_t>(d2, 1))));
+        if (ntiles > 4) ntiles = (ntiles + 7) / 8 * 8;             // every XCD the same number of tiles (2 and 4 tiles: XCD groups)
+        else if (ntiles == 3) ntiles = 4;
+        if (tune.spmm_tiles > 0) ntiles = tune.spmm_tiles;
+        ntiles = std::max<int64_t>(1, std::min<int64_t>(ntiles, std::max<int64_t>(nu, 1)));
+        tile_users_max = std::max<int64_t>(tile_users_max, 2 * (int64_t)cdiv(nu, ntiles));       // (the density bound may ask for larger tiles)
+        tile_u.assign(1, 0);                                     // user boundaries: equal ratings, at most tile_users_max users
+        for (int64_t t = 1; t < ntiles; ++t) {
+            const int64_t want = nnz_local * t / ntiles;
+            int64_t u = std::lower_bound(uptr.begin(), uptr.end(), want) - uptr.begin();
+            u = std::min(u, tile_u.back() + tile_users_max);
+            u = std::max(u, tile_u.back());
+            u = std::min<int64_t>(u, nu);
+            tile_u.push_back(u);
+        }
+        tile_u.push_back(nu);
+        while ((int64_t)tile_u.size() >= 2 && nu - tile_u[tile_u.size() - 2] > tile_users_max) {     // the cap pushed users to the end
+            tile_u.back() = tile_u[tile_u.size() - 2] + tile_users_max;
+            tile_u.push_back(nu);
+        }
+        ntiles = (int64_t)tile_u.size() - 1;
+        P.ntiles = (int)ntiles;
+        // item ranges (see n_rng): OPT-IN through pcr_tune("allreduce_chunks", n) -- the overlap of one range's all-reduce with the
+        // next range's SpMM is equality-tested with several ranks on one device, but has never run across two physical GPUs
+        // (no multi-GPU node was available to this build), so the default exchange is the plain one: one all-reduce per vector
+        // on the solver's stream.  Where it should pay: vectors of 16 MB and more (the Yahoo!Music shape's 109 MB: one exchange
+        // ~ a third of a CG iteration at N = 8), about one range per 4 MB, at most 8; a range costs two more launches and its
+        // own ramp and tail, which an exchange of a few MB does not pay for.
+        n_rng = 1;
+        if (tune.allreduce_chunks > 0) n_rng = tune.allreduce_chunks;
+        n_rng = (int)std::max<int64_t>(1, std::min<int64_t>(n_rng, std::min<int64_t>(64, d2)));
+        rng_item.assign(n_rng + 1, 0);
+        for (int r = 0; r <= n_rng; ++r) rng_item[r] = d2 * r / n_rng;
+    }
+}
+
+// 2. plan_chunks: the chunk list of every (tile, item range) from where the tile's sorted entries cross into each range
+//    (cut[t * (n_rng + 1) + r], from the device's sorted keys; cut[.. + 0] / [.. + n_rng] = the tile's first / past-the-end entry).
+//    Chunks never straddle tiles or ranges.  trc0[t * n_rng + r] = first chunk of (tile, range).
+static inline void plan_chunks(SpmmPlan& P, int64_t nnz_local, const std::vector<int64_t>& cut, std::vector<int32_t>& trc0) {
+    const int64_t ntiles = P.ntiles;
+    const int n_rng = P.n_rng;
+    trc0.assign((size_t)ntiles * n_rng + 1, 0);
+    P.chunk_ptr.clear();
+    for (int64_t t = 0; t < ntiles; ++t)
+        for (int r = 0; r < n_rng; ++r) {
+            trc0[(size_t)t * n_rng + r] = (int32_t)P.chunk_ptr.size();
+            for (int64_t a = cut[(size_t)t * (n_rng + 1) + r]; a < cut[(size_t)t * (n_rng + 1) + r + 1]; a += P.chunk) P.chunk_ptr.push_back((int32_t)a);
+        }
+    trc0[(size_t)ntiles * n_rng] = (int32_t)P.chunk_ptr.size();
+    P.chunk_ptr.push_back((int32_t)nnz_local);
+}
+
+// 3. plan_blocks: workgroup -> chunks: gpb chunks per workgroup, never across tiles; tile t is walked by workgroups b = t mod 8 (mod 8).
+//    One plan per item range, back to back (each a multiple of 8 workgroups, so the affinity holds in a launch of one range
+//    as in a launch of all of them).
+static inline void plan_blocks(SpmmPlan& P, int G, const std::vector<int32_t>& trc0) {
+    const int64_t ntiles = P.ntiles;
+    const int n_rng = P.n_rng;
+    auto& blk = P.blk; auto& rng_blk = P.rng_blk;
+    const int gpb = 256 / G;
+    blk.clear();
+    rng_blk.assign(n_rng + 1, 0);
+    for (int r = 0; r < n_rng; ++r) {
+        std::vector<std::vector<int2>> per_xcd(8);
+        size_t rr8 = 0;
+        for (int64_t t = 0; t < ntiles; ++t) {
+            const int32_t c0 = trc0[(size_t)t * n_rng + r], c1 = trc0[(size_t)t * n_rng + r + 1];
+            // tile t -> XCD t mod 8; 2 or 4 tiles: tile t -> the XCDs {t, t + ntiles, ..} in turn (each of them then caches only
+            // that tile's rows of U and slice of c); any other count below 8: no affinity, use every XCD
+            size_t turn = 0;
+            for (int32_t c = c0; c < c1; c += gpb) {
+                const size_t x = ntiles >= 8 ? (size_t)(t % 8) : (ntiles == 2 || ntiles == 4) ? (size_t)t + (size_t)ntiles * (turn++ % (8 / ntiles)) : rr8++ % 8;
+                per_xcd[x].push_back(make_int2(c, std::min<int32_t>(gpb, c1 - c)));
+            }
+        }
+        size_t deepest = 0;
+        for (auto& v : per_xcd) deepest = std::max(deepest, v.size());
+        const size_t base = blk.size();
+        blk.resize(base + deepest * 8, make_int2(0, 0));
+        for (int x = 0; x < 8; ++x)
+            for (size_t i = 0; i < per_xcd[x].size(); ++i) blk[base + i * 8 + x] = per_xcd[x][i];
+        rng_blk[r + 1] = (int)blk.size();
+    }
+    if (blk.empty()) blk.push_back(make_int2(0, 0));
+    P.blocks = rng_blk[n_rng];
+}
+
+#ifdef PCR_PLAN_CHECK
+// The whole plan on the host, as rounds 1-4 built it: kept for -DPCR_PLAN_CHECK builds, where pcr_solver_create builds both and
+// compares every array (developer check of pcr_plan_dev.h; never in the shipped library).
+static inline void build_spmm_plan_host(const SpmmPlanIn& in, SpmmPlan& P) {
     const std::vector<int64_t>& uptr = in.uptr;
     const int32_t* item = in.item;
     const int64_t nu = in.nu, nnz_local = in.nnz, d2 = in.d2;
@@ -204,3 +338,4 @@ static inline void build_spmm_plan(const SpmmPlanIn& in, SpmmPlan& P) {
         P.ntiles = (int)ntiles;
     }
 }
+#endif

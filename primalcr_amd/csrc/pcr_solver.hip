@@ -46,6 +46,7 @@
 static inline int host_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 #include "pcr_plan.h"
+#include "pcr_plan_dev.h"
 
 // device buffer with RAII
 template <typename X>
@@ -506,6 +507,130 @@ struct Solver final : pcr_solver {
         }
     }
 
+    // The SpMM plan: tiles / chunk lists / workgroup map on the host (pcr_plan.h), the tile-major CSC, flags and slab rows on the
+    // device (pcr_plan_dev.h) from d_uptr / d_item.  Fills d_ruser, d_c2r, d_crow, d_cuser, d_cuf, d_chunk_ptr, d_slot_base,
+    // d_slot_id, d_item_slot, d_blk_chunks and P's host-side fields.
+    template <typename K>
+    int build_plan_keys(const SpmmPlanIn& in, SpmmPlan& P, const std::vector<int64_t>& tile_u, std::vector<int64_t>& cut) {
+        const int64_t nu = in.nu, n = in.nnz, ntiles = P.ntiles;
+        const int n_rng_ = P.n_rng;
+        RC(d_ruser.alloc((size_t)n)); RC(d_c2r.alloc((size_t)n)); RC(d_crow.alloc((size_t)n)); RC(d_cuser.alloc((size_t)n));
+        cut.assign((size_t)ntiles * (n_rng_ + 1), 0);
+        for (int64_t t = 0; t < ntiles; ++t) {                    // (one item range: the cuts are the tiles' own bounds)
+            cut[(size_t)t * (n_rng_ + 1)] = in.uptr[tile_u[t]];
+            cut[(size_t)t * (n_rng_ + 1) + n_rng_] = in.uptr[tile_u[t + 1]];
+        }
+        if (n == 0) return PCR_OK;
+        DBuf<K> key, skey;
+        DBuf<int32_t> val, sval;
+        DBuf<int64_t> d_tile_u;
+        RC(key.alloc((size_t)n)); RC(skey.alloc((size_t)n)); RC(val.alloc((size_t)n)); RC(sval.alloc((size_t)n));
+        RC(d_tile_u.upload(tile_u, st));
+        const unsigned grid_u = (unsigned)std::min<int64_t>(1 << 20, cdiv(std::max<int64_t>(nu, 1), 4));
+        hipLaunchKernelGGL((k_plan_keys<K>), dim3(grid_u), dim3(256), 0, st, d_uptr.p, d_item.p, d_tile_u.p, (int)ntiles, d2, nu, key.p, val.p, d_ruser.p);
+        HIPCHK(hipGetLastError());
+        const int bits = plan_bits((unsigned long long)ntiles * (unsigned long long)std::max<int64_t>(d2, 1));
+        HIPCHK(plan_sort_pairs<K>(key.p, skey.p, val.p, sval.p, (size_t)n, bits, st));
+        const unsigned grid_z = (unsigned)std::min<int64_t>(1 << 20, cdiv(n, 256));
+        hipLaunchKernelGGL(k_plan_gather, dim3(grid_z), dim3(256), 0, st, sval.p, d_item.p, d_ruser.p, d_c2r.p, d_crow.p, d_cuser.p, n);
+        HIPCHK(hipGetLastError());
+        if (n_rng_ > 1) {                                         // where every tile's sorted entries cross into each item range
+            std::vector<K> probe;
+            for (int64_t t = 0; t < ntiles; ++t)
+                for (int r = 1; r < n_rng_; ++r) probe.push_back((K)t * (K)d2 + (K)P.rng_item[r]);
+            DBuf<K> d_probe;
+            DBuf<int64_t> d_pos;
+            RC(d_probe.upload(probe, st)); RC(d_pos.alloc(probe.size()));
+            hipLaunchKernelGGL((k_plan_lower_bounds<K>), dim3((unsigned)cdiv((int64_t)probe.size(), 256)), dim3(256), 0, st, skey.p, n, d_probe.p, (int)probe.size(), d_pos.p);
+            HIPCHK(hipGetLastError());
+            std::vector<int64_t> pos(probe.size());
+            HIPCHK(hipMemcpyAsync(pos.data(), d_pos.p, pos.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            size_t q = 0;
+            for (int64_t t = 0; t < ntiles; ++t)
+                for (int r = 1; r < n_rng_; ++r) cut[(size_t)t * (n_rng_ + 1) + r] = pos[q++];
+        }
+        HIPCHK(hipStreamSynchronize(st));                         // (the temporaries go out of scope)
+        return PCR_OK;
+    }
+    int build_plan(const SpmmPlanIn& in, SpmmPlan& P) {
+        std::vector<int64_t> tile_u, cut;
+        plan_tiles(in, P, tile_u);
+        const int64_t n = in.nnz;
+        const unsigned long long key_span = (unsigned long long)P.ntiles * (unsigned long long)std::max<int64_t>(d2, 1);
+        if (key_span < ((unsigned long long)1 << 32)) RC(build_plan_keys<uint32_t>(in, P, tile_u, cut));
+        else RC(build_plan_keys<unsigned long long>(in, P, tile_u, cut));
+        std::vector<int32_t> trc0;
+        plan_chunks(P, n, cut, trc0);
+        plan_blocks(P, geo.G, trc0);
+        const int64_t nchunks = (int64_t)P.chunk_ptr.size() - 1;
+        RC(d_chunk_ptr.upload(P.chunk_ptr, st)); RC(d_blk_chunks.upload(P.blk, st));
+        RC(d_cuf.alloc((size_t)n)); RC(d_slot_base.alloc((size_t)nchunks + 1)); RC(d_item_slot.alloc((size_t)d2 + 1));
+        // new-item flags and the incidence count of every chunk; their prefix sums on the host (nchunks integers)
+        std::vector<int32_t> inc_base((size_t)nchunks + 1, 0);
+        const unsigned grid_c = (unsigned)std::min<int64_t>(1 << 20, cdiv(std::max<int64_t>(nchunks, 1), 4));
+        if (nchunks > 0) {
+            DBuf<int32_t> d_cnt;
+            RC(d_cnt.alloc((size_t)nchunks));
+            hipLaunchKernelGGL(k_plan_flags, dim3(grid_c), dim3(256), 0, st, d_chunk_ptr.p, nchunks, d_crow.p, d_cuser.p, d_cuf.p, d_cnt.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(inc_base.data() + 1, d_cnt.p, (size_t)nchunks * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (int64_t c = 0; c < nchunks; ++c) inc_base[(size_t)c + 1] += inc_base[(size_t)c];
+        }
+        HIPCHK(hipMemcpyAsync(d_slot_base.p, inc_base.data(), inc_base.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        const int64_t n_inc = inc_base[(size_t)nchunks];
+        P.slab_rows = (size_t)n_inc;
+        RC(d_slot_id.alloc((size_t)n_inc));
+        DBuf<int32_t> inc_item, inc_idx, sitem, sidx;
+        RC(inc_item.alloc((size_t)n_inc)); RC(inc_idx.alloc((size_t)n_inc)); RC(sitem.alloc((size_t)n_inc)); RC(sidx.alloc((size_t)n_inc));
+        if (n_inc > 0) {
+            hipLaunchKernelGGL(k_plan_inc_items, dim3(grid_c), dim3(256), 0, st, d_chunk_ptr.p, nchunks, d_crow.p, d_slot_base.p, inc_item.p, inc_idx.p);
+            HIPCHK(hipGetLastError());
+            // the rows of one item are consecutive in the slab, in chunk order: a STABLE sort of the incidences by item
+            HIPCHK(plan_sort_pairs<uint32_t>(reinterpret_cast<const uint32_t*>(inc_item.p), reinterpret_cast<uint32_t*>(sitem.p), inc_idx.p, sidx.p, (size_t)n_inc,
+                                             plan_bits((unsigned long long)std::max<int64_t>(d2, 1)), st));
+            hipLaunchKernelGGL(k_plan_slots, dim3((unsigned)std::min<int64_t>(1 << 20, cdiv(n_inc, 256))), dim3(256), 0, st, sidx.p, d_slot_id.p, n_inc);
+            HIPCHK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_plan_item_slot, dim3((unsigned)std::min<int64_t>(1 << 20, cdiv(d2 + 1, 256))), dim3(256), 0, st, sitem.p, n_inc, d2, d_item_slot.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+#ifdef PCR_PLAN_CHECK
+        RC(check_plan_against_host(in, P, inc_base));
+#endif
+        return PCR_OK;
+    }
+#ifdef PCR_PLAN_CHECK
+    template <typename X>
+    static bool same_as(const DBuf<X>& d, const std::vector<X>& h, const char* name) {
+        std::vector<X> g(h.size());
+        if (d.n < h.size()) { fprintf(stderr, "[plan check] %s: device %zu elements, host %zu\n", name, d.n, h.size()); return false; }
+        if (!h.empty() && hipMemcpy(g.data(), d.p, h.size() * sizeof(X), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        for (size_t i = 0; i < h.size(); ++i)
+            if (memcmp(&g[i], &h[i], sizeof(X)) != 0) { fprintf(stderr, "[plan check] %s differs at %zu of %zu\n", name, i, h.size()); return false; }
+        return true;
+    }
+    int check_plan_against_host(const SpmmPlanIn& in, const SpmmPlan& P, const std::vector<int32_t>& inc_base) {
+        SpmmPlan H;
+        build_spmm_plan_host(in, H);
+        std::vector<int32_t> c2r((size_t)in.nnz);
+        for (int64_t z = 0; z < in.nnz; ++z) c2r[(size_t)H.cpos[(size_t)z]] = (int32_t)z;
+        bool ok = H.chunk == P.chunk && H.ntiles == P.ntiles && H.n_rng == P.n_rng && H.blocks == P.blocks && H.slab_rows == P.slab_rows &&
+                  H.rng_item == P.rng_item && H.rng_blk == P.rng_blk && H.chunk_ptr == P.chunk_ptr && H.inc_base == inc_base &&
+                  H.blk.size() == P.blk.size() && (H.blk.empty() || memcmp(H.blk.data(), P.blk.data(), H.blk.size() * sizeof(int2)) == 0);
+        if (!ok) fprintf(stderr, "[plan check] host-side fields differ (chunk %d/%d tiles %d/%d blocks %d/%d slab %zu/%zu)\n", H.chunk, P.chunk, H.ntiles,
+                         P.ntiles, H.blocks, P.blocks, H.slab_rows, P.slab_rows);
+        ok = same_as(d_ruser, H.ruser, "ruser") && ok; ok = same_as(d_c2r, c2r, "c2r") && ok; ok = same_as(d_crow, H.crow, "crow") && ok;
+        ok = same_as(d_cuser, H.cuser, "cuser") && ok; ok = same_as(d_cuf, H.cuf, "cuf") && ok; ok = same_as(d_slot_id, H.slot_id, "slot_id") && ok;
+        ok = same_as(d_item_slot, H.item_slot, "item_slot") && ok;
+        fprintf(stderr, "[plan check] %lld ratings, %d tiles, %d ranges, %zu slab rows: %s\n", (long long)in.nnz, P.ntiles, P.n_rng, P.slab_rows,
+                ok ? "device plan == host plan" : "MISMATCH");
+        if (!ok) { pcr_set_error("PCR_PLAN_CHECK: the device-built SpMM plan differs from the host-built one"); return PCR_ERR_STATE; }
+        return PCR_OK;
+    }
+#endif
+
     // shard_first >= 0: `ds` holds ONLY this rank's users (renumbered from 0) -- users [shard_first, shard_first + ds.d1) of a
     // job with d1_total users (pcr_solver_create_shard); else the whole data set, partitioned here by pcr_partition_users
     int init(const pcr_dataset* ds, const pcr_params* p, int rank_, int nranks_, int64_t shard_first = -1, int64_t d1_total = 0) {
@@ -581,8 +706,12 @@ struct Solver final : pcr_solver {
         int rc = pcr_build_levels(X, ds_u0, ds_u0 + nu, prm.solver_type, lv, err);
         if (rc != PCR_OK) { pcr_set_error(err); return rc; }
         phase("levels");
+        // the shard's CSR goes up first: the nnz-sized part of the SpMM plan is built from it on the device (pcr_plan_dev.h)
+        RC(d_uptr.upload(uptr, st)); RC(d_item.upload_n(item, (size_t)nnz_local));
+        phase("CSR upload");
         SpmmPlan P;
-        build_spmm_plan(SpmmPlanIn{uptr, item, nu, nnz_local, d2, geo.ld, geo.G, ncu, sizeof(T), tune.spmm_chunk, tune.spmm_tiles, tune.allreduce_chunks}, P);
+        const SpmmPlanIn plan_in{uptr, item, nu, nnz_local, d2, geo.ld, geo.G, ncu, sizeof(T), tune.spmm_chunk, tune.spmm_tiles, tune.allreduce_chunks};
+        RC(build_plan(plan_in, P));
         spmm_chunk = P.chunk; n_rng = P.n_rng; rng_item = P.rng_item; rng_blk = P.rng_blk; spmm_blocks = P.blocks; spmm_tiles = P.ntiles;
         if (n_rng > 1) {          // the all-reduce of a finished item range runs on its own stream (launch_spmm)
             HIPCHK(hipStreamCreateWithFlags(&ar_st, hipStreamNonBlocking));
@@ -590,13 +719,9 @@ struct Solver final : pcr_solver {
             ev_rng.resize(n_rng);
             for (auto& e : ev_rng) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
-        RC(d_cuf.upload(P.cuf, st));
-        RC(d_chunk_ptr.upload(P.chunk_ptr, st)); RC(d_slot_base.upload(P.inc_base, st)); RC(d_slot_id.upload(P.slot_id, st));
-        RC(d_blk_chunks.upload(P.blk, st)); RC(d_item_slot.upload(P.item_slot, st));
         RC(d_slab.alloc(std::max<size_t>(P.slab_rows, 1) * geo.ld));
         sddmm_csc = (size_t)d2 * geo.ld * sizeof(T) > ((size_t)32 << 20) && spmm_tiles >= 8;     // item table larger than all L2s together
         if (tune.sddmm_csc >= 0) sddmm_csc = tune.sddmm_csc != 0;
-        std::vector<int32_t>&cpos = P.cpos, &cuser = P.cuser, &crow = P.crow, &ruser = P.ruser;
         phase("tile-major CSC, slab plan");
         std::vector<int32_t> by_len;
         length_order(uptr, nu, by_len);
@@ -803,13 +928,7 @@ struct Solver final : pcr_solver {
         }
 
         phase("length classes");
-        RC(d_uptr.upload(uptr, st)); RC(d_item.upload_n(item, (size_t)nnz_local)); RC(d_lvl.upload(lv.level, st));
-        {   // static CSC entry -> CSR position map (the inverse of cpos)
-            std::vector<int32_t> c2r(nnz_local);
-            pcr_parallel_ranges(nnz_local, pcr_host_threads(), [&](int, int64_t lo, int64_t hi) { for (int64_t z = lo; z < hi; ++z) c2r[cpos[z]] = (int32_t)z; });
-            RC(d_c2r.upload(c2r, st));
-        }
-        RC(d_cuser.upload(cuser, st)); RC(d_crow.upload(crow, st)); RC(d_ruser.upload(ruser, st));
+        RC(d_lvl.upload(lv.level, st));
         RC(d_runofs.upload(lv.run_ofs, st)); RC(d_runstart.upload(lv.run_start, st));
         RC(d_ms.alloc(nnz_local)); RC(d_sitem.alloc(nnz_local)); RC(d_slvl.alloc(nnz_local));
         RC(d_c.alloc(nnz_local)); RC(d_objp.alloc(nu)); RC(d_mcsr.alloc(nnz_local)); RC(d_b.alloc(nnz_local));
