@@ -34,6 +34,21 @@ def test_initial_matches_reference_stream(oracle):
     assert np.array_equal(X, oracle.initial(50, 7))
 
 
+def test_initial_in_parallel_is_the_reference_stream_bit_for_bit(oracle):
+    """Above 4 M values pcr_initial cuts the stream into ranges of tries (four minstd_rand0 draws each, jump-ahead by modular
+    exponentiation) and runs std::normal_distribution over every range on its own thread: the same bits as the reference's single
+    loop (util.cpp:80-93 through the compiled reference where it is built, else the C restatement's std calls), odd totals and row
+    ranges (pcr_initial_rows, what a rank of a sharded job asks for) included."""
+    from oracle.oracle_py import RefShim
+    ref = RefShim() if RefShim.available() else oracle
+    n, k = 60013, 71                                        # 4 260 923 values: odd, above the threshold
+    want = ref.initial(n, k)
+    got = pcr.initial(n, k)
+    assert got.tobytes() == want.tobytes()
+    for row0, nrows in ((0, 5), (n - 3, 3), (12345, 30000), (n // 2, 0)):
+        assert pcr.initial_rows(n, k, row0, nrows).tobytes() == want[row0:row0 + nrows].tobytes()
+
+
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_loader_and_convert_match_reference(name, tmp_path):
     g, _ = load_golden(name)
