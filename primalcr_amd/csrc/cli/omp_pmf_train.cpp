@@ -26,6 +26,7 @@
 //                     pcrpp.cpp:874-881; eval_s = train_s - iter_s; wall_s = from the first line of main to the last)
 #include <atomic>
 #include <cerrno>
+#include <charconv>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -99,7 +100,8 @@ static void write_outputs(const pcr_params& param, const std::string& model, con
                           int64_t d1, int64_t d2) {
     const int k = param.k;
     std::string suffix = param.solver_type == PCR_SOLVER_PCR ? std::to_string(static_cast<int>(param.lambda)) : "";
-    // Same bytes as the reference's `f << M[a][b]` (an ofstream at its default precision = "%g"), formatted by up to 16 threads
+    // Same bytes as the reference's `f << M[a][b]` (an ofstream at its default precision = printf's "%g" = std::to_chars in its
+    // general format at precision 6, which the standard defines through that printf conversion), formatted by up to 16 threads
     // into per-thread buffers that go to the file in row order: 48 M numbers (the Netflix shape's U) are seconds, not a minute.
     auto dump = [&](const char* name, const std::vector<double>& M, int64_t rows) {
         std::cout << name << " matrix of size " << rows << ", " << k << std::endl;
@@ -117,7 +119,7 @@ static void write_outputs(const pcr_params& param, const std::string& model, con
                     o.resize((size_t)(a1 - a0) * (size_t)k * 16 + 16);
                     char* p = &o[0];
                     for (int64_t a = a0; a < a1; ++a)
-                        for (int b = 0; b < k; ++b) { p += snprintf(p, 16, "%g", M[a * k + b]); *p++ = b < k - 1 ? ' ' : '\n'; }
+                        for (int b = 0; b < k; ++b) { p = std::to_chars(p, p + 16, M[a * k + b], std::chars_format::general, 6).ptr; *p++ = b < k - 1 ? ' ' : '\n'; }
                     o.resize((size_t)(p - &o[0]));
                 });
             for (auto& x : th) x.join();

@@ -264,6 +264,25 @@ __global__ __launch_bounds__(PCR_EW_BLOCK) void k_fin4(const double* __restrict_
 }
 
 // pmf-predict.cpp:58-63: pred[z] = U[user[z]] . V[item[z]]; G lanes per pair
+// fp64 row-major rows x r (the reference's mat_t payload) <-> the device's rows x ld matrix of T (pad columns zero)
+template <typename T>
+__global__ __launch_bounds__(256) void k_mat_in(const double* __restrict__ src, T* __restrict__ dst, int64_t rows, int r, int ld) {
+    const int64_t n = rows * ld;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / ld;
+        const int col = (int)(i - row * ld);
+        dst[i] = col < r ? (T)src[row * r + col] : (T)0;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_mat_out(const T* __restrict__ src, double* __restrict__ dst, int64_t rows, int r, int ld) {
+    const int64_t n = rows * r;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / r;
+        dst[i] = (double)src[row * ld + (i - row * r)];
+    }
+}
+
 // gain[z] = gain of the rating's level (util.cpp:519: pow(2, v) - 1, evaluated once per (user, level) on the host and looked up
 // here): one wave per user, coalesced over its ratings.  lgain uses the slots of run_start (run_ofs[u] + level).
 __global__ __launch_bounds__(256) void k_gain_from_levels(const int64_t* __restrict__ uptr, const uint16_t* __restrict__ lvl,

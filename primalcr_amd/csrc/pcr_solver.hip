@@ -1537,20 +1537,34 @@ struct Solver final : pcr_solver {
     }
 
     // ------------------------------------------------------------------------------ host <-> device
+    // Factor matrices cross the boundary as the reference's fp64 row-major payload (mat_t); the device keeps rows padded to ld
+    // elements of T.  The conversion runs on the device (k_mat_in / k_mat_out) on slabs of at most 64 M values, straight from / into
+    // the caller's buffer: no host-side staging copy, no serial conversion loop (48 M values at the Netflix shape).
     int upload_mat(const double* H, int64_t rows, T* D) {
-        std::vector<T> tmp((size_t)rows * geo.ld, (T)0);
-        for (int64_t i = 0; i < rows; ++i)
-            for (int j = 0; j < geo.r; ++j) tmp[(size_t)i * geo.ld + j] = (T)H[i * geo.r + j];
-        if (!tmp.empty()) HIPCHK(hipMemcpyAsync(D, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
+        const int64_t slab_rows = std::max<int64_t>(1, ((int64_t)64 << 20) / std::max(1, geo.r));
+        DBuf<double> stage;
+        RC(stage.alloc((size_t)std::min(rows, slab_rows) * geo.r));
+        for (int64_t r0 = 0; r0 < rows; r0 += slab_rows) {
+            const int64_t nr = std::min(slab_rows, rows - r0);
+            HIPCHK(hipMemcpyAsync(stage.p, H + r0 * geo.r, (size_t)nr * geo.r * sizeof(double), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((k_mat_in<T>), dim3((unsigned)std::min<int64_t>(1 << 16, cdiv(nr * geo.ld, 256))), dim3(256), 0, st, stage.p, D + r0 * geo.ld, nr, geo.r, geo.ld);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+        }
         return PCR_OK;
     }
     int download_mat(const T* D, int64_t rows, double* H) {
-        std::vector<T> tmp((size_t)rows * geo.ld);
-        if (!tmp.empty()) HIPCHK(hipMemcpyAsync(tmp.data(), D, tmp.size() * sizeof(T), hipMemcpyDeviceToHost, st));
-        RC(sync_checked());
-        for (int64_t i = 0; i < rows; ++i)
-            for (int j = 0; j < geo.r; ++j) H[i * geo.r + j] = (double)tmp[(size_t)i * geo.ld + j];
+        const int64_t slab_rows = std::max<int64_t>(1, ((int64_t)64 << 20) / std::max(1, geo.r));
+        DBuf<double> stage;
+        RC(stage.alloc((size_t)std::min(rows, slab_rows) * geo.r));
+        for (int64_t r0 = 0; r0 < rows; r0 += slab_rows) {
+            const int64_t nr = std::min(slab_rows, rows - r0);
+            hipLaunchKernelGGL((k_mat_out<T>), dim3((unsigned)std::min<int64_t>(1 << 16, cdiv(nr * geo.r, 256))), dim3(256), 0, st, D + r0 * geo.ld, stage.p, nr, geo.r, geo.ld);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(H + r0 * geo.r, stage.p, (size_t)nr * geo.r * sizeof(double), hipMemcpyDeviceToHost, st));
+            RC(sync_checked());
+        }
+        if (rows == 0) RC(sync_checked());
         return PCR_OK;
     }
 
