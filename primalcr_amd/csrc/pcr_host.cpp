@@ -828,6 +828,14 @@ int pcr_host_threads() {
 // (and, for PrimalCR's raw keys, every rating IS an integer) the level of a rating is a popcount in a 64-bit presence mask -- two
 // streaming passes over the ratings, no searching; otherwise insertion into a small sorted vector (<= 64 distinct values), else
 // sort + unique.
+// lround() without the libm call: truncate, then step away from zero when the (exactly representable) remainder is at least a half
+static inline long fast_lround(double v) {
+    if (!(v > -4.0e15 && v < 4.0e15)) return lround(v);
+    const long t = (long)v;
+    const double f = v - (double)t;
+    return f >= 0.5 ? t + 1 : f <= -0.5 ? t - 1 : t;
+}
+
 int pcr_build_levels(const PcrCsr& X, int64_t u0, int64_t u1, int solver_type, PcrLevels& out, std::string& err) {
     const int64_t z0 = X.index[u0], z1 = X.index[u1], nu = u1 - u0;
     out.level.resize((size_t)(z1 - z0));
@@ -853,16 +861,16 @@ int pcr_build_levels(const PcrCsr& X, int64_t u0, int64_t u1, int solver_type, P
             bool ints = true;
             for (int64_t z = a; z < b; ++z) {
                 const double v = val[z];
-                const long k = lround(v);
+                const long k = fast_lround(v);
                 kmin = std::min(kmin, k); kmax = std::max(kmax, k);
                 ints = ints && (double)k == v;
             }
             if (!ints) allint[t] = 0;
             if ((pp || ints) && kmax - kmin < 64 && kmin > LONG_MIN / 2 && kmax < LONG_MAX / 2) {
                 uint64_t m = 0;
-                for (int64_t z = a; z < b; ++z) m |= (uint64_t)1 << (lround(val[z]) - kmin);
+                for (int64_t z = a; z < b; ++z) m |= (uint64_t)1 << (fast_lround(val[z]) - kmin);
                 for (int64_t z = a; z < b; ++z) {
-                    const int sh = (int)(lround(val[z]) - kmin);
+                    const int sh = (int)(fast_lround(val[z]) - kmin);
                     out.level[z - z0] = (uint16_t)__builtin_popcountll(m & (((uint64_t)1 << sh) - 1));
                 }
                 const int T = __builtin_popcountll(m);
@@ -874,13 +882,13 @@ int pcr_build_levels(const PcrCsr& X, int64_t u0, int64_t u1, int solver_type, P
             uniq.clear();
             bool small = true;
             for (int64_t z = a; z < b && small; ++z) {
-                const double k = pp ? (double)lround(val[z]) : val[z];
+                const double k = pp ? (double)fast_lround(val[z]) : val[z];
                 auto it = std::lower_bound(uniq.begin(), uniq.end(), k);
                 if (it == uniq.end() || *it != k) { if (uniq.size() >= 64) small = false; else uniq.insert(it, k); }
             }
             if (!small) {
                 keys.resize((size_t)(b - a));
-                for (int64_t z = a; z < b; ++z) keys[z - a] = pp ? (double)lround(val[z]) : val[z];
+                for (int64_t z = a; z < b; ++z) keys[z - a] = pp ? (double)fast_lround(val[z]) : val[z];
                 uniq = keys;
                 std::sort(uniq.begin(), uniq.end());
                 uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
@@ -890,7 +898,7 @@ int pcr_build_levels(const PcrCsr& X, int64_t u0, int64_t u1, int solver_type, P
             maxlev[t] = std::max(maxlev[t], T);
             out.run_ofs[ui + 1] = T + 1;
             for (int64_t z = a; z < b; ++z) {
-                const double k = pp ? (double)lround(val[z]) : val[z];
+                const double k = pp ? (double)fast_lround(val[z]) : val[z];
                 out.level[z - z0] = (uint16_t)(std::lower_bound(uniq.begin(), uniq.end(), k) - uniq.begin());
             }
         }
@@ -916,7 +924,7 @@ int pcr_build_levels(const PcrCsr& X, int64_t u0, int64_t u1, int solver_type, P
                 int l = 0;
                 for (uint64_t m = umask[ui]; m; m &= m - 1) lvv[l++] = (double)(ubase[ui] + __builtin_ctzll(m));
             } else {
-                for (int64_t z = a; z < b; ++z) lvv[out.level[z - z0]] = pp ? (double)lround(val[z]) : val[z];
+                for (int64_t z = a; z < b; ++z) lvv[out.level[z - z0]] = pp ? (double)fast_lround(val[z]) : val[z];
             }
         }
     });

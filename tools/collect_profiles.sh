@@ -13,7 +13,7 @@ REPO=$PWD
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-B="python3 $REPO/bench.py --no-live-traffic --full-line --full-record /tmp/bench_full_prof.json --shape $SHAPE --precision $PREC --no-cpu --no-f64 --no-netflix --no-rows $EXTRA"
+B="python3 $REPO/bench.py --no-live-traffic --full-line --full-record /tmp/bench_full_prof.json --shape $SHAPE --precision $PREC --no-cpu --no-cli --no-f64 --no-netflix --no-rows $EXTRA"
 declare -A PMC=( [fetch]="FETCH_SIZE" [write]="WRITE_SIZE" [l2]="TCC_HIT_sum TCC_MISS_sum" [lds]="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES"
                  [occ]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
                  [mix]="SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" )
