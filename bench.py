@@ -395,8 +395,10 @@ def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name
     args, torch, dist, rank, N = job.args, job.torch, job.dist, job.rank, job.N
     first, total = shard
     p = pcr.Parameter(k=r, precision=prec, device=job.device, do_predict=0, maxiter=1, **{"lambda": lam})
+    t_create = time.perf_counter()
     with pcr.tuned(**({"count_rows": 1} if count_rows else {})):
         s = pcr.Solver(ds, p, rank, N, shard=shard)
+    t_create = time.perf_counter() - t_create          # pcr_solver_create(_shard): uploads + the set-up built on the device
     if N > 1:
         if args.comm == "p2p":
             s.comm_init_p2p(shm_name + ("_64" if prec == pcr.PCR_F64 else "_32") + ("c" if count_rows else ""))
@@ -464,7 +466,7 @@ def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name
         s.iterate(steps)
         barrier()
         noev = job.allmax(time.perf_counter() - t1)
-    out = dict(secs=secs, secs_noevents=noev, objs=objs, inner=inner, prof=prof, launches=launches, scope=scope, prof_period=prof_period, cold=cold,
+    out = dict(secs=secs, secs_noevents=noev, create_s=t_create, objs=objs, inner=inner, prof=prof, launches=launches, scope=scope, prof_period=prof_period, cold=cold,
                u_rows=s.counter("ustep_row_gathers") - rows0, rows_by_class=rows_by_class, steps=steps,
                te=(te_err, te_ndcg), tr=(tr_err, tr_ndcg), comm_nranks=comm_n, shard=shard_now)
     s.close()
@@ -696,6 +698,7 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
         # the timed region carries the HIP-event pairs the roofline's durations come from; the same K steps straight after, without them:
         "ms_per_step_noevents": None if not run.get("secs_noevents") else 1e3 * run["secs_noevents"] / steps,
         "profile_overhead_pct": None if not run.get("secs_noevents") else 100.0 * (secs / run["secs_noevents"] - 1.0),
+        "solver_create_s": run.get("create_s"),          # rank 0's pcr_solver_create: off the timed region (the reference's convert(), util.cpp:219-274)
         "dtype": main_p, "scaling": scaling,
         "workload": f"{note}; {total} users x {R.d2} items, {nnz_job} ratings, {n_pairs} ordered pairs; 1 step = 1 outer "
                     f"iteration (V step + U step)",
@@ -845,6 +848,7 @@ def compact_line(full, full_record_path=None):
     line["roofline_phase"] = _phases(g("roofline_phase"))
     line["top_kernels"] = _top_kernels(g("kernels"))
     line["profile_overhead_pct"] = _r(g("profile_overhead_pct"), 3)
+    line["solver_create_s"] = _r(g("solver_create_s"), 3)
     f64 = g("f64")
     if f64:
         # the reference's arithmetic type: the like-for-like leg carries the same blocks as the headline (two numbers per phase)
@@ -867,6 +871,7 @@ def compact_line(full, full_record_path=None):
         rf, nf64, ncb = nf.get("roofline") or {}, nf.get("f64") or {}, nf.get("cpu_baseline") or {}
         line["netflix"] = {"workload": "configs[3] Netflix-shaped 480189 x 17770, 100 M ratings, k=100, 1 GPU",
                            "ms_per_step": _r(nf["ms_per_step"], 6), "value": _r(nf["value"], 7), "steps": nf.get("steps"), "warmup": nf.get("warmup"),
+                           "solver_create_s": _r(nf.get("solver_create_s"), 3),
                            "ndcg10_test": _r(nf.get("ndcg10_test"), 6), "pairwise_error_test": _r(nf.get("pairwise_error_test"), 6),
                            "roofline": {"kernel": rf.get("kernel"), "frac": rf.get("frac"), "avg_launch_us": rf.get("avg_launch_us"),
                                         "traffic_over_algorithmic": rf.get("traffic_over_algorithmic")} if rf else None,
