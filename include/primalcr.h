@@ -84,11 +84,13 @@ const char *pcr_version(void);                                            /* [ho
 /* ------------------------------------------------------------------------- */
 
 /* util.cpp:80-93 initial(): N(0,1) from a default-seeded std::default_random_engine
- * through std::normal_distribution<double>; a fresh engine per call. */
+ * through std::normal_distribution<double>; a fresh engine per call.  The same values bit for bit; above 4 M of them
+ * produced by several host threads (the engine is an LCG: a range of tries starts at a state that modular
+ * exponentiation gives directly, and libstdc++'s polar method takes exactly four draws per try). */
 int pcr_initial(double *X, int64_t n, int64_t k);                         /* [host] */
-/* rows [row0, row0 + nrows) of what pcr_initial(., n, k) would produce, into X (nrows x k): the stream is
- * sequential (libstdc++'s polar normal_distribution consumes a data-dependent number of draws), so the rows before
- * row0 are generated and dropped -- for a rank that holds only its own users' rows of a large U. */
+/* rows [row0, row0 + nrows) of what pcr_initial(., n, k) would produce, into X (nrows x k): where an output lands
+ * depends on how many tries were accepted before it, so the tries before row0 are still evaluated (in parallel, without
+ * their sqrt / log) -- for a rank that holds only its own users' rows of a large U. */
 int pcr_initial_rows(double *X, int64_t n, int64_t k, int64_t row0, int64_t nrows);   /* [host] */
 
 typedef struct pcr_dataset pcr_dataset;   /* training CSR + test CSR, host memory */
@@ -97,7 +99,11 @@ typedef struct pcr_dataset pcr_dataset;   /* training CSR + test CSR, host memor
  * testset_t::load + util.cpp:219-274 convert(): reads <dir>/meta and the rating
  * files it names. */
 int pcr_dataset_load(const char *dir, pcr_dataset **out);                 /* [host] */
-/* the same with `threads` host parser threads (the CLI passes -n; 0 = up to 16) */
+/* the same with `threads` host threads (the CLI passes -n; 0 = up to 16) for every stage: the rating files are mapped, cut at
+ * line boundaries and parsed piece by piece into the CSR's own arrays; a file ordered by (user, item) -- what the reference's
+ * data sets are -- needs no further data movement, any other order goes through a bucketed counting sort; the test set's
+ * rows follow the reference's scan (util.cpp:250-274: the row of the largest user id seen so far, ending at the first
+ * id that is no user). */
 int pcr_dataset_load_mt(const char *dir, int threads, pcr_dataset **out); /* [host] */
 /* Binary side-car of a loaded data set (the reference re-parses the text with fgets/sscanf and re-sorts on
  * every run, util.cpp:6-25, util.h:197-271).  pcr_dataset_save_cache writes the converted CSRs (train + test) to
@@ -177,6 +183,7 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *   count_rows      1 = the U-step kernels count the rows of V they gather (pcr_solver_counter; a diagnostic that
  *                   costs the short-user classes 10-20 %, so off by default)
  *   debug           1 = print launch decisions to stderr
+ *   plan_key64      test hook: 1 = the set-up's (tile, item) sort keys in 64 bits -- the form an item side beyond 2^32 / tiles takes anyway
  *   win16, ustep_win_lds   test hooks: 0 = the forms shards with very long users take anyway -- 32-bit window-cache entries (a user
  *                   of 65536 ratings or more), k_ustep reading the window cache from global memory (a class whose LDS is full) --
  *                   forced on small data so that the fuzz tests cover them

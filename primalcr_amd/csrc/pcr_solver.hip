@@ -149,7 +149,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, ustep_mode = 0, cluster_k = 4, cluster_users = 0, window_cache = 1,
         prepare_merged = -1, pipeline = 1, debug = 0, fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, allreduce_chunks = 0,
-        resort_window = 8, p2p_ll = 16, p2p_timeout_ms = 20000, fault_p2p_skip = 0, fault_p2p_coarse = 0, win16 = 1, ustep_win_lds = 1;
+        resort_window = 8, p2p_ll = 16, p2p_timeout_ms = 20000, fault_p2p_skip = 0, fault_p2p_coarse = 0, win16 = 1, ustep_win_lds = 1, plan_key64 = 0;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -162,7 +162,7 @@ struct Tune {
         resort_window = pcr_tune_int("resort_window", 8); p2p_ll = pcr_tune_int("p2p_ll", 16);
         p2p_timeout_ms = pcr_tune_int("p2p_timeout_ms", 20000); fault_p2p_skip = pcr_tune_int("fault_p2p_skip", 0);
         fault_p2p_coarse = pcr_tune_int("fault_p2p_coarse", 0);
-        win16 = pcr_tune_int("win16", 1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1);
+        win16 = pcr_tune_int("win16", 1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); plan_key64 = pcr_tune_int("plan_key64", 0);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -558,7 +558,7 @@ struct Solver final : pcr_solver {
         plan_tiles(in, P, tile_u);
         const int64_t n = in.nnz;
         const unsigned long long key_span = (unsigned long long)P.ntiles * (unsigned long long)std::max<int64_t>(d2, 1);
-        if (key_span < ((unsigned long long)1 << 32)) RC(build_plan_keys<uint32_t>(in, P, tile_u, cut));
+        if (key_span < ((unsigned long long)1 << 32) && !tune.plan_key64) RC(build_plan_keys<uint32_t>(in, P, tile_u, cut));
         else RC(build_plan_keys<unsigned long long>(in, P, tile_u, cut));
         std::vector<int32_t> trc0;
         plan_chunks(P, n, cut, trc0);

@@ -332,6 +332,7 @@ VARIANTS = [
     {"cluster_users": "64"},                                 # as many clusters as the chip holds (members on every XCD)
     {"resort_window": "0"}, {"resort_window": "2"}, {"resort_window": "64"},   # the sorts' nearly-sorted fast path: off, narrow, widest
     {"spmm_tiles": "2"}, {"spmm_tiles": "4"},                # tiles bound to groups of 4 / 2 XCDs
+    {"plan_key64": "1"}, {"plan_key64": "1", "allreduce_chunks": "3", "spmm_tiles": "16"},   # the device-built plan with 64-bit (tile, item) keys
 ]
 
 
