@@ -748,7 +748,10 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
                 if "f64" in rec:
                     rec["f64"]["speedup_vs_cpu_baseline"] = rec["f64"]["value"] / rec["cpu_baseline"]["value"]
             if cli is not None:
-                rec["cli"] = cli_leg(data_dir, r, lam, **cli)
+                try:
+                    rec["cli"] = cli_leg(data_dir, r, lam, **cli)
+                except Exception as e:               # (a time-out, a missing binary: the leg reports it, the measurement stands)
+                    rec["cli"] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 c = rec["cli"]
                 log("[cli] omp-pmf-train end to end: " + (c.get("error") or
                     f"{c['wall_s']:.2f}s wall (load {c['load_s']:.2f} init {c['init_s']:.2f} create {c['create_s']:.2f} iterations {c['iter_s']:.3f} "
@@ -947,7 +950,11 @@ def spawn_ranks(N):
             for q, k in enumerate(kids):
                 rc = k.poll()
                 if rc is not None and rc != 0 and failed is None:
-                    why = f"killed by signal {-rc} ({signal.Signals(-rc).name})" if rc < 0 else f"exited with code {rc}"
+                    try:
+                        signame = signal.Signals(-rc).name if rc < 0 else ""
+                    except ValueError:
+                        signame = "?"
+                    why = f"killed by signal {-rc} ({signame})" if rc < 0 else f"exited with code {rc}"
                     failed = (q, rc, why)
                     log(f"[bench] rank {q} {why} (pid {k.pid}): stopping the other ranks")
                     for o in kids:
