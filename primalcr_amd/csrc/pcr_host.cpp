@@ -14,9 +14,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <random>
 #include <thread>
@@ -40,6 +42,31 @@ static int guarded(const char* what, F&& body) noexcept {
     catch (const std::exception& e) { try { pcr_set_error(std::string(what) + ": " + e.what()); } catch (...) {} return PCR_ERR_ARG; }
     catch (...) { return PCR_ERR_ARG; }
 }
+// Worker threads of the host data path: `n_workers` std::threads run body(worker index); an exception thrown on a worker (a failed
+// allocation inside a counting sort, say) must not end the process through std::terminate -- the first one is carried back and
+// rethrown on the calling thread, where the entry point's guard turns it into an error code.
+template <class Body>
+static void run_workers(int n_workers, Body&& body) {
+    if (n_workers <= 1) { body(0); return; }
+    std::exception_ptr first;
+    std::mutex mu;
+    auto safe = [&](int w) {
+        try { body(w); }
+        catch (...) { std::lock_guard<std::mutex> lk(mu); if (!first) first = std::current_exception(); }
+    };
+    std::vector<std::thread> th;
+    th.reserve((size_t)n_workers - 1);
+    try {
+        for (int w = 1; w < n_workers; ++w) th.emplace_back(safe, w);
+    } catch (...) {                                        // (thread creation failed: finish with the threads that exist)
+        std::lock_guard<std::mutex> lk(mu);
+        if (!first) first = std::current_exception();
+    }
+    safe(0);
+    for (auto& x : th) x.join();
+    if (first) std::rethrow_exception(first);
+}
+
 static const int64_t kMaxDim = ((int64_t)1 << 31) - 2;             // ids are int32 throughout (the device solver's limit too)
 extern "C" const char* pcr_version(void) { return "primalcr-mi355x 0.1 (gfx950)"; }
 
@@ -124,11 +151,7 @@ void normal_stream(double* X, int64_t first, int64_t count) {
     std::atomic<int> next{0};
     auto run = [&](const std::function<void(int)>& body) {
         next.store(0);
-        std::vector<std::thread> th;
-        auto work = [&]() { for (;;) { const int r = next.fetch_add(1); if (r >= R) break; body(r); } };
-        for (int t = 1; t < T; ++t) th.emplace_back(work);
-        work();
-        for (auto& x : th) x.join();
+        run_workers(T, [&](int) { for (;;) { const int r = next.fetch_add(1); if (r >= R) break; body(r); } });
     };
     // pass 1 needs only which tries are accepted: the distribution's own test (x * x + y * y inside the unit circle, not the origin) on
     // the same two generate_canonical values, without the sqrt / log of an accepted try
@@ -178,9 +201,7 @@ template <class F>
 static void run_pieces(int64_t n, int T, F&& fn) {
     T = (int)std::max<int64_t>(1, std::min<int64_t>(T, n));
     if (T == 1) { fn(0, (int64_t)0, n); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; ++t) th.emplace_back([&, t]() { fn(t, n * t / T, n * (t + 1) / T); });
-    for (auto& x : th) x.join();
+    run_workers(T, [&](int t) { fn(t, n * t / T, n * (t + 1) / T); });
 }
 static int pieces_for(int64_t n, int threads) { return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(threads, 64), n / 65536 + 1)); }
 
@@ -297,12 +318,7 @@ static int build_train_csr(int64_t d1, int64_t d2, int64_t nnz, const int32_t* u
             }
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (int t = 1; t < T; ++t) th.emplace_back(bucket_work);
-        bucket_work();
-        for (auto& x : th) x.join();
-    }
+    run_workers(T, [&](int) { bucket_work(); });
     for (int64_t u = NB * bw; u < d1; ++u) X.index[u] = nnz;              // (none: NB * bw >= d1)
     X.index[d1] = nnz;
     X.item.swap(oi); X.val.swap(ov);
@@ -813,9 +829,7 @@ extern "C" int pcr_dataset_csr(const pcr_dataset* ds, int which, int64_t* index,
 void pcr_parallel_ranges(int64_t n, int nthreads, const std::function<void(int, int64_t, int64_t)>& fn) {
     nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, n / 4096 + 1));
     if (nthreads == 1) { fn(0, 0, n); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < nthreads; ++t) th.emplace_back([&, t]() { fn(t, n * t / nthreads, n * (t + 1) / nthreads); });
-    for (auto& x : th) x.join();
+    run_workers(nthreads, [&](int t) { fn(t, n * t / nthreads, n * (t + 1) / nthreads); });
 }
 int pcr_host_threads() {
     // (the cgroup quota of a container is not visible through hardware_concurrency: cap at 16, the loader's default too)
