@@ -102,3 +102,18 @@ def test_p2p_rendezvous_and_barriers_under_tsan():
     assert "ranks 4: 4 ok, 0 failed" in r.stderr and "ranks 3: 0 ok, 3 failed" in r.stderr and "ranks 3: 0 ok, 2 failed" in r.stderr
     # the target machine's 8 ranks and the control block's 16 (no GPU box lets 8 processes share its one card: NOTES.md, round 5)
     assert "ranks 8: 8 ok, 0 failed" in r.stderr and "ranks 16: 16 ok, 0 failed" in r.stderr
+
+
+@pytest.mark.timeout(300)
+def test_host_data_path_threads_under_tsan():
+    """The multi-threaded loader (pieces, ordered-file adoption, bucketed counting sort, running-maximum test rows), the level builder
+    and the parallel pcr_initial of pcr_host.cpp under ThreadSanitizer: every stage hands its workers disjoint ranges and joins them
+    before the next stage reads."""
+    subprocess.run(["make", "-s", "-C", CSRC, "tsan"], check=True)
+    r = subprocess.run([os.path.join(ROOT, "build_san", "tsan", "host_harness")], capture_output=True, text=True, timeout=240,
+                       env=_env(TSAN_OPTIONS="halt_on_error=0:exitcode=66"))
+    if "FATAL: ThreadSanitizer" in r.stderr and "unexpected memory mapping" in r.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow in this container")
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert "loader, CSR build, levels and initial() behaved" in r.stderr
