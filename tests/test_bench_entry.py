@@ -143,6 +143,52 @@ def test_five_ranks_on_one_gpu_through_the_bench_launcher():
     assert recs[-1]["obj"] == pytest.approx(line["objective"], rel=2e-5)
 
 
+def run_bench_under_torchrun(nproc, *args, timeout=600):
+    """The driver's launch for N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ... (one rank per process; bench.py is one of the ranks and starts nothing itself)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), BENCH, "--gpus", str(nproc), *args], capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+@pytest.mark.timeout(300)
+def test_under_the_drivers_launcher_a_job_without_gpus_says_so():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: test_two_ranks_under_the_drivers_launcher runs the job itself")
+    p = run_bench_under_torchrun(2, "--steps", "1", "--warmup", "0", "--no-cpu")
+    assert p.returncode != 0
+    assert "[rank 0]" in p.stderr and "[rank 1]" in p.stderr and "no GPU visible" in p.stderr and "starting 2 ranks" not in p.stderr
+    errs = [json.loads(l) for l in p.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(errs) == 1 and errs[0]["value"] is None and "no GPU visible" in errs[0]["error"]        # rank 0's line, nobody else's
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_ranks_under_the_drivers_launcher():
+    """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` -- how the driver starts the N > 1 points of the
+    scaling curve: bench.py is one of the ranks (RANK / WORLD_SIZE from the launcher), rank 0 prints the one line.  Two ranks on the
+    one GPU through the peer-to-peer exchange; the line equals the one bench.py's own launcher gives for the same job."""
+    common = ("--comm", "p2p", "--devices", "0,0", "--rendezvous", "gloo", "--steps", "2", "--warmup", "1", "--users", "800", "--nnz", "100000",
+              "--no-cpu", "--no-f64", "--no-rows")
+    a = run_bench_under_torchrun(2, *common)
+    assert a.returncode == 0, a.stderr[-3000:]
+    assert "starting 2 ranks" not in a.stderr
+    la = json.loads([l for l in a.stdout.strip().split("\n") if l.startswith("{")][-1])
+    b = run_bench("--gpus", "2", *common)
+    assert b.returncode == 0, b.stderr[-3000:]
+    lb = json.loads(b.stdout.strip().split("\n")[-1])
+    for line in (la, lb):
+        assert "error" not in line and line["n_gpus"] == 2 and line["comm_nranks"] == 2 and line["shards"] == [[0, 800, 100000], [800, 800, 100000]]
+    assert la["objective"] == lb["objective"] and la["ndcg10_test"] == lb["ndcg10_test"] and la["inner_per_step"] == lb["inner_per_step"]
+
+
 def _two_devices():
     try:
         import torch
