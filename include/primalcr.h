@@ -204,6 +204,11 @@ int pcr_tune(const char *key, const char *value);                          /* [h
 
 typedef struct pcr_solver pcr_solver;
 
+/* Optional: initialise the HIP runtime for `device` and load the library's code object now (otherwise the first
+ * pcr_solver_create does both, ~0.2-0.3 s).  Thread-safe with the [host] functions: a host application can call it on a
+ * second thread while it parses its input (omp-pmf-train does: the reference has nothing to overlap, pmf-train.cpp:247-266). */
+int pcr_device_warmup(int device);                                         /* [device] */
+
 /* Upload this rank's user shard (rank 0 of 1 = everything) and allocate the
  * device state.  Replaces convert(R), convert(T) at pcrpp.cpp:850-851. */
 int pcr_solver_create(const pcr_dataset *ds, const pcr_params *p, int rank, int nranks,

@@ -90,8 +90,14 @@ static void snap_log(void* vctx, const char* line) {
     }
 }
 
+// the thread that brings the HIP runtime up while main() parses the input (one-GPU runs): joined before any way out of the process
+static std::thread g_warm;
+static void join_warm() { if (g_warm.joinable()) g_warm.join(); }
+
 static void die(const char* what) {
-    fprintf(stderr, "%s: %s\n", what, pcr_last_error());
+    const std::string msg = pcr_last_error();
+    join_warm();
+    fprintf(stderr, "%s: %s\n", what, msg.c_str());
     exit(1);
 }
 
@@ -393,6 +399,12 @@ int main(int argc, char** argv) {
     if (!fp) { fprintf(stderr, "can't open output file %s\n", model.c_str()); return 1; }
     fclose(fp);
 
+    // One GPU: the HIP runtime and the library's code object come up on a second thread while this one parses the ratings and draws
+    // the initial factors (with --gpus N nothing may touch a GPU before the workers are forked).  Its result does not matter here:
+    // pcr_solver_create reports a missing device itself.
+    std::thread& warm = g_warm;
+    if (gpus == 1) warm = std::thread([dev = devices.empty() ? param.device : devices[0]]() { (void)pcr_device_warmup(dev); });
+    struct Joiner { ~Joiner() { join_warm(); } } join_at_return;
     pcr_dataset* ds = nullptr;
     (void)lap();
     if ((cache.empty() ? pcr_dataset_load_mt(input.c_str(), param.threads, &ds)
@@ -443,6 +455,7 @@ int main(int argc, char** argv) {
     }
     auto t0 = std::chrono::steady_clock::now();
     (void)lap();
+    if (warm.joinable()) warm.join();
     pcr_solver* s = nullptr;
     if (!devices.empty()) param.device = devices[0];
     if (pcr_solver_create(ds, &param, 0, 1, &s) != PCR_OK) { fprintf(stderr, "solver: %s\n", pcr_last_error()); return 1; }

@@ -2097,6 +2097,22 @@ int pcr_solver_create_shard(const pcr_dataset* ds_local, const pcr_params* p, in
 }
 void pcr_solver_destroy(pcr_solver* s) { delete s; }
 
+// Initialise the HIP runtime for `device` and load this library's code object (the first launch of any of its kernels does):
+// a few tenths of a second that a host application can spend on another thread while it is still parsing its input.
+int pcr_device_warmup(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { pcr_set_error("no HIP device available"); return PCR_ERR_DEVICE; }
+    if (device < 0 || device >= ndev) { pcr_set_error("device ordinal out of range"); return PCR_ERR_ARG; }
+    return abi_guard("pcr_device_warmup", [&]() -> int {
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipFree(nullptr));
+        hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
+        return PCR_OK;
+    });
+}
+
 int pcr_comm_unique_id(void* id128) {
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
     if (!id128) { pcr_set_error("null id"); return PCR_ERR_ARG; }

@@ -27,6 +27,7 @@ int pcr_solver_create_shard(const pcr_dataset* ds, const pcr_params* p, int rank
     return absent();
 }
 void pcr_solver_destroy(pcr_solver*) {}
+int pcr_device_warmup(int) { return absent(); }
 int pcr_comm_unique_id(void* id128) { if (!id128) { pcr_set_error("null id"); return PCR_ERR_ARG; } return absent(); }
 #define NO_SOLVER(name, ...) int name(__VA_ARGS__) { pcr_set_error("null solver"); return PCR_ERR_ARG; }
 NO_SOLVER(pcr_solver_comm_init, pcr_solver*, const void*)
