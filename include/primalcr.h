@@ -134,6 +134,14 @@ int pcr_dataset_csr(const pcr_dataset *ds, int which, int64_t *index, int64_t *i
  * PrimalCR++, pcrpp.cpp:41; raw doubles for PrimalCR, pcr.cpp:23) */
 int64_t pcr_dataset_count_pairs(const pcr_dataset *ds, int solver_type);   /* [host] */
 
+/* A rating file on its own (omp-pmf-predict's test file: pmf-predict.cpp:52-55 reads "user item rating" triples until fscanf
+ * fails, no meta file).  count: the file's non-blank lines.  read: at most n entries by `threads` host threads (0 = up to 16),
+ * ids 0-based, val may be NULL; the input ends at the first malformed entry: *n_read entries stand before it (the reference's
+ * loop never ends on such a line: it tests `!= EOF`, pmf-predict.cpp:56). */
+int pcr_rating_file_count(const char *path, int64_t *n);                   /* [host] */
+int pcr_rating_file_read(const char *path, int threads, int64_t n, int32_t *user, int32_t *item, double *val,
+                         int64_t *n_read);                                 /* [host] */
+
 /* pmf-train.cpp:297-310 + util.cpp:30-51 save_mat_t(U^T,false); save_mat_t(V^T,false):
  * "long d1, long k, d1*k doubles, long d2, long k, d2*k doubles" */
 int pcr_model_save(const char *path, const double *U, int64_t d1, const double *V, int64_t d2, int64_t k);

@@ -617,46 +617,93 @@ static int64_t nonblank_lines(const char* base, size_t a, size_t b) {
     return n + (content ? 1 : 0);
 }
 
-static int parse_ratings(const std::string& path, int64_t nnz, pcr_vec<int32_t>& user,
-                         pcr_vec<int32_t>& item, pcr_vec<double>& val, int threads) {
-    if (nnz < 0) { pcr_set_error(path + ": a negative rating count in meta"); return PCR_ERR_IO; }
+// a rating file opened, cut into pieces at line boundaries, the entries before every piece counted
+struct ScannedFile {
     TextFile tf;
-    int rc = tf.open(path);
+    int T = 1;
+    std::vector<size_t> cut;
+    std::vector<int64_t> first;                            // first[t] = entries before piece t; first[T] = entries of the file
+};
+static int scan_ratings(const std::string& path, int threads, ScannedFile& sf) {
+    int rc = sf.tf.open(path);
     if (rc != PCR_OK) return rc;
-    const char* base = tf.p;
-    const size_t len = tf.len;
+    const char* base = sf.tf.p;
+    const size_t len = sf.tf.len;
     int T = std::max(1, std::min(threads, 64));
     if (len < (size_t)1 << 20) T = 1;
-    std::vector<size_t> cut(T + 1, len);
-    cut[0] = 0;
+    sf.T = T;
+    sf.cut.assign((size_t)T + 1, len);
+    sf.cut[0] = 0;
     for (int t = 1; t < T; ++t) {
-        size_t c = std::max(cut[t - 1], len * t / T);
+        size_t c = std::max(sf.cut[t - 1], len * t / T);
         while (c < len && base[c] != '\n') ++c;
-        cut[t] = c < len ? c + 1 : len;
+        sf.cut[t] = c < len ? c + 1 : len;
     }
-    std::vector<int64_t> first(T + 1, 0);
-    {
-        std::vector<int64_t> cnt(T, 0);
-        run_pieces(T, T, [&](int, int64_t lo, int64_t hi) { for (int64_t t = lo; t < hi; ++t) cnt[t] = nonblank_lines(base, cut[t], cut[t + 1]); });
-        for (int t = 0; t < T; ++t) first[t + 1] = first[t] + cnt[t];
-    }
-    if (first[T] < nnz) {
-        pcr_set_error(path + ": expected " + std::to_string(nnz) + " ratings, found " + std::to_string(first[T]));
-        return PCR_ERR_IO;
-    }
-    user.resize((size_t)nnz); item.resize((size_t)nnz); val.resize((size_t)nnz);          // (only now: meta may promise any number)
+    sf.first.assign((size_t)T + 1, 0);
+    std::vector<int64_t> cnt(T, 0);
+    run_pieces(T, T, [&](int, int64_t lo, int64_t hi) { for (int64_t t = lo; t < hi; ++t) cnt[t] = nonblank_lines(base, sf.cut[t], sf.cut[t + 1]); });
+    for (int t = 0; t < T; ++t) sf.first[t + 1] = sf.first[t] + cnt[t];
+    return PCR_OK;
+}
+// entries [0, n) of a scanned file into user / item / val (val may be null); returns the index of the first malformed entry, or -1
+static int64_t parse_scanned(const ScannedFile& sf, int64_t n, int32_t* user, int32_t* item, double* val) {
+    const int T = sf.T;
+    const char* base = sf.tf.p;
     std::vector<int64_t> bad(T, -1);
     run_pieces(T, T, [&](int, int64_t lo, int64_t hi) {
         for (int64_t t = lo; t < hi; ++t) {
-            const char* p = base + cut[t];
-            const char* end = base + cut[t + 1];
-            for (int64_t z = first[t]; z < first[t + 1] && z < nnz; ++z)
-                if (!parse_one(p, end, user[z], item[z], val[z])) { bad[t] = z; break; }
+            const char* p = base + sf.cut[t];
+            const char* end = base + sf.cut[t + 1];
+            double dummy;
+            for (int64_t z = sf.first[t]; z < sf.first[t + 1] && z < n; ++z)
+                if (!parse_one(p, end, user[z], item[z], val ? val[z] : dummy)) { bad[t] = z; break; }
         }
     });
-    for (int t = 0; t < T; ++t)
-        if (bad[t] >= 0) { pcr_set_error(path + ": malformed rating line " + std::to_string(bad[t] + 1)); return PCR_ERR_IO; }
+    for (int t = 0; t < T; ++t) if (bad[t] >= 0) return bad[t];
+    return -1;
+}
+
+static int parse_ratings(const std::string& path, int64_t nnz, pcr_vec<int32_t>& user,
+                         pcr_vec<int32_t>& item, pcr_vec<double>& val, int threads) {
+    if (nnz < 0) { pcr_set_error(path + ": a negative rating count in meta"); return PCR_ERR_IO; }
+    ScannedFile sf;
+    int rc = scan_ratings(path, threads, sf);
+    if (rc != PCR_OK) return rc;
+    if (sf.first[sf.T] < nnz) {
+        pcr_set_error(path + ": expected " + std::to_string(nnz) + " ratings, found " + std::to_string(sf.first[sf.T]));
+        return PCR_ERR_IO;
+    }
+    user.resize((size_t)nnz); item.resize((size_t)nnz); val.resize((size_t)nnz);          // (only now: meta may promise any number)
+    const int64_t bad = parse_scanned(sf, nnz, user.data(), item.data(), val.data());
+    if (bad >= 0) { pcr_set_error(path + ": malformed rating line " + std::to_string(bad + 1)); return PCR_ERR_IO; }
     return PCR_OK;
+}
+
+// A rating file without a meta file beside it (pmf-predict.cpp:52-55 reads "user item rating" triples until fscanf fails):
+// count = the file's non-blank lines; read = at most n entries by `threads` host threads, 0-based ids, ending at the first malformed
+// entry (*n_read entries stand before it; the reference's `!= EOF` loop never ends there).
+extern "C" int pcr_rating_file_count(const char* path, int64_t* n) {
+    if (!path || !n) { pcr_set_error("pcr_rating_file_count: bad argument"); return PCR_ERR_ARG; }
+    return guarded("pcr_rating_file_count", [&]() -> int {
+        ScannedFile sf;
+        int rc = scan_ratings(path, pcr_host_threads(), sf);
+        if (rc != PCR_OK) return rc;
+        *n = sf.first[sf.T];
+        return PCR_OK;
+    });
+}
+extern "C" int pcr_rating_file_read(const char* path, int threads, int64_t n, int32_t* user, int32_t* item, double* val, int64_t* n_read) {
+    if (!path || n < 0 || !n_read || (n > 0 && (!user || !item))) { pcr_set_error("pcr_rating_file_read: bad argument"); return PCR_ERR_ARG; }
+    if (threads <= 0) threads = pcr_host_threads();
+    return guarded("pcr_rating_file_read", [&]() -> int {
+        ScannedFile sf;
+        int rc = scan_ratings(path, threads, sf);
+        if (rc != PCR_OK) return rc;
+        const int64_t m = std::min(n, sf.first[sf.T]);
+        const int64_t bad = parse_scanned(sf, m, user, item, val);
+        *n_read = bad >= 0 ? bad : m;
+        return PCR_OK;
+    });
 }
 
 extern "C" int pcr_dataset_load(const char* dir, pcr_dataset** out) { return pcr_dataset_load_mt(dir, 0, out); }

@@ -2217,20 +2217,40 @@ int pcr_predict(const double* U, int64_t d1, const double* V, int64_t d2, int64_
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { pcr_set_error("no HIP device available"); return PCR_ERR_DEVICE; }
     return abi_guard("pcr_predict", [&]() -> int {
     HIPCHK(hipSetDevice(device));
-    for (int64_t z = 0; z < n; ++z)
-        if (user[z] < 0 || user[z] >= d1 || item[z] < 0 || item[z] >= d2) { pcr_set_error("pair " + std::to_string(z) + " outside the model"); return PCR_ERR_ARG; }
+    {   // ids inside the model (the reference reads out of bounds on a bad line, pmf-predict.cpp:58): checked by the host threads
+        const int nth = pcr_host_threads();
+        std::vector<int64_t> bad((size_t)nth, -1);
+        pcr_parallel_ranges(n, nth, [&](int t, int64_t lo, int64_t hi) {
+            for (int64_t z = lo; z < hi; ++z)
+                if (user[z] < 0 || user[z] >= d1 || item[z] < 0 || item[z] >= d2) { bad[(size_t)t] = z; return; }
+        });
+        int64_t first_bad = -1;
+        for (int64_t x : bad) if (x >= 0 && (first_bad < 0 || x < first_bad)) first_bad = x;
+        if (first_bad >= 0) { pcr_set_error("pair " + std::to_string(first_bad) + " outside the model"); return PCR_ERR_ARG; }
+    }
     Geo geo;
     geo.r = (int)k; geo.ld = ((int)k + 3) & ~3; geo.nchunk = geo.ld / 2; geo.G = std::min(64, host_pow2(geo.nchunk));
-    // the model file holds fp64 factors: score in fp64 like pmf-predict.cpp:58-62
-    std::vector<double> Up((size_t)d1 * geo.ld, 0.0), Vp((size_t)d2 * geo.ld, 0.0);
-    for (int64_t i = 0; i < d1; ++i) for (int64_t j = 0; j < k; ++j) Up[i * geo.ld + j] = U[i * k + j];
-    for (int64_t i = 0; i < d2; ++i) for (int64_t j = 0; j < k; ++j) Vp[i * geo.ld + j] = V[i * k + j];
-    DBuf<double> dU, dV, dP;
+    // the model file holds fp64 factors: score in fp64 like pmf-predict.cpp:58-62.  The matrices go up as they are (slabs of 64 M
+    // values) and are padded to ld on the device; the ids from the caller's arrays.
+    DBuf<double> dU, dV, dP, stage;
     DBuf<int32_t> du, di;
     hipStream_t st = nullptr;
-    RC(dU.upload(Up, st)); RC(dV.upload(Vp, st)); RC(dP.alloc(n));
-    std::vector<int32_t> hu(user, user + n), hi(item, item + n);
-    RC(du.upload(hu, st)); RC(di.upload(hi, st));
+    RC(dU.alloc((size_t)d1 * geo.ld)); RC(dV.alloc((size_t)d2 * geo.ld)); RC(dP.alloc((size_t)n));
+    const int64_t slab_rows = std::max<int64_t>(1, ((int64_t)64 << 20) / std::max<int64_t>(1, k));
+    RC(stage.alloc((size_t)std::min<int64_t>(std::max(d1, d2), slab_rows) * (size_t)k));
+    for (int w = 0; w < 2; ++w) {
+        const double* H = w == 0 ? U : V;
+        double* D = w == 0 ? dU.p : dV.p;
+        const int64_t rows = w == 0 ? d1 : d2;
+        for (int64_t r0 = 0; r0 < rows; r0 += slab_rows) {
+            const int64_t nr = std::min(slab_rows, rows - r0);
+            HIPCHK(hipMemcpyAsync(stage.p, H + r0 * k, (size_t)nr * k * sizeof(double), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((k_mat_in<double>), dim3((unsigned)std::min<int64_t>(1 << 16, cdiv(nr * geo.ld, 256))), dim3(256), 0, st, stage.p, D + r0 * geo.ld, nr, (int)k, geo.ld);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+        }
+    }
+    RC(du.upload_n(user, (size_t)n)); RC(di.upload_n(item, (size_t)n));
     if (n > 0) {
         const int gpb = 256 / geo.G;
         hipLaunchKernelGGL((k_predict<double>), dim3(cdiv(n, gpb)), dim3(256), 0, st, dU.p, dV.p, du.p, di.p, n, geo, dP.p);

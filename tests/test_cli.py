@@ -263,6 +263,39 @@ def test_train_cli_on_the_references_own_rating_files(name, tag, args, tmp_path)
         assert abs(e_ours - e_ref) < 1e-6 and abs(n_ours - n_ref) < 1e-6 * max(1.0, abs(n_ref)), (e_ours, e_ref, n_ours, n_ref)
 
 
+def test_predict_reads_and_writes_like_the_reference_at_size(tmp_path):
+    """omp-pmf-predict parses its test file with the host threads (several pieces above 1 MB) and formats its output in threads:
+    150 000 lines through `--host` must be the reference binary's bytes, and like the reference (one fscanf per line until it
+    fails) a malformed line ends the input: the lines before it are scored, nothing after."""
+    import primalcr_amd as pcr
+    from oracle import oracle_py
+    rng = np.random.default_rng(8)
+    d1, d2, k, n = 5000, 3000, 9, 150_000
+    U, V = rng.normal(size=(d1, k)) * 3, rng.normal(size=(d2, k)) * 3
+    U[7] *= 1e5; V[11] *= 1e-7                                       # large and tiny scores: the fixed-notation formatter's corners
+    pcr.model_save(str(tmp_path / "m.model"), U, V)
+    user, item = rng.integers(0, d1, n), rng.integers(0, d2, n)
+    lines = [f"{u + 1} {i + 1} {1 + (u + i) % 5}" for u, i in zip(user.tolist(), item.tolist())]
+    (tmp_path / "t.ratings").write_text("\n".join(lines) + "\n")
+    assert os.path.getsize(tmp_path / "t.ratings") > (1 << 20)
+    r = run([PREDICT, "--host", "t.ratings", "m.model", "ours.txt"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    ours = open(tmp_path / "ours.txt").read()
+    assert ours.count("\n") == n
+    if os.path.exists(oracle_py.REF_PREDICT):
+        ref = run([oracle_py.REF_PREDICT, "t.ratings", "m.model", "ref.txt"], tmp_path)
+        assert ref.returncode == 0 and open(tmp_path / "ref.txt").read() == ours
+    else:
+        assert ours == "".join("%f\n" % float(U[u] @ V[i]) for u, i in zip(user, item))
+    bad = list(lines)
+    bad[100_003] = "17 oops 3"
+    (tmp_path / "bad.ratings").write_text("\n".join(bad) + "\n")
+    r = run([PREDICT, "--host", "bad.ratings", "m.model", "cut.txt"], tmp_path)
+    assert r.returncode == 0 and open(tmp_path / "cut.txt").read() == "".join(ours.splitlines(True)[:100_003])
+    # (not compared with the reference here: its loop tests `fscanf(...) != EOF`, pmf-predict.cpp:56, so a malformed token, which
+    # fscanf neither consumes nor reports as EOF, makes it print the previous pair's score for ever)
+
+
 def test_gpus_option_bootstrap_without_a_gpu(tmp_path):
     """--gpus N forks one worker per GPU before anything touches a GPU and the parent only waits.  On a machine without a
     GPU every worker must fail loudly in pcr_solver_create, the parent must reap them all and exit 1 -- and bad option
