@@ -915,23 +915,26 @@ int pcr_build_levels(const PcrCsr& X, int64_t u0, int64_t u1, int solver_type, P
     const double* val = X.val.data();
     pcr_parallel_ranges(nu, nth, [&](int t, int64_t lo, int64_t hi) {
         std::vector<double> uniq, keys;
+        std::vector<long> ikey;
         for (int64_t ui = lo; ui < hi; ++ui) {
             const int64_t a = X.index[u0 + ui], b = X.index[u0 + ui + 1];
             if (b == a) { out.run_ofs[ui + 1] = 1; continue; }
             long kmin = LONG_MAX, kmax = LONG_MIN;
             bool ints = true;
+            ikey.resize((size_t)(b - a));                          // the rounded keys once (the user's ratings stay in cache)
             for (int64_t z = a; z < b; ++z) {
                 const double v = val[z];
                 const long k = fast_lround(v);
+                ikey[(size_t)(z - a)] = k;
                 kmin = std::min(kmin, k); kmax = std::max(kmax, k);
                 ints = ints && (double)k == v;
             }
             if (!ints) allint[t] = 0;
             if ((pp || ints) && kmax - kmin < 64 && kmin > LONG_MIN / 2 && kmax < LONG_MAX / 2) {
                 uint64_t m = 0;
-                for (int64_t z = a; z < b; ++z) m |= (uint64_t)1 << (fast_lround(val[z]) - kmin);
+                for (int64_t z = a; z < b; ++z) m |= (uint64_t)1 << (ikey[(size_t)(z - a)] - kmin);
                 for (int64_t z = a; z < b; ++z) {
-                    const int sh = (int)(fast_lround(val[z]) - kmin);
+                    const int sh = (int)(ikey[(size_t)(z - a)] - kmin);
                     out.level[z - z0] = (uint16_t)__builtin_popcountll(m & (((uint64_t)1 << sh) - 1));
                 }
                 const int T = __builtin_popcountll(m);
