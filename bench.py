@@ -1063,6 +1063,11 @@ def main():
         pcr.use_library(args.lib)
     for kv in args.tune:
         pcr.tune(*kv.split("=", 1))
+    if args.devices and len(set(args.devices.split(","))) < len(args.devices.split(",")) and not any(kv.startswith("lanes=") for kv in args.tune):
+        # ranks that share a device (a rehearsal on fewer GPUs) share its hardware queues: one stream per rank, no lane probing
+        pcr.tune("lanes", "1")
+        if rank == 0:
+            log("[bench] several ranks share a device: one stream per rank (--tune lanes=1)")
     job = Job(args, torch, dist, rank, N, device)
     r, lam = args.rank_k or (200 if args.shape == "yahoo" else 100), args.lam
     precisions = (args.precision,) if (args.no_f64 or args.precision == "f64") else ("f32", "f64")

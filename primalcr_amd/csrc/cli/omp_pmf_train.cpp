@@ -93,6 +93,7 @@ static void snap_log(void* vctx, const char* line) {
 // the thread that brings the HIP runtime up while main() parses the input (one-GPU runs): joined before any way out of the process
 static std::thread g_warm;
 static void join_warm() { if (g_warm.joinable()) g_warm.join(); }
+static bool g_lanes_given = false;                                        // --tune lanes=... on the command line
 
 static void die(const char* what) {
     const std::string msg = pcr_last_error();
@@ -262,6 +263,11 @@ static int train_multi(const pcr_dataset* ds, const pcr_params& param, int gpus,
     double* Ush = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(hdr + 1) + 63) & ~(uintptr_t)63);
     double* Vsh = Ush + nU;
     fflush(stdout); fflush(stderr);
+    bool shared_device = false;
+    for (size_t a = 0; a < devices.size(); ++a)
+        for (size_t b = a + 1; b < devices.size(); ++b) shared_device = shared_device || devices[a] == devices[b];
+    const bool pcr_tune_is_default_lanes = !g_lanes_given;
+    if (shared_device && pcr_tune_is_default_lanes) fprintf(stderr, "omp-pmf-train: several ranks share a device: one stream per rank (--tune lanes=1)\n");
     std::vector<pid_t> kids;
     struct sigaction sa_new, sa_int, sa_term;
     memset(&sa_new, 0, sizeof sa_new);
@@ -276,6 +282,11 @@ static int train_multi(const pcr_dataset* ds, const pcr_params& param, int gpus,
             signal(SIGINT, SIG_DFL); signal(SIGTERM, SIG_DFL);
             pcr_params p = param;
             p.device = devices.empty() ? q : devices[q];
+            // Ranks that share a device (a rehearsal of the N-rank path on fewer GPUs) share its hardware queues too: every rank
+            // keeps to its solver's stream instead of probing and using side lanes of its own (pcr_tune "lanes" = 1, unless
+            // the command line says otherwise) -- five processes that each claim half a dozen queues, with spinning probe kernels
+            // measuring each other, is what the one-rank-per-GPU layout never sees.
+            if (shared_device && pcr_tune_is_default_lanes) (void)pcr_tune("lanes", "1");
             const int rc = worker(ds, p, q, gpus, comm_kind, hdr, Ush, Vsh, U, V, d1, d2, snapshot_every, model);
             fflush(stdout); fflush(stderr);
             _exit(rc);
@@ -359,6 +370,7 @@ int main(int argc, char** argv) {
         if (!strcmp(argv[i - 1], "--tune")) {
             std::string kv = argv[i];
             const size_t eq = kv.find('=');
+            if (kv.compare(0, 6, "lanes=") == 0) g_lanes_given = true;
             if (eq == std::string::npos || pcr_tune(kv.substr(0, eq).c_str(), kv.substr(eq + 1).c_str()) != PCR_OK) {
                 fprintf(stderr, "--tune %s: %s\n", argv[i], eq == std::string::npos ? "expected key=value" : pcr_last_error());
                 return 1;

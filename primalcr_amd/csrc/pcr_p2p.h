@@ -341,7 +341,7 @@ struct P2PComm {
     // in-place sum of buf[0, n) over the ranks; stream-ordered on st from the caller's point of view
     template <typename X>
     bool allreduce(X* buf, size_t n, hipStream_t st, bool scalars = false) {
-        if (ll_err && *ll_err) return fail("a device-driven exchange timed out waiting for a peer rank");
+        if (ll_err && *ll_err) return fail(timeout_text());
         if (ll_max_bytes && n > 0 && (scalars ? (sizeof(X) == 8 && n <= LL_SCAL) : (sizeof(X) == ll_elt && n <= ll_elems))) {
             // device-driven: one kernel, stream-ordered, nothing on the host
             const int set = scalars ? 1 : 0;
@@ -392,7 +392,12 @@ struct P2PComm {
 
     void abort_peers() { if (ctl) ctl->error.store(1); }
     // has a device-driven exchange of this rank run into its deadline (or into a peer's poison)?  (read after a stream synchronisation)
-    bool exchange_failed() { if (ll_err && *ll_err) { fail("a device-driven exchange timed out waiting for a peer rank"); return true; } return false; }
+    bool exchange_failed() { if (ll_err && *ll_err) { fail(timeout_text()); return true; } return false; }
+    // (how far this rank had come says which exchange the job stalled in: the counts are the same on every rank of a healthy job)
+    std::string timeout_text() const {
+        return "a device-driven exchange timed out waiting for a peer rank (rank " + std::to_string(rank) + " of " + std::to_string(nranks) + " had launched " +
+               std::to_string(ll_seq[0]) + " vector and " + std::to_string(ll_seq[1]) + " scalar exchanges; deadline " + std::to_string((int)(ll_timeout_s * 1e3)) + " ms)";
+    }
 
     // Closing rendezvous: the last all-reduce launched its reduce / gather kernel asynchronously after its last host barrier, so a
     // peer's kernel may still be reading this rank's buffers when this rank gets here.  Drain the device, then meet the peers
