@@ -177,7 +177,7 @@ struct Solver final : pcr_solver {
     hipStream_t st = nullptr;
     static constexpr int NSIDE = 12;
     hipStream_t side[NSIDE] = {};                                 // length bins run concurrently
-    hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {};
+    hipEvent_t ev_fork = nullptr;
     hipStream_t hi = nullptr;                                     // high priority: the cluster class of the U step
     hipEvent_t ev_hi = nullptr;
     // Streams that really run side by side.  HIP multiplexes its streams onto a few hardware queues (4 by default) in
@@ -318,7 +318,7 @@ struct Solver final : pcr_solver {
         if (h_scal) (void)hipHostFree(h_scal);
         if (h_uobj) (void)hipHostFree(h_uobj);
         if (h_counters) (void)hipHostFree(h_counters);
-        for (int i = 0; i < NSIDE; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
+        for (int i = 0; i < NSIDE; ++i) if (side[i]) (void)hipStreamDestroy(side[i]);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (int i = 0; i < MAXLANE; ++i) if (ev_lane[i]) (void)hipEventDestroy(ev_lane[i]);
         if (hi) (void)hipStreamDestroy(hi);
@@ -428,10 +428,13 @@ struct Solver final : pcr_solver {
         lane[0] = st; nlane = 1;
         if (tune.lanes == 1) return PCR_OK;                                                      // pcr_tune("lanes", "1"): no concurrency
         bool dummy = false;
+        auto ensure_side = [&](int c) -> int { if (!side[c]) HIPCHK(hipStreamCreateWithFlags(&side[c], hipStreamNonBlocking)); return PCR_OK; };
+        RC(ensure_side(0));
         RC(shares_queue(st, side[0], ticks / 30, ev_lane[0], &dummy));                          // warm up: first launches are slow
         const int want = tune.lanes > 0 ? std::min(MAXLANE, tune.lanes) : 4;
         for (int c = 0; c < NSIDE && nlane < want; ++c) {
             bool clash = false;
+            RC(ensure_side(c));
             for (int l = 0; l < nlane && !clash; ++l) RC(shares_queue(lane[l], side[c], ticks, ev_lane[0], &clash));
             if (!clash) lane[nlane++] = side[c];
             if (tune.debug) fprintf(stderr, "[pcr] side stream %d %s\n", c, clash ? "shares a queue with a lane" : "is a lane");
@@ -635,6 +638,7 @@ struct Solver final : pcr_solver {
     // job with d1_total users (pcr_solver_create_shard); else the whole data set, partitioned here by pcr_partition_users
     int init(const pcr_dataset* ds, const pcr_params* p, int rank_, int nranks_, int64_t shard_first = -1, int64_t d1_total = 0) {
         prm = *p; rank = rank_; nranks = nranks_;
+        const auto t_init = std::chrono::steady_clock::now();
         tune.read();
         if (prm.cg_max_iter == 0) prm.cg_max_iter = 10;      // zero-filled extension fields = the reference's constants
         if (prm.cg_tol == 0.0) prm.cg_tol = 0.01;
@@ -646,9 +650,11 @@ struct Solver final : pcr_solver {
         }
         if (prm.device < 0 || prm.device >= ndev) { pcr_set_error("device ordinal out of range"); return PCR_ERR_ARG; }
         HIPCHK(hipSetDevice(prm.device));
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, prm.device));
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        {   // (one attribute, not hipGetDeviceProperties: that call fills a hundred fields, some of them through slow queries)
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, prm.device) != hipSuccess) cus = 0;
+            ncu = cus > 0 ? cus : 256;
+        }
         HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_hi, hipEventDisableTiming));
@@ -657,10 +663,8 @@ struct Solver final : pcr_solver {
             HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
             HIPCHK(hipStreamCreateWithPriority(&hi, hipStreamNonBlocking, greatest));
         }
-        for (int i = 0; i < NSIDE; ++i) {
-            HIPCHK(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
-        }
+        // (the side streams are created when pick_lanes probes them: a solver that needs three lanes creates four or five streams,
+        // not twelve -- a stream is 4-5 ms of set-up and a hardware queue of the device)
 
         const PcrCsr& X = ds->train;
         d1 = X.d1; d2 = X.d2; tnnz_file = ds->tnnz_file;
@@ -689,6 +693,7 @@ struct Solver final : pcr_solver {
         const int64_t nu = n_users;
 
         // (pcr_tune("debug"): wall time of the set-up phases)
+        if (tune.debug) fprintf(stderr, "[pcr] set-up: %-28s %8.1f ms\n", "device, streams, events", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_init).count());
         auto t_phase = std::chrono::steady_clock::now();
         auto phase = [&](const char* what) {
             if (!tune.debug) return;
