@@ -203,9 +203,9 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *                   answers and fail with PCR_ERR_COMM; nobody may hang or consume garbage)
  *   fault_p2p_coarse   test hook: this rank behaves as if fine-grained memory were unavailable (all ranks must fall back to the
  *                   host-synchronised exchange together)
- * Stream layout: the solver creates its stream, a high-priority stream and its side streams, then MEASURES (a few ms at
- * creation; pcr_tune("debug") prints it) which side streams share a hardware queue with the solver's stream (they are not used
- * as lanes) and which lanes share its command-processor PIPE (queues on one pipe share workgroup dispatch and throttle each
+ * Stream layout: the solver creates its stream and a high-priority stream, then creates side streams one by one and MEASURES
+ * (a few ms each at creation; pcr_tune("debug") prints it) which of them share a hardware queue with the solver's stream (they are
+ * not used as lanes; it stops at three lanes, usually after four or five streams) and which lanes share its command-processor PIPE (queues on one pipe share workgroup dispatch and throttle each
  * other): such a lane is placed last, and a high-priority stream that landed on the solver's pipe is replaced.  So the layout
  * no longer depends on how many streams the host application created before the solver; results never did. */
 int pcr_tune(const char *key, const char *value);                          /* [host] */
