@@ -53,6 +53,7 @@ int pcr_build_levels(const PcrCsr& X, int64_t u0, int64_t u1, int solver_type, P
 
 // host set-up helpers: fn(thread, lo, hi) over contiguous pieces of [0, n); the thread count set-up work uses
 void pcr_parallel_ranges(int64_t n, int nthreads, const std::function<void(int, int64_t, int64_t)>& fn);
+void pcr_parallel_tasks(int ntasks, int nthreads, const std::function<void(int)>& fn);
 int pcr_host_threads();
 
 void pcr_set_error(const std::string& msg);
