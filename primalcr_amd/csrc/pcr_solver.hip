@@ -23,6 +23,7 @@
 #include "pcr_host.h"
 #include "pcr_kernels.h"
 #include "pcr_gram.h"
+#include "pcr_newton.h"
 #include "pcr_p2p.h"
 
 #define HIPCHK(expr)                                                                           \
@@ -149,7 +150,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, ustep_mode = 0, cluster_k = 4, cluster_users = 0, window_cache = 1,
         prepare_merged = -1, pipeline = 1, debug = 0, fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, allreduce_chunks = 0,
-        resort_window = 8, p2p_ll = 16, p2p_timeout_ms = 20000, fault_p2p_skip = 0, fault_p2p_coarse = 0, win16 = 1, ustep_win_lds = 1, plan_key64 = 0;
+        resort_window = 8, p2p_ll = 16, p2p_timeout_ms = 20000, fault_p2p_skip = 0, fault_p2p_coarse = 0, win16 = 1, ustep_win_lds = 1, plan_key64 = 0, ustep_newton = 0;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -162,7 +163,7 @@ struct Tune {
         resort_window = pcr_tune_int("resort_window", 8); p2p_ll = pcr_tune_int("p2p_ll", 16);
         p2p_timeout_ms = pcr_tune_int("p2p_timeout_ms", 20000); fault_p2p_skip = pcr_tune_int("fault_p2p_skip", 0);
         fault_p2p_coarse = pcr_tune_int("fault_p2p_coarse", 0);
-        win16 = pcr_tune_int("win16", 1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); plan_key64 = pcr_tune_int("plan_key64", 0);
+        win16 = pcr_tune_int("win16", 1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); plan_key64 = pcr_tune_int("plan_key64", 0); ustep_newton = pcr_tune_int("ustep_newton", 0);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -203,6 +204,12 @@ struct Solver final : pcr_solver {
     DBuf<double> d_objr;
     DBuf<int32_t> d_item, d_c2r, d_runstart, d_sitem, d_cuser, d_crow, d_ruser, d_slot_base, d_item_slot, d_chunk_ptr, d_slot_id;
     DBuf<int2> d_blk_chunks;                      // k_spmm: first chunk and chunk count of every workgroup
+    // pcr_tune("ustep_newton"): the users k_unewton covers, its directions (nu x ld, NaN = none), its prefix tables
+    DBuf<int32_t> d_newton_users;
+    DBuf<double> d_dir;
+    DBuf<char> d_newton_scratch;
+    int newton_n = 0, newton_cap = 0, newton_rs = 0, newton_grid = 0;
+    size_t newton_stride = 0;
     DBuf<int32_t> d_cuf;                          // k_spmm: user id | new-item flag per CSC entry
     int spmm_blocks = 0, spmm_tiles = 1;
     // Item ranges of the SpMM (N > 1, wide item tables): k_spmm / k_spmm_fin run range by range and the all-reduce of a finished
@@ -907,6 +914,25 @@ struct Solver final : pcr_solver {
             }
         }
         for (auto& b : ubins) RC(b.d_users.upload(b.users, st));
+        if (tune.ustep_newton && geo.ld <= NEWTON_MAX_LD) {
+            // the exact-Newton mode (pcr_newton.h): users of 1 .. NEWTON_MAX_N ratings get their direction from the explicit Hessian
+            std::vector<int32_t> nus_list;
+            for (int64_t q = 0; q < nu; ++q) {
+                const int32_t u = by_len[(size_t)q];
+                const int64_t len = uptr[u + 1] - uptr[u];
+                if (len >= 1 && len <= NEWTON_MAX_N) { nus_list.push_back(u); newton_cap = std::max<int>(newton_cap, (int)len); }
+            }
+            newton_n = (int)nus_list.size();
+            newton_rs = lv.max_levels + 2;
+            RC(d_newton_users.upload(nus_list, st));
+            RC(d_dir.alloc((size_t)std::max<int64_t>(nu, 1) * geo.ld));
+            const int ldp = (geo.ld + 15) & ~15;
+            newton_grid = std::max(1, std::min(newton_n, 2 * ncu));
+            newton_stride = (((size_t)newton_cap + 1) * ldp * sizeof(double) + 255) & ~(size_t)255;
+            RC(d_newton_scratch.alloc(newton_stride * (size_t)newton_grid));
+            HIPCHK(hipFuncSetAttribute((const void*)k_unewton<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (tune.debug) fprintf(stderr, "[pcr] exact-Newton U step: %d of %lld users through the explicit Hessian (<= %d ratings)\n", newton_n, (long long)nu, NEWTON_MAX_N);
+        }
         {
             size_t need_x = 0;
             for (auto& b : ubins)
@@ -1734,6 +1760,23 @@ struct Solver final : pcr_solver {
     int launch_ustep() {
         RC(zero_counters());
         counters_zeroed = false;
+        // pcr_tune("ustep_newton"): exact Newton directions first (explicit Hessian + Cholesky, k_unewton); every other user's CG
+        // runs to convergence instead of stopping after cg_max_iter iterations -- the same step by another route
+        const bool newton = tune.ustep_newton != 0;
+        const double* dirp = nullptr;
+        if (newton && d_dir.p) {
+            HIPCHK(hipMemsetAsync(d_dir.p, 0xFF, d_dir.n * sizeof(double), st));          // all ones = NaN: "no direction"
+            if (newton_n > 0) {
+                const int ldp = (geo.ld + 15) & ~15;
+                ProfScope ps(this, "unewton", st, -1, newton_n);
+                hipLaunchKernelGGL((k_unewton<T>), dim3(newton_grid), dim3(256), newton_bytes<T>(newton_cap, newton_rs, geo.ld, ldp), st, sh, geo,
+                                   d_newton_users.p, newton_n, d_U.p, d_V.p, prm.lambda, strict(), newton_cap, newton_rs, ldp, d_newton_scratch.p, newton_stride, d_dir.p);
+                HIPCHK(hipGetLastError());
+            }
+            dirp = d_dir.p;
+        }
+        const int cg_max_u = newton ? 2 * geo.r + 10 : prm.cg_max_iter;
+        const double cg_tol_u = newton ? 1e-12 : prm.cg_tol;
         auto fn = [&](Bin& b, hipStream_t q) {
             const int nus = (int)b.users.size();
             const int cap_pad = host_pow2(b.cap), rsc = b.max_lev + 2;
@@ -1745,7 +1788,7 @@ struct Solver final : pcr_solver {
             // clusters: grid <= one workgroup per CU so that every member of every cluster is resident
             const int grid = b.ugrid;
             char* scr = d_scratch.p + (size_t)b.scratch_ofs * scratch_stride;
-#define LUS(BL, BG, KK, RS, UN, SY) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN, SY>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb, (tune.fault_cluster_member ? 1 : 0) | (tune.count_rows ? 2 : 0) | (state_of_rejected_V ? 4 : 0), b.wcap)
+#define LUS(BL, BG, KK, RS, UN, SY) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN, SY>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, cg_max_u, cg_tol_u, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb, (tune.fault_cluster_member ? 1 : 0) | (tune.count_rows ? 2 : 0) | (state_of_rejected_V ? 4 : 0), b.wcap, dirp)
 #define LU(BL, BG, KK, RS, UN) LUS(BL, BG, KK, RS, UN, 0)
 #define LU2(BL) do { if (b.sym) LUS(BL, false, 1, false, 4, 1); else LUS(BL, false, 1, false, 4, 0); } while (0)
             if (b.gram) {

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && UNR == 4 && !RES && K == 1 
                                                  T* __restrict__ U, const T* __restrict__ Vm, double lambda, double stepsize0,
                                                  int cg_max, double cg_tol, int strict, int solver1, int cap, int cap_pad, int rs_cap, int rcap, int nchp,
                                                  char* scratch, size_t stride, unsigned long long* counters, ClusterBufs cb, int fault,
-                                                 int wcap) {
+                                                 int wcap, const double* __restrict__ dir = nullptr) {
     typedef typename LiSel<T, BIG>::type LI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // test hook (pcr_tune "fault_cluster_member"): the last member of every cluster leaves at once, so that the others run
@@ -252,8 +252,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && UNR == 4 && !RES && K == 1 
         __syncthreads();
         UPROF(6);
         if (!skip) {
+            // pcr_tune("ustep_newton"): the exact Newton direction of this user, from the explicit Hessian (k_unewton, pcr_newton.h),
+            // replaces the CG below; NaN in its first word = not provided (a user k_unewton does not cover, or a Hessian it could
+            // not factor): the CG runs, with the caller's cg_max / cg_tol
+            const bool have_dir = dir != nullptr && dir[(size_t)u * ld] == dir[(size_t)u * ld];
             // ---- CG, solve_delta_u_new (pcrpp.cpp:628-647)
-            for (int t = tid; t < ld; t += BLOCK) { delta[t] = 0.0; rr[t] = gvec[t] * -1.0; pv[t] = gvec[t]; }
+            for (int t = tid; t < ld; t += BLOCK) { delta[t] = have_dir ? dir[(size_t)u * ld + t] : 0.0; rr[t] = gvec[t] * -1.0; pv[t] = gvec[t]; }
             const double err = sqrt(gn2) * cg_tol;                              // 0.01 in the reference (:632)
             // The first line-search try needs no pass over the rows: V_I (u - s delta) = m - s sum_k alpha_k (V_I p_k), and
             // b_k = V_I p_k is what every CG iteration computes anyway.  With the window cache on, the gradient point's scores
@@ -261,11 +265,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && UNR == 4 && !RES && K == 1 
             // writes its coefficients beside b (into the sort's index array, idle until the line search) so that b survives
             // until alpha is known.  Not when the sorted state belongs to a REJECTED V_new (its m is not V_I u, quirk q5), not
             // without the window cache (the sweeps then search ms0), not when T is wider than the index array (fp64 in LDS).
-            const bool mrec = !(fault & 4) && win && sizeof(T) <= sizeof(LI);
+            const bool mrec = !have_dir && !(fault & 4) && win && sizeof(T) <= sizeof(LI);
             T* cst = mrec ? reinterpret_cast<T*>(li) : key;
             ls_free = mrec ? 1 : 0;
             __syncthreads();
-            for (int k = 1; k <= cg_max; ++k) {                                 // 10 in the reference (:636)
+            for (int k = 1; k <= (have_dir ? 0 : cg_max); ++k) {                // 10 in the reference (:636)
                 for (int t = tid; t < ld; t += BLOCK) { vecT[t] = (T)pv[t]; Hp[t] = pv[t] * lambda; }
                 __syncthreads();
                 sddmm(key);                                                     // b = V_I p  (:592-594)

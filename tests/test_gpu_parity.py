@@ -554,6 +554,57 @@ def test_fuzz_evaluator_against_oracle(oracle):
         assert (np.isnan(n) and np.isnan(no)) or abs(n - no) < 1e-9 * max(1.0, abs(no)), (tag, n, no)
 
 
+@pytest.mark.parametrize("solver,r,real", [(2, 12, False), (2, 100, False), (1, 7, True), (2, 33, True)])
+def test_exact_newton_u_step_from_the_explicit_hessian(oracle, solver, r, real):
+    """SURVEY 8f-3, the literal object: pcr_tune("ustep_newton") builds every covered user's r x r Hessian
+    H = lambda I + 2 sum over active pairs (x_j - x_q)(x_j - x_q)^T on the matrix cores (k_unewton, fp64 MFMA), factors it by
+    Cholesky and hands k_ustep the exact Newton direction; users beyond 1024 ratings run their CG to convergence.  Checked
+    against the ORACLE's U step with its CG run to convergence (the same Newton step by the reference's own route): factors,
+    objective, line-search counts -- on users of 0 .. 5000 ratings, both solvers, integer and real-valued ratings, a rank with
+    pad columns and the bench's rank 100."""
+    d1, d2, user, item, val = _mixed_set(seed=5, d1=260, d2=5600)
+    if real:
+        val = val + np.random.default_rng(1).uniform(-0.4, 0.4, val.shape[0])
+    lam = 40.0
+    X = oracle.build_csr(d1, d2, user, item, val)
+    U0 = oracle.initial(d1, r) * 0.3; V0 = oracle.initial(d2, r) * 0.3
+    ds = pcr.Dataset.from_triplets(d1, d2, user, item, val)
+    try:
+        oracle.set_cg(6 * r + 50, 1e-13)
+        m0 = oracle.comp_m(U0, V0, X)
+        U1, objU, info_o = (oracle.update_U_new(X, m0, lam, 1.0, V0, U0) if solver == 2 else
+                            _oracle_update_U_solver1(oracle, X, m0, lam, V0, U0))
+    finally:
+        oracle.set_cg()
+    with pcr.tuned(ustep_newton=1):
+        s = pcr.Solver(ds, pcr.Parameter(k=r, solver_type=solver, precision=pcr.PCR_F64, **{"lambda": lam}))
+    s.set_factors(U0, V0)
+    s.comp_m()
+    oU, iu = s.update_U()
+    Ug, _ = s.get_factors()
+    if solver == 2:
+        assert abs(oU / objU - 1) < 1e-9, (oU, objU)
+    assert rel(Ug, U1) < 2e-7
+    assert iu["ls"] == info_o["ls"]
+    # the covered users took no CG iteration at all: what is counted comes from the users beyond 1024 ratings only
+    lens = np.diff(X.idx)
+    assert iu["cg"] <= int((lens > 1024).sum()) * (2 * r + 10)
+    # and the default mode is untouched by the knob's existence: the truncated CG of the reference
+    s2 = pcr.Solver(ds, pcr.Parameter(k=r, solver_type=solver, precision=pcr.PCR_F64, **{"lambda": lam}))
+    s2.set_factors(U0, V0); s2.comp_m()
+    _, iu2 = s2.update_U()
+    assert iu2["cg"] > iu["cg"]
+
+
+def _oracle_update_U_solver1(oracle, X, m, lam, V, U):
+    """update_U of PrimalCR (pcr.cpp:587) through the oracle's per-user entry point."""
+    Un = U.copy(); obj = 0.0; ls = 0; cg = 0
+    for i in range(X.d1):
+        un, o, inf = oracle.update_u_new(i, V, X, m, lam, 1.0, U[i], solver=1)
+        Un[i] = un; obj += o; ls += inf["ls"]; cg += inf["cg"]
+    return Un, obj + lam / 2.0 * (V ** 2).sum(), {"ls": ls, "cg": cg}
+
+
 def test_cg_knobs_and_exact_newton_u_step(oracle):
     """cg_max_iter / cg_tol (the reference hard-codes 10 / 0.01).  With the same settings the device and the
     oracle still agree step by step (iteration counts included); with cg_max_iter = r and a tiny tolerance the U step
