@@ -594,6 +594,13 @@ def test_exact_newton_u_step_from_the_explicit_hessian(oracle, solver, r, real):
     s2.set_factors(U0, V0); s2.comp_m()
     _, iu2 = s2.update_U()
     assert iu2["cg"] > iu["cg"]
+    # fp32 storage: the Hessian is still accumulated in fp64 from the fp32 rows
+    if solver == 2 and not real:
+        with pcr.tuned(ustep_newton=1):
+            s3 = pcr.Solver(ds, pcr.Parameter(k=r, solver_type=solver, precision=pcr.PCR_F32, **{"lambda": lam}))
+        s3.set_factors(U0, V0); s3.comp_m()
+        o3, iu3 = s3.update_U()
+        assert abs(o3 / objU - 1) < 2e-4 and rel(s3.get_factors()[0], U1) < 5e-3
 
 
 def _oracle_update_U_solver1(oracle, X, m, lam, V, U):
