@@ -33,11 +33,14 @@ static inline size_t newton_bytes(int cap, int rs_cap, int ld, int ldp) {
            carve_bytes(cap, 8) + carve_bytes(rs_cap, 4) + carve_bytes(8, 8) + 3 * carve_bytes(ldp, 8) + carve_bytes(2 * ldp, 8) +
            2 * carve_bytes((size_t)NEWTON_CHUNK * ldp, 8) + carve_bytes((size_t)ld * ld, 8);
 }
+// + the window bounds of every rating (8 slots of 16 bits), kept where the 160 KB allow it: the Hessian pass then issues all its
+// prefix-table loads at once instead of one binary search at a time
+static inline size_t newton_wb_bytes(int cap) { return carve_bytes((size_t)cap * 8, 2); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_unewton(Shard<T> S, Geo geo, const int32_t* __restrict__ users, int nusers,
                                                  const T* __restrict__ U, const T* __restrict__ Vm, double lambda, int strict,
-                                                 int cap, int rs_cap, int ldp, char* scratch, size_t stride, double* __restrict__ dir) {
+                                                 int cap, int rs_cap, int ldp, char* scratch, size_t stride, double* __restrict__ dir, int wbcap) {
     constexpr int BLOCK = 256;
     typedef GramMfma<double> MM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(256) void k_unewton(Shard<T> S, Geo geo, const int3
     double* Xc = cv.take<double>((size_t)NEWTON_CHUNK * ldp);
     double* Yc = cv.take<double>((size_t)NEWTON_CHUNK * ldp);
     double* Hm = cv.take<double>((size_t)ld * ld);
+    uint16_t* wb = cv.take<uint16_t>((size_t)wbcap * 8);          // (wbcap = cap or 0)
     double* Ptab = reinterpret_cast<double*>(scratch + (size_t)blockIdx.x * stride);          // (n + 1) x ldp
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nt = ldp / MM::TS, npairs = nt * (nt + 1) / 2;
@@ -87,11 +91,14 @@ __global__ __launch_bounds__(256) void k_unewton(Shard<T> S, Geo geo, const int3
             cg[p] = sweep_coeff<T>(ms0, Sx, rs, nlev, lev, mp, (double)mp, 1.0, strict);
             const T lo = mp - (T)1, hi = mp + (T)1;
             int d = 0;
+            const bool keep = wbcap > 0 && nlev <= 9;
             for (int l = 0; l < nlev; ++l) {
                 if (l == lev) continue;
                 const int s = rs[l], e = rs[l + 1];
-                if (l < lev) d += e - (strict ? ubound(ms0, s, e, lo) : lbound(ms0, s, e, lo));
-                else d += (strict ? lbound(ms0, s, e, hi) : ubound(ms0, s, e, hi)) - s;
+                int w;
+                if (l < lev) { w = strict ? ubound(ms0, s, e, lo) : lbound(ms0, s, e, lo); d += e - w; }
+                else { w = strict ? lbound(ms0, s, e, hi) : ubound(ms0, s, e, hi); d += w - s; }
+                if (keep) wb[(size_t)p * 8 + (l - (l > lev))] = (uint16_t)w;
             }
             deg[p] = d;
         }
@@ -147,11 +154,13 @@ __global__ __launch_bounds__(256) void k_unewton(Shard<T> S, Geo geo, const int3
                     const T* vrow = Vm + (size_t)itm[p] * ld;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { const int c = t32 + 32 * k; x[k] = c < ld ? (double)vrow[c] : 0.0; }
+                    const bool kept = wbcap > 0 && nlev <= 9;
                     for (int l = 0; l < nlev; ++l) {
                         if (l == lev) continue;
                         const int s = rs[l], e = rs[l + 1];
                         int a, b;
-                        if (l < lev) { a = strict ? ubound(ms0, s, e, lo) : lbound(ms0, s, e, lo); b = e; }
+                        if (kept) { const int w = wb[(size_t)p * 8 + (l - (l > lev))]; if (l < lev) { a = w; b = e; } else { a = s; b = w; } }
+                        else if (l < lev) { a = strict ? ubound(ms0, s, e, lo) : lbound(ms0, s, e, lo); b = e; }
                         else { a = s; b = strict ? lbound(ms0, s, e, hi) : ubound(ms0, s, e, hi); }
                         if (b > a) {
                             const double* pb = Ptab + (size_t)b * ldp;
