@@ -1013,6 +1013,8 @@ def main():
     ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end leg of the default N = 1 run: the drop-in omp-pmf-train (-t 10, "
                                                           "defaults) and the reference binary on the workload's text directory, wall-clocked")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--all-legs", action="store_true", help="N > 1: also the fp64 leg and the diagnostic replay that counts the U step's row gathers "
+                                                            "(default for N > 1: the one timed run)")
     ap.add_argument("--no-rows", action="store_true", help="skip the diagnostic replay that counts the rows the U step gathers (profiler passes)")
     ap.add_argument("--profile-period", type=int, default=0,
                     help="event-time every n-th launch of each kernel (the first one included); 0 = as sparse as leaves a dozen "
@@ -1070,6 +1072,11 @@ def main():
             log("[bench] several ranks share a device: one stream per rank (--tune lanes=1)")
     job = Job(args, torch, dist, rank, N, device)
     r, lam = args.rank_k or (200 if args.shape == "yahoo" else 100), args.lam
+    # N > 1: ONE timed run, one communicator (the scaling record needs `value`; the fp64 leg and the row-counting replay are three
+    # more solvers and communicators per rank on a path that has never met a peer over xGMI -- ask for them with --all-legs)
+    if N > 1 and not args.all_legs:
+        args.no_f64 = True
+        args.no_rows = True
     precisions = (args.precision,) if (args.no_f64 or args.precision == "f64") else ("f32", "f64")
     default_run = (N == 1 and args.shape == "ml1m" and args.users is None and args.nnz is None and args.rank_k is None and args.precision == "f32")
     rec = measure(job, args.shape, r, lam, args.steps, args.warmup, args.users, args.nnz, precisions, not args.no_profile,

@@ -90,7 +90,7 @@ def test_a_rank_that_dies_is_named_and_takes_the_job_down(n, fault, want):
 def test_two_ranks_on_one_gpu_equal_one_rank():
     users, nnz, r, steps, warmup = 2000, 250000, 100, 2, 1
     p = run_bench("--gpus", "2", "--comm", "p2p", "--devices", "0,0", "--rendezvous", "gloo", "--steps", str(steps), "--warmup",
-                  str(warmup), "--users", str(users), "--nnz", str(nnz), "--no-cpu", "--no-f64")
+                  str(warmup), "--users", str(users), "--nnz", str(nnz), "--no-cpu", "--no-f64", "--all-legs")   # (--all-legs: with the row-counting replay)
     assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads(p.stdout.strip().split("\n")[-1])
     assert line["n_gpus"] == 2 and line["comm_nranks"] == 2 and line["scaling"] == "weak" and line["config"]["exchange"] == "p2p"
