@@ -172,6 +172,10 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *   ustep_newton    1 = EXACT Newton U step: users of at most 1024 ratings (ranks up to 112) get their direction from the
  *                   explicit r x r Hessian, built on the matrix cores and factored by Cholesky (k_unewton); every other user's CG runs
  *                   to convergence.  Leaves the reference's truncated-CG trajectory on purpose; default 0
+ *   vblock_users    n > 0 = BLOCKED-USER V step: the n users with the most ratings (those that rate at least a sixteenth
+ *                   of the items) take their share of every Hessian-vector product's two rating-parallel products as dense GEMMs on
+ *                   the matrix cores (k_vblock_b, k_vblock_hp) and stay out of the sparse kernels' plan; same results to summation-
+ *                   order rounding; default 0
  *   ustep_gram      dual (Gram-matrix on MFMA) U step for users with at most that many ratings (<= 128; default 0 = off)
  *   spmm_tiles, spmm_chunk, sddmm_csc   tiling of the rating-parallel kernels (user tiles per XCD group, ratings per lane group, the
  *                   CG's SDDMM over the tile-major CSC: chosen from the shard's shape)

@@ -119,7 +119,7 @@ static inline void plan_chunks(SpmmPlan& P, int64_t nnz_local, const std::vector
             for (int64_t a = cut[(size_t)t * (n_rng + 1) + r]; a < cut[(size_t)t * (n_rng + 1) + r + 1]; a += P.chunk) P.chunk_ptr.push_back((int32_t)a);
         }
     trc0[(size_t)ntiles * n_rng] = (int32_t)P.chunk_ptr.size();
-    P.chunk_ptr.push_back((int32_t)nnz_local);
+    P.chunk_ptr.push_back((int32_t)nnz_local);                 // (the end of the last chunk: the entries the chunks cover)
 }
 
 // 3. plan_blocks: workgroup -> chunks: gpb chunks per workgroup, never across tiles; tile t is walked by workgroups b = t mod 8 (mod 8).

@@ -23,12 +23,14 @@
 template <typename K>
 __global__ __launch_bounds__(256) void k_plan_keys(const int64_t* __restrict__ uptr, const int32_t* __restrict__ item,
                                                    const int64_t* __restrict__ tile_u, int ntiles, int64_t d2, int64_t nu,
-                                                   K* __restrict__ key, int32_t* __restrict__ val, int32_t* __restrict__ ruser) {
+                                                   K* __restrict__ key, int32_t* __restrict__ val, int32_t* __restrict__ ruser,
+                                                   const unsigned char* __restrict__ excl) {
     const int lane = threadIdx.x & 63;
     for (int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); u < nu; u += (int64_t)gridDim.x * 4) {
         int lo = 0, hi = ntiles;                       // largest t with tile_u[t] <= u (empty tiles share a boundary: the last one wins)
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_u[mid] <= u) lo = mid; else hi = mid; }
-        const K base = (K)lo * (K)d2;
+        // (excl: users whose ratings the dense block kernels of pcr_vblock.h handle sort behind every tile and stay out of the chunks)
+        const K base = (K)((excl && excl[u]) ? ntiles : lo) * (K)d2;
         const int64_t a = uptr[u], b = uptr[u + 1];
         for (int64_t z = a + lane; z < b; z += 64) { key[z] = base + (K)item[z]; val[z] = (int32_t)z; ruser[z] = (int32_t)u; }
     }

@@ -24,6 +24,7 @@
 #include "pcr_kernels.h"
 #include "pcr_gram.h"
 #include "pcr_newton.h"
+#include "pcr_vblock.h"
 #include "pcr_p2p.h"
 
 #define HIPCHK(expr)                                                                           \
@@ -150,7 +151,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, ustep_mode = 0, cluster_k = 4, cluster_users = 0, window_cache = 1,
         prepare_merged = -1, pipeline = 1, debug = 0, fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, allreduce_chunks = 0,
-        resort_window = 8, p2p_ll = 16, p2p_timeout_ms = 20000, fault_p2p_skip = 0, fault_p2p_coarse = 0, win16 = 1, ustep_win_lds = 1, plan_key64 = 0, ustep_newton = 0;
+        resort_window = 8, p2p_ll = 16, p2p_timeout_ms = 20000, fault_p2p_skip = 0, fault_p2p_coarse = 0, win16 = 1, ustep_win_lds = 1, plan_key64 = 0, ustep_newton = 0, vblock_users = 0;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -163,7 +164,7 @@ struct Tune {
         resort_window = pcr_tune_int("resort_window", 8); p2p_ll = pcr_tune_int("p2p_ll", 16);
         p2p_timeout_ms = pcr_tune_int("p2p_timeout_ms", 20000); fault_p2p_skip = pcr_tune_int("fault_p2p_skip", 0);
         fault_p2p_coarse = pcr_tune_int("fault_p2p_coarse", 0);
-        win16 = pcr_tune_int("win16", 1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); plan_key64 = pcr_tune_int("plan_key64", 0); ustep_newton = pcr_tune_int("ustep_newton", 0);
+        win16 = pcr_tune_int("win16", 1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); plan_key64 = pcr_tune_int("plan_key64", 0); ustep_newton = pcr_tune_int("ustep_newton", 0); vblock_users = pcr_tune_int("vblock_users", 0);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
 };
@@ -204,6 +205,11 @@ struct Solver final : pcr_solver {
     DBuf<double> d_objr;
     DBuf<int32_t> d_item, d_c2r, d_runstart, d_sitem, d_cuser, d_crow, d_ruser, d_slot_base, d_item_slot, d_chunk_ptr, d_slot_id;
     DBuf<int2> d_blk_chunks;                      // k_spmm: first chunk and chunk count of every workgroup
+    // pcr_tune("vblock_users"): the blocked-user V step (pcr_vblock.h): the block's users (padded to 32 with -1), the dense
+    // (user, item) -> CSR position index, the per-user exclusion flags of the sparse plan
+    DBuf<int32_t> d_blk_user, d_cpos_dense;
+    DBuf<unsigned char> d_excl;
+    int vblock_nbp = 0;
     // pcr_tune("ustep_newton"): the users k_unewton covers, its directions (nu x ld, NaN = none), its prefix tables
     DBuf<int32_t> d_newton_users;
     DBuf<double> d_dir;
@@ -537,17 +543,19 @@ struct Solver final : pcr_solver {
         RC(key.alloc((size_t)n)); RC(skey.alloc((size_t)n)); RC(val.alloc((size_t)n)); RC(sval.alloc((size_t)n));
         RC(d_tile_u.upload(tile_u, st));
         const unsigned grid_u = (unsigned)std::min<int64_t>(1 << 20, cdiv(std::max<int64_t>(nu, 1), 4));
-        hipLaunchKernelGGL((k_plan_keys<K>), dim3(grid_u), dim3(256), 0, st, d_uptr.p, d_item.p, d_tile_u.p, (int)ntiles, d2, nu, key.p, val.p, d_ruser.p);
+        const bool excl = vblock_nbp > 0;
+        hipLaunchKernelGGL((k_plan_keys<K>), dim3(grid_u), dim3(256), 0, st, d_uptr.p, d_item.p, d_tile_u.p, (int)ntiles, d2, nu, key.p, val.p, d_ruser.p,
+                           excl ? d_excl.p : (const unsigned char*)nullptr);
         HIPCHK(hipGetLastError());
-        const int bits = plan_bits((unsigned long long)ntiles * (unsigned long long)std::max<int64_t>(d2, 1));
+        const int bits = plan_bits((unsigned long long)(ntiles + (excl ? 1 : 0)) * (unsigned long long)std::max<int64_t>(d2, 1));
         HIPCHK(plan_sort_pairs<K>(key.p, skey.p, val.p, sval.p, (size_t)n, bits, st));
         const unsigned grid_z = (unsigned)std::min<int64_t>(1 << 20, cdiv(n, 256));
         hipLaunchKernelGGL(k_plan_gather, dim3(grid_z), dim3(256), 0, st, sval.p, d_item.p, d_ruser.p, d_c2r.p, d_crow.p, d_cuser.p, n);
         HIPCHK(hipGetLastError());
-        if (n_rng_ > 1) {                                         // where every tile's sorted entries cross into each item range
+        if (n_rng_ > 1 || excl) {                                 // where every tile's sorted entries begin and cross into each item range
             std::vector<K> probe;
-            for (int64_t t = 0; t < ntiles; ++t)
-                for (int r = 1; r < n_rng_; ++r) probe.push_back((K)t * (K)d2 + (K)P.rng_item[r]);
+            for (int64_t t = 0; t <= ntiles; ++t)
+                for (int r = 0; r < (t < ntiles ? n_rng_ : 1); ++r) probe.push_back((K)t * (K)d2 + (K)P.rng_item[r]);
             DBuf<K> d_probe;
             DBuf<int64_t> d_pos;
             RC(d_probe.upload(probe, st)); RC(d_pos.alloc(probe.size()));
@@ -556,9 +564,10 @@ struct Solver final : pcr_solver {
             std::vector<int64_t> pos(probe.size());
             HIPCHK(hipMemcpyAsync(pos.data(), d_pos.p, pos.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            size_t q = 0;
-            for (int64_t t = 0; t < ntiles; ++t)
-                for (int r = 1; r < n_rng_; ++r) cut[(size_t)t * (n_rng_ + 1) + r] = pos[q++];
+            for (int64_t t = 0; t < ntiles; ++t) {
+                for (int r = 0; r < n_rng_; ++r) cut[(size_t)t * (n_rng_ + 1) + r] = pos[(size_t)t * n_rng_ + r];
+                cut[(size_t)t * (n_rng_ + 1) + n_rng_] = pos[(size_t)(t + 1) * n_rng_];      // (the next tile's first entry; the excluded ratings' first for the last tile)
+            }
         }
         HIPCHK(hipStreamSynchronize(st));                         // (the temporaries go out of scope)
         return PCR_OK;
@@ -567,11 +576,11 @@ struct Solver final : pcr_solver {
         std::vector<int64_t> tile_u, cut;
         plan_tiles(in, P, tile_u);
         const int64_t n = in.nnz;
-        const unsigned long long key_span = (unsigned long long)P.ntiles * (unsigned long long)std::max<int64_t>(d2, 1);
+        const unsigned long long key_span = (unsigned long long)(P.ntiles + (vblock_nbp ? 1 : 0)) * (unsigned long long)std::max<int64_t>(d2, 1);
         if (key_span < ((unsigned long long)1 << 32) && !tune.plan_key64) RC(build_plan_keys<uint32_t>(in, P, tile_u, cut));
         else RC(build_plan_keys<unsigned long long>(in, P, tile_u, cut));
         std::vector<int32_t> trc0;
-        plan_chunks(P, n, cut, trc0);
+        plan_chunks(P, cut.empty() ? n : cut.back(), cut, trc0);       // (cut.back(): the entries the tiles hold -- all of them unless a block is left out)
         plan_blocks(P, geo.G, trc0);
         const int64_t nchunks = (int64_t)P.chunk_ptr.size() - 1;
         RC(d_chunk_ptr.upload(P.chunk_ptr, st)); RC(d_blk_chunks.upload(P.blk, st));
@@ -721,8 +730,35 @@ struct Solver final : pcr_solver {
         // the shard's CSR goes up first: the nnz-sized part of the SpMM plan is built from it on the device (pcr_plan_dev.h)
         RC(d_uptr.upload(uptr, st)); RC(d_item.upload_n(item, (size_t)nnz_local));
         phase("CSR upload");
+        std::vector<int32_t> by_len;
+        length_order(uptr, nu, by_len);
+        if (tune.vblock_users > 0 && nu > 0) {
+            // The blocked-user V step (pcr_vblock.h): the users with the most ratings -- at most vblock_users of them, those that rate
+            // at least a sixteenth of the catalogue -- go through dense MFMA kernels; the sparse plan leaves their ratings out.
+            std::vector<int32_t> blk;
+            for (int64_t q = 0; q < nu && (int)blk.size() < tune.vblock_users; ++q) {
+                const int32_t u = by_len[(size_t)q];
+                if ((uptr[u + 1] - uptr[u]) * 16 < d2) break;
+                blk.push_back(u);
+            }
+            if (!blk.empty()) {
+                vblock_nbp = ((int)blk.size() + 31) & ~31;
+                std::vector<unsigned char> excl((size_t)nu, 0);
+                std::vector<int32_t> cpos((size_t)vblock_nbp * (size_t)d2, -1);
+                for (size_t i = 0; i < blk.size(); ++i) {
+                    const int32_t u = blk[i];
+                    excl[(size_t)u] = 1;
+                    for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) cpos[i * (size_t)d2 + (size_t)item[z]] = (int32_t)z;
+                }
+                blk.resize((size_t)vblock_nbp, -1);
+                RC(d_blk_user.upload(blk, st)); RC(d_cpos_dense.upload(cpos, st)); RC(d_excl.upload(excl, st));
+                if (tune.debug) fprintf(stderr, "[pcr] blocked-user V step: %d users (padded to %d) x %lld items through the dense kernels\n",
+                                        (int)std::count(excl.begin(), excl.end(), 1), vblock_nbp, (long long)d2);
+            }
+        }
         SpmmPlan P;
-        const SpmmPlanIn plan_in{uptr, item, nu, nnz_local, d2, geo.ld, geo.G, ncu, sizeof(T), tune.spmm_chunk, tune.spmm_tiles, tune.allreduce_chunks};
+        // (a block left out of the sparse plan: one item range -- the dense kernels add their share before the one exchange)
+        const SpmmPlanIn plan_in{uptr, item, nu, nnz_local, d2, geo.ld, geo.G, ncu, sizeof(T), tune.spmm_chunk, tune.spmm_tiles, vblock_nbp ? 0 : tune.allreduce_chunks};
         RC(build_plan(plan_in, P));
         spmm_chunk = P.chunk; n_rng = P.n_rng; rng_item = P.rng_item; rng_blk = P.rng_blk; spmm_blocks = P.blocks; spmm_tiles = P.ntiles;
         if (n_rng > 1) {          // the all-reduce of a finished item range runs on its own stream (launch_spmm)
@@ -734,9 +770,8 @@ struct Solver final : pcr_solver {
         RC(d_slab.alloc(std::max<size_t>(P.slab_rows, 1) * geo.ld));
         sddmm_csc = (size_t)d2 * geo.ld * sizeof(T) > ((size_t)32 << 20) && spmm_tiles >= 8;     // item table larger than all L2s together
         if (tune.sddmm_csc >= 0) sddmm_csc = tune.sddmm_csc != 0;
+        if (vblock_nbp) sddmm_csc = true;                          // the CG's SDDMM walks the plan (which leaves the block out), b in CSR order
         phase("tile-major CSC, slab plan");
-        std::vector<int32_t> by_len;
-        length_order(uptr, nu, by_len);
         make_bins(uptr, nu, &lv.run_ofs, bins, by_len);
         for (auto& b : bins) RC(b.d_users.upload(b.users, st));
         // sweep / prepare classes: class 0 = one wave per user, class 1 = one 512-thread workgroup, class 2 = global scratch.
@@ -1375,6 +1410,12 @@ struct Solver final : pcr_solver {
         // b = u_user . A_item per rating: walking the sorted state's item ids leaves it in sorted order (what the sweep reads);
         // the CSC walk (item tables beyond the L2s) leaves it in CSR order and the sweep picks it up through sidx
         if (hv) { if (sddmm_by_tiles()) RC(launch_sddmm_csc(A, d_b.p, skip)); else RC(launch_sddmm(A, d_sitem.p, d_b.p, skip)); }
+        if (hv && vblock_nbp) {                                   // the block's share of b = U A^T on the matrix cores (pcr_vblock.h)
+            ProfScope ps(this, "vblock_b");
+            const int64_t tiles = (int64_t)(vblock_nbp / GramMfma<T>::TS) * cdiv(d2, GramMfma<T>::TS);
+            hipLaunchKernelGGL((k_vblock_b<T>), dim3((unsigned)cdiv(tiles, 4)), dim3(256), 0, st, d_U.p, A, d_blk_user.p, vblock_nbp, d_cpos_dense.p, d2, geo, d_b.p, skip);
+            HIPCHK(hipGetLastError());
+        }
         return launch_sweeps(hv, skip, hv && sddmm_by_tiles());
     }
     // the per-user sweeps alone: b (d_b) -> c (CSR order, d_c)
@@ -1450,6 +1491,11 @@ struct Solver final : pcr_solver {
         const size_t n = (size_t)d2 * geo.ld;
         if (n_rng == 1) {
             RC(launch_spmm_range(0, out, base, beta, skip, dots_rr));
+            if (vblock_nbp) {                                     // + the block's share, C_B^T U_B on the matrix cores, before the exchange
+                ProfScope ps(this, "vblock_hp");
+                const int64_t tiles = (int64_t)cdiv(d2, GramMfma<T>::TS) * cdiv(geo.ld, GramMfma<T>::TS);
+                hipLaunchKernelGGL((k_vblock_hp<T>), dim3((unsigned)cdiv(tiles, 4)), dim3(256), 0, st, d_U.p, d_c.p, d_blk_user.p, vblock_nbp, d_cpos_dense.p, d2, geo, out, skip);
+            }
             HIPCHK(hipGetLastError());
             return allreduce_T(out, n);
         }
@@ -1669,7 +1715,7 @@ struct Solver final : pcr_solver {
         const int* skip = &d_cgp->done;
         // one GPU: Hp is final when k_spmm_fin stores it, so that kernel also produces the p.Hp / rr.p partials;
         // with an all-reduce in between they need their own pass (k_cg_a)
-        const bool fused_dots = single() && n_rng == 1;
+        const bool fused_dots = single() && n_rng == 1 && !vblock_nbp;      // (the dense block adds to Hp AFTER k_spmm_fin)
         const bool exact_rr = prm.cg_tol < 1e-5;                   // the residual recurrence of k_cg_bc cancels below that
         for (int k = 1; k <= prm.cg_max_iter; ++k) {
             RC(device_hv(d_p.p, d_Hp.p, skip, fused_dots ? d_rr.p : nullptr));

@@ -333,6 +333,7 @@ VARIANTS = [
     {"resort_window": "0"}, {"resort_window": "2"}, {"resort_window": "64"},   # the sorts' nearly-sorted fast path: off, narrow, widest
     {"spmm_tiles": "2"}, {"spmm_tiles": "4"},                # tiles bound to groups of 4 / 2 XCDs
     {"plan_key64": "1"}, {"plan_key64": "1", "allreduce_chunks": "3", "spmm_tiles": "16"},   # the device-built plan with 64-bit (tile, item) keys
+    {"vblock_users": "8"}, {"vblock_users": "40", "spmm_tiles": "4"}, {"vblock_users": "33", "allreduce_chunks": "3"},   # the blocked-user V step: dense MFMA kernels for the longest users
 ]
 
 
@@ -610,6 +611,53 @@ def _oracle_update_U_solver1(oracle, X, m, lam, V, U):
         un, o, inf = oracle.update_u_new(i, V, X, m, lam, 1.0, U[i], solver=1)
         Un[i] = un; obj += o; ls += inf["ls"]; cg += inf["cg"]
     return Un, obj + lam / 2.0 * (V ** 2).sum(), {"ls": ls, "cg": cg}
+
+
+@pytest.mark.parametrize("precision,tol", [(pcr.PCR_F64, 1e-10), (pcr.PCR_F32, 3e-5)])
+def test_blocked_user_v_step_against_the_oracle(oracle, precision, tol):
+    """SURVEY 8f-3, the second object: pcr_tune("vblock_users") takes the users with the most ratings out of the sparse plan and
+    computes their share of b = U A^T and of Hp += C^T U as dense GEMMs on the matrix cores (k_vblock_b / k_vblock_hp, fp32 and
+    fp64 MFMA) through a static dense (user, item) -> CSR position index.  Gradient, one Hessian-vector product, the CG's direction
+    and count and a whole V step + U step against the oracle -- a shard where the block holds most of the ratings (users of 5000,
+    4500, ... of 6000 items) and one where no user qualifies (the knob then changes nothing)."""
+    d1, d2, user, item, val = _mixed_set(seed=3, d1=300, d2=6000)
+    r, lam = 20, 25.0
+    X = oracle.build_csr(d1, d2, user, item, val)
+    U0 = oracle.initial(d1, r) * 0.3; V0 = oracle.initial(d2, r) * 0.3
+    ds = pcr.Dataset.from_triplets(d1, d2, user, item, val)
+    m0 = oracle.comp_m(U0, V0, X)
+    g_o = oracle.obtain_g_new(U0, V0, X, m0, lam)
+    a = oracle.initial(d2, r)[::-1].copy() * 0.1
+    Ha_o = oracle.compute_Ha_new(a, m0, U0, X, lam)
+    d_o, its_o = oracle.solve_delta_new(g_o, m0, U0, X, lam)
+    V1, m1, objV, iv = oracle.update_V_new(X, lam, 1.0, U0, V0)
+    U1, objU, iu = oracle.update_U_new(X, m1, lam, 1.0, V1, U0)
+    for nb in (24, 64):
+        with pcr.tuned(vblock_users=nb):
+            s = pcr.Solver(ds, pcr.Parameter(k=r, precision=precision, **{"lambda": lam}))
+        s.set_factors(U0, V0)
+        s.comp_m()
+        assert rel(s.obtain_g(), g_o) < tol
+        assert rel(s.compute_Ha(a), Ha_o) < tol
+        dg, its = s.solve_delta(g_o)
+        assert rel(dg, d_o) < 50 * tol and (precision == pcr.PCR_F32 or its == its_o)
+        s.set_factors(U0, V0)
+        oV, info = s.update_V()
+        oU, info_u = s.update_U()
+        Ug, Vg = s.get_factors()
+        assert abs(oV / objV - 1) < 20 * tol and abs(oU / objU - 1) < 20 * tol
+        assert rel(Vg, V1) < 200 * tol and rel(Ug, U1) < 200 * tol
+        if precision == pcr.PCR_F64:
+            assert (info["cg"], info["ls"]) == (iv["cg"], iv["ls"]) and (info_u["cg"], info_u["ls"]) == (iu["cg"], iu["ls"])
+    # nobody rates a sixteenth of the catalogue: no block, the plain path
+    R = synth.generate("small", seed=2, d1=200, d2=4000, nnz=12000, mu=3.5, sigma=0.6)
+    ds2 = pcr.Dataset.from_triplets(R.d1, R.d2, R.user, R.item, R.val)
+    X2 = oracle.build_csr(R.d1, R.d2, R.user, R.item, R.val)
+    Ua, Va = oracle.initial(R.d1, r) * 0.3, oracle.initial(R.d2, r) * 0.3
+    with pcr.tuned(vblock_users=64):
+        s = pcr.Solver(ds2, pcr.Parameter(k=r, precision=precision, **{"lambda": lam}))
+    s.set_factors(Ua, Va); s.comp_m()
+    assert rel(s.obtain_g(), oracle.obtain_g_new(Ua, Va, X2, oracle.comp_m(Ua, Va, X2), lam)) < tol
 
 
 def test_cg_knobs_and_exact_newton_u_step(oracle):
