@@ -977,6 +977,7 @@ def spawn_ranks(N):
         for q, k in enumerate(kids):             # (a rank that failed after the loop's last look)
             if k.returncode != 0:
                 failed = (q, k.returncode, f"exited with code {k.returncode}" if k.returncode > 0 else f"killed by signal {-k.returncode}")
+                log(f"[bench] rank {q} {failed[2]} (pid {k.pid})")
                 break
     if stop["sig"] is not None and failed is None:
         failed = (-1, 128 + stop["sig"], f"the launcher received signal {stop['sig']}")
