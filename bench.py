@@ -870,7 +870,9 @@ def compact_line(full, full_record_path=None):
                        "roofline_iteration_frac": it64.get("frac"),
                        "gather_frac": (f64.get("gather") or {}).get("frac")}
     nf = g("netflix")
-    if nf:
+    if nf and nf.get("error"):
+        line["netflix"] = {"error": str(nf["error"])[:300]}          # the second leg failed: the headline above stands
+    elif nf:
         rf, nf64, ncb = nf.get("roofline") or {}, nf.get("f64") or {}, nf.get("cpu_baseline") or {}
         line["netflix"] = {"workload": "configs[3] Netflix-shaped 480189 x 17770, 100 M ratings, k=100, 1 GPU",
                            "ms_per_step": _r(nf["ms_per_step"], 6), "value": _r(nf["value"], 7), "steps": nf.get("steps"), "warmup": nf.get("warmup"),
@@ -886,6 +888,14 @@ def compact_line(full, full_record_path=None):
                                             "s_per_iter": _r(ncb.get("s_per_iter"), 5),
                                             "sample": _sample_short(ncb.get("sample"))} if ncb else None,
                            "speedup_vs_cpu_baseline": _r(nf.get("speedup_vs_cpu_baseline"))}
+        if (g("n_gpus") or 1) > 1:
+            # the strong-scaling leg of an N > 1 line: the same user-sharded job over all ranks, its shards and its exchange steps
+            nb = line["netflix"]
+            nb["workload"] = nf.get("workload_short") or f"configs[3] Netflix-shaped, k=100, user-sharded x{g('n_gpus')}"
+            for drop in ("cpu_baseline", "speedup_vs_cpu_baseline", "f64_ms_per_step", "solver_create_s"):
+                nb.pop(drop, None)
+            nb.update({"scaling": nf.get("scaling"), "comm_nranks": nf.get("comm_nranks"),
+                       "shards": nf.get("shards") if nf.get("shards") and len(nf["shards"]) <= 8 else None, "exchange": nf.get("exchange_profile")})
     cli = g("cli")
     if cli:
         ref = cli.get("reference") or {}
@@ -987,6 +997,90 @@ def spawn_ranks(N):
     return 0
 
 
+class SecondLeg:
+    """The Netflix-shaped strong-scaling leg of an N > 1 run (configs[3]) must never cost the headline: the ml1m record is complete
+    when this leg starts, rank 0 HOLDS it (stdout carries ONE line per run) and prints it whatever happens next --
+      * an exception on any rank: the rank leaves a note under `flag` (the ranks of a job share one node) and stops;
+      * a rank that hangs (a collective whose peer is gone has no time-out of its own): every rank's watchdog thread sees the note
+        or the deadline and ends its process -- rank 0 prints the held line with netflix = {"error": ...} first;
+      * SIGTERM (a launcher taking the job down because a peer died): rank 0 prints the held line first.
+    Processes end through os._exit(0) on those paths: nothing may wait in a destructor for a peer that will not come."""
+
+    def __init__(self, rank, flag, deadline_s, emit):
+        import threading
+        self.rank, self.flag, self.deadline, self.emit = rank, flag, time.time() + deadline_s, emit
+        self.done = threading.Event()
+        self.lock = threading.Lock()
+        self.left = False
+        self.thread = threading.Thread(target=self.watch, daemon=True)
+
+    def leave(self, why):
+        with self.lock:                         # (the watchdog, the signal handler and the main thread: the line is printed once)
+            if self.left:
+                return
+            self.left = True
+        log(f"[rank {self.rank}] Netflix-shaped leg: {why}")
+        if self.rank == 0:
+            self.emit({"error": why})
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
+
+    def note(self, why):
+        try:
+            with open(self.flag, "a") as f:
+                f.write(f"rank {self.rank}: {why}\n")
+        except OSError:
+            pass
+
+    def watch(self):
+        import select, signal
+        while not self.done.is_set():
+            # (a SIGTERM while the main thread sits in a library call: Python runs its handler only once that call returns, but the
+            # C-level handler writes the signal's number to the wake-up pipe at once -- this thread reads it)
+            ready, _, _ = select.select([self.pipe_r], [], [], 0.5)
+            if ready:
+                try:
+                    got = os.read(self.pipe_r, 64)
+                except OSError:
+                    got = b""
+                if bytes([signal.SIGTERM]) in got:
+                    self.note("the job received SIGTERM during the leg")
+                    self.leave("the job received SIGTERM during the leg")
+            if os.path.exists(self.flag):
+                try:
+                    why = open(self.flag).read().strip().split("\n")[0]
+                except OSError:
+                    why = "a rank failed"
+                self.leave(why)
+            if time.time() > self.deadline:
+                self.note("the leg did not finish within its time budget")
+                self.leave(f"not finished within its time budget on rank {self.rank}")
+
+    def run(self, fn):
+        import signal
+        self.pipe_r, pipe_w = os.pipe()
+        os.set_blocking(self.pipe_r, False); os.set_blocking(pipe_w, False)
+        old_fd = signal.set_wakeup_fd(pipe_w, warn_on_full_buffer=False)
+        old = signal.signal(signal.SIGTERM, lambda sig, frame: self.leave("the job received SIGTERM during the leg"))
+        self.thread.start()
+        try:
+            out = fn()
+        except BaseException as e:              # (SystemExit / KeyboardInterrupt included: the held line goes out first)
+            import traceback
+            traceback.print_exc()
+            why = f"{type(e).__name__}: {e}"[:300]
+            self.note(why)
+            self.leave(why)
+        self.done.set()
+        self.thread.join()
+        signal.signal(signal.SIGTERM, old)
+        signal.set_wakeup_fd(old_fd)
+        os.close(self.pipe_r); os.close(pipe_w)
+        if self.rank == 0 and os.path.exists(self.flag):
+            os.unlink(self.flag)
+        return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1010,7 +1104,11 @@ def main():
     ap.add_argument("--lib", default=None, help="A/B: load this libprimalcr.so instead of primalcr_amd/lib/libprimalcr.so")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-f64", action="store_true", help="skip the second timed run in the reference's arithmetic type")
-    ap.add_argument("--no-netflix", action="store_true", help="skip the Netflix-shaped sub-record of the default N = 1 run")
+    ap.add_argument("--no-netflix", action="store_true", help="skip the Netflix-shaped sub-record (the default N = 1 run; every N > 1 run of the ml1m shape)")
+    ap.add_argument("--netflix-users", type=int, default=None, help="N > 1: user count of the Netflix-shaped leg (default: the shape's 480 189)")
+    ap.add_argument("--netflix-nnz", type=int, default=None, help="N > 1: rating count of the Netflix-shaped leg (default: 100 M)")
+    ap.add_argument("--netflix-budget-s", type=float, default=420.0, help="N > 1: wall-clock bound of the Netflix-shaped leg; past it the line goes out "
+                                                                          "with netflix = {\"error\": ...} and the headline intact")
     ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end leg of the default N = 1 run: the drop-in omp-pmf-train (-t 10, "
                                                           "defaults) and the reference binary on the workload's text directory, wall-clocked")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
@@ -1027,6 +1125,8 @@ def main():
                          "(default N = 1 ml1m run only; the stored passes of profiles/ are used instead)")
     ap.add_argument("--full-line", action="store_true", help="developer tools only: print the full record as the stdout line (tens of KB)")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--fault-netflix", type=int, default=None, help="test hook: that rank raises inside the Netflix-shaped leg of an N > 1 run (the line must "
+                                                                     "still carry the ml1m headline, with netflix = {\"error\": ...})")
     ap.add_argument("--fault", default=None, help="test hook, 'rank:signal' or 'rank:exit:code': that rank ends itself that way before it touches "
                                                   "a GPU (the launcher must name it, stop the others and print an error line)")
     args = ap.parse_args()
@@ -1088,6 +1188,7 @@ def main():
             and args.precision == "f32"):
         nf = measure(job, "netflix", 100, lam, 3, 1, None, None, precisions, not args.no_profile, not args.no_cpu,
                      cpu_sample=1_000_000, cpu_single=False)
+    out = None
     if rank == 0:
         out = {"metric": "pairwise-comparisons/sec", "value": rec["value"], "unit": "pairs/s", "n_gpus": N, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": rec["scaling"],
@@ -1098,9 +1199,12 @@ def main():
         for k, v in rec.items():
             if k not in out and k not in ("workload", "scaling", "dtype", "steps", "warmup"):
                 out[k] = v
-        if nf:
-            out["netflix"] = nf
-        # The driver reads the LAST stdout line and keeps only a few KB of it: the line is the compact summary (< 4 KB, every
+
+    def emit(netflix):
+        """Rank 0: the full record to its file, the ONE compact line to stdout."""
+        if netflix:
+            out["netflix"] = netflix
+        # The driver reads the LAST stdout line and keeps only a few KB of it: the line is the compact summary (< 5 KB, every
         # field the contract names + roofline + cpu_baseline), the full record (per-kernel tables, phases, notes) goes to a file.
         full_path = args.full_record or os.path.join(ROOT, "bench_full.json")
         try:
@@ -1111,6 +1215,23 @@ def main():
             log(f"[bench] could not write the full record to {full_path}: {e}")
             shown = None
         print(json.dumps(out) if args.full_line else json.dumps(compact_line(out, shown), separators=(",", ":")), flush=True)
+
+    # configs[3] in the N > 1 line too (north star "Target": both shapes at 1, 2, 4 and 8 GPUs): once the weak-scaled ml1m record is
+    # complete, the SAME ranks build the Netflix-shaped set cut into N nnz-balanced user ranges, with a communicator of its own, and
+    # time 3 steps -- strong scaling.  Guarded (SecondLeg): whatever happens in this leg, the line goes out with the headline intact.
+    if N > 1 and args.shape == "ml1m" and not args.no_netflix:
+        flag = job.bcast(os.path.join(tempfile.gettempdir(), f"pcr_bench_nf_{os.getpid()}_{int(time.time())}.failed"))
+        leg = SecondLeg(rank, flag, args.netflix_budget_s, emit)
+
+        def second():
+            if args.fault_netflix is not None and args.fault_netflix == rank:
+                raise RuntimeError("fault hook: this rank fails in the Netflix-shaped leg")
+            return measure(job, "netflix", 100, lam, 3, 1, args.netflix_users, args.netflix_nnz, ("f32",), not args.no_profile, False)
+        nf = leg.run(second)
+        if rank == 0 and nf is not None:
+            nf["workload_short"] = (f"configs[3] Netflix-shaped {nf['workload'].split('; ')[1]}, k=100, user-sharded x{N}")[:160]
+    if rank == 0:
+        emit(nf)
     if N > 1:
         dist.barrier(); dist.destroy_process_group()
 

@@ -95,12 +95,12 @@ static std::thread g_warm;
 static void join_warm() { if (g_warm.joinable()) g_warm.join(); }
 static bool g_lanes_given = false;                                        // --tune lanes=... on the command line
 
-static void die(const char* what) {
-    const std::string msg = pcr_last_error();
+static void die_with(const char* what, const std::string& msg) {
     join_warm();
     fprintf(stderr, "%s: %s\n", what, msg.c_str());
     exit(1);
 }
+static void die(const char* what) { die_with(what, pcr_last_error()); }
 
 // side files (pmf-train.cpp:208-227, 276-295) and the model (pmf-train.cpp:297-310)
 static void write_outputs(const pcr_params& param, const std::string& model, const std::vector<double>& U, const std::vector<double>& V,
@@ -112,8 +112,11 @@ static void write_outputs(const pcr_params& param, const std::string& model, con
     // into per-thread buffers that go to the file in row order: 48 M numbers (the Netflix shape's U) are seconds, not a minute.
     auto dump = [&](const char* name, const std::vector<double>& M, int64_t rows) {
         std::cout << name << " matrix of size " << rows << ", " << k << std::endl;
-        FILE* f = fopen((std::string(name) + suffix + ".txt").c_str(), "wb");
-        if (!f) return;
+        const std::string path = std::string(name) + suffix + ".txt";
+        FILE* f = fopen(path.c_str(), "wb");
+        // (a side file that cannot be written is an error, not a silent omission: a full disk must not end in exit code 0)
+        if (!f) die_with("output", "can't open " + path + ": " + strerror(errno));
+        bool ok = true;
         const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), rows * k / 65536 + 1));
         const int64_t rows_per_round = std::max<int64_t>(1, ((int64_t)1 << 20) / std::max(1, k));      // ~1 M numbers (16 MB of text at most) per thread and round
         for (int64_t r0 = 0; r0 < rows; r0 += rows_per_round * T) {
@@ -130,9 +133,11 @@ static void write_outputs(const pcr_params& param, const std::string& model, con
                     o.resize((size_t)(p - &o[0]));
                 });
             for (auto& x : th) x.join();
-            for (int t = 0; t < T; ++t) if (!out[(size_t)t].empty()) fwrite(out[(size_t)t].data(), 1, out[(size_t)t].size(), f);
+            for (int t = 0; t < T; ++t)
+                if (!out[(size_t)t].empty()) ok = fwrite(out[(size_t)t].data(), 1, out[(size_t)t].size(), f) == out[(size_t)t].size() && ok;
         }
-        fclose(f);
+        ok = fclose(f) == 0 && ok;
+        if (!ok) die_with("output", "short write to " + path + ": " + strerror(errno));
     };
     dump("U", U, d1);
     dump("V", V, d2);
@@ -490,6 +495,8 @@ int main(int argc, char** argv) {
 #ifndef PCR_CLI_PLAIN_EXIT
     // Everything this run produces is on disk and flushed: leave without tearing the solver and the HIP runtime down piece by piece
     // (streams, queues, code objects: ~0.1 s that only a process about to exit pays; the driver reclaims them with the process).
+    // Invariant: _exit skips `hold` and `join_at_return` -- the warm-up thread was joined before pcr_solver_create above, and every
+    // output has been written AND checked (write_outputs leaves through die_with on a failed open / write / close).
     fflush(stdout); fflush(stderr);
     _exit(0);
 #endif

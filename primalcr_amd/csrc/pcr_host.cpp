@@ -505,7 +505,12 @@ static int64_t nonblank_lines(const char* base, size_t a, size_t b) {
         }
         nl += bn; odd += bo;
     }
-    if (odd == 0) return nl + (b > a && base[b - 1] != '\n' ? 1 : 0);
+    if (odd == 0) {
+        // an unterminated last line counts only if it has content ("1 2 3\n  " holds one entry, not two)
+        bool tail = false;
+        for (size_t q = b; q > a && base[q - 1] != '\n' && !tail; --q) tail = base[q - 1] != ' ' && base[q - 1] != '\t' && base[q - 1] != '\r';
+        return nl + (tail ? 1 : 0);
+    }
     int64_t n = 0; bool content = false;
     for (size_t q = a; q < b; ++q) {
         if (base[q] == '\n') { n += content; content = false; }

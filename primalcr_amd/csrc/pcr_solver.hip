@@ -735,21 +735,35 @@ struct Solver final : pcr_solver {
         if (tune.vblock_users > 0 && nu > 0) {
             // The blocked-user V step (pcr_vblock.h): the users with the most ratings -- at most vblock_users of them, those that rate
             // at least a sixteenth of the catalogue -- go through dense MFMA kernels; the sparse plan leaves their ratings out.
+            // The dense (user, item) -> CSR position table has ONE slot per pair, and the loader keeps a (user, item) pair that the
+            // rating file holds twice as two ratings (as the reference's convert() does): a user with such a pair stays in the
+            // sparse plan.  The table is capped at 1 GiB (a block of 256 users at the Yahoo!Music shape's d2 would be 140 MB).
+            const int64_t blk_cap = std::min<int64_t>(tune.vblock_users, (((int64_t)1 << 30) / 4 / std::max<int64_t>(d2, 1)) & ~(int64_t)31);
             std::vector<int32_t> blk;
-            for (int64_t q = 0; q < nu && (int)blk.size() < tune.vblock_users; ++q) {
+            std::vector<int32_t> cpos;
+            for (int64_t q = 0; q < nu && (int64_t)blk.size() < blk_cap; ++q) {
                 const int32_t u = by_len[(size_t)q];
                 if ((uptr[u + 1] - uptr[u]) * 16 < d2) break;
+                const size_t row = blk.size() * (size_t)d2;
+                cpos.resize(row + (size_t)d2, -1);
+                bool dup = false;
+                for (int64_t z = uptr[u]; z < uptr[u + 1] && !dup; ++z) {
+                    int32_t& slot = cpos[row + (size_t)item[z]];
+                    dup = slot != -1;
+                    slot = (int32_t)z;
+                }
+                if (dup) {
+                    cpos.resize(row);
+                    if (tune.debug) fprintf(stderr, "[pcr] blocked-user V step: user %d rates an item twice -- left in the sparse plan\n", (int)u);
+                    continue;
+                }
                 blk.push_back(u);
             }
             if (!blk.empty()) {
                 vblock_nbp = ((int)blk.size() + 31) & ~31;
                 std::vector<unsigned char> excl((size_t)nu, 0);
-                std::vector<int32_t> cpos((size_t)vblock_nbp * (size_t)d2, -1);
-                for (size_t i = 0; i < blk.size(); ++i) {
-                    const int32_t u = blk[i];
-                    excl[(size_t)u] = 1;
-                    for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) cpos[i * (size_t)d2 + (size_t)item[z]] = (int32_t)z;
-                }
+                cpos.resize((size_t)vblock_nbp * (size_t)d2, -1);
+                for (int32_t u : blk) excl[(size_t)u] = 1;
                 blk.resize((size_t)vblock_nbp, -1);
                 RC(d_blk_user.upload(blk, st)); RC(d_cpos_dense.upload(cpos, st)); RC(d_excl.upload(excl, st));
                 if (tune.debug) fprintf(stderr, "[pcr] blocked-user V step: %d users (padded to %d) x %lld items through the dense kernels\n",

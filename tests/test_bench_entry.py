@@ -98,7 +98,12 @@ def test_two_ranks_on_one_gpu_equal_one_rank():
     assert line["shards"] == [[0, users, nnz], [users, users, nnz]]
     # (which slot has the most GPU time is a close call between a U-step class and the rating-parallel kernels when the ranks keep
     # to one stream each; only the gather kernels carry a `binding`)
-    assert line["roofline"] and line["roofline"]["kernel"] and (line["roofline"]["binding"] or {"level": "l2-gather"})["level"] == "l2-gather"
+    assert line["roofline"] and line["roofline"]["kernel"]
+    full = json.load(open(os.path.join(ROOT, line["full_record"])))
+    gather_slots = {k: v for k, v in full["kernels"].items() if k.partition("/")[0] in ("sddmm", "spmm")}
+    assert gather_slots and all(v["binding"]["level"] == "l2-gather" and 0 < v["binding"]["frac"] < 1.5 for v in gather_slots.values())
+    if line["roofline"]["kernel"] in gather_slots:
+        assert line["roofline"]["binding"]["level"] == "l2-gather"
     assert line["gather"]["level"] == "l2-gather"
     # what the exchange steps cost, for the day a scaling curve has to be decomposed: 1 gradient + 10 Hessian-vector all-reduces of
     # the d2 x ld vector per step, plus the objective's scalar blocks

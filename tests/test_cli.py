@@ -583,6 +583,16 @@ def test_gpus_option_a_signal_to_the_parent_ends_the_whole_job(tmp_path):
 
 
 @pytest.mark.gpu
+def test_a_side_file_that_cannot_be_written_is_an_error(tmp_path):
+    """pmf-train.cpp:276-295 writes U.txt / V.txt after training and ignores a failure; the drop-in CLI must not report success for a
+    run whose outputs are missing: U.txt is a directory here, the run ends with a message and a non-zero exit code."""
+    g, meta, d = golden_dir("edge5", tmp_path)
+    (tmp_path / "U.txt").mkdir()
+    r = run([TRAIN, "-k", "4", "-t", "1", "-p", "0", d, "m.model"], tmp_path)
+    assert r.returncode != 0 and "U.txt" in r.stderr, (r.returncode, r.stderr[-300:])
+
+
+@pytest.mark.gpu
 def test_gpus_option_with_more_ranks_than_users_that_have_ratings(tmp_path):
     """One user holds nearly every rating: the nnz-balanced partition gives two of the four workers NO users.  They still take part
     in every exchange (contributing zeros) and the job's model equals the one-process model to summation-order rounding."""

@@ -660,6 +660,36 @@ def test_blocked_user_v_step_against_the_oracle(oracle, precision, tol):
     assert rel(s.obtain_g(), oracle.obtain_g_new(Ua, Va, X2, oracle.comp_m(Ua, Va, X2), lam)) < tol
 
 
+def test_blocked_user_v_step_with_a_pair_rated_twice(oracle):
+    """A rating file may hold a (user, item) pair twice; the loader keeps both entries, as the reference's convert() does
+    (util.cpp:219-247).  The dense (user, item) -> position index of the blocked-user V step has one slot per pair, so a block
+    candidate with such a pair must stay in the sparse plan: gradient, Hessian-vector product and CG direction still equal the
+    oracle's, which treats the two entries as two ratings."""
+    d1, d2, user, item, val = _mixed_set(seed=3, d1=300, d2=6000)
+    longest = int(np.bincount(user, minlength=d1).argmax())
+    z = np.flatnonzero(user == longest)[[5, 900]]
+    user = np.concatenate([user, user[z]]); item = np.concatenate([item, item[z]])
+    val = np.concatenate([val, np.where(val[z] >= 3, val[z] - 2, val[z] + 2)])          # the second entry carries another level
+    r, lam = 20, 25.0
+    X = oracle.build_csr(d1, d2, user, item, val)
+    assert X.nnz == len(user)                                                              # (both entries kept)
+    U0 = oracle.initial(d1, r) * 0.3; V0 = oracle.initial(d2, r) * 0.3
+    ds = pcr.Dataset.from_triplets(d1, d2, user, item, val)
+    m0 = oracle.comp_m(U0, V0, X)
+    g_o = oracle.obtain_g_new(U0, V0, X, m0, lam)
+    a = oracle.initial(d2, r)[::-1].copy() * 0.1
+    Ha_o = oracle.compute_Ha_new(a, m0, U0, X, lam)
+    d_o, its_o = oracle.solve_delta_new(g_o, m0, U0, X, lam)
+    with pcr.tuned(vblock_users=24):
+        s = pcr.Solver(ds, pcr.Parameter(k=r, precision=pcr.PCR_F64, **{"lambda": lam}))
+    s.set_factors(U0, V0)
+    s.comp_m()
+    assert rel(s.obtain_g(), g_o) < 1e-10
+    assert rel(s.compute_Ha(a), Ha_o) < 1e-10
+    dg, its = s.solve_delta(g_o)
+    assert rel(dg, d_o) < 5e-9 and its == its_o
+
+
 def test_cg_knobs_and_exact_newton_u_step(oracle):
     """cg_max_iter / cg_tol (the reference hard-codes 10 / 0.01).  With the same settings the device and the
     oracle still agree step by step (iteration counts included); with cg_max_iter = r and a tiny tolerance the U step

@@ -1,6 +1,7 @@
 """CPU tests of the product's host side: the C-ABI library loads, exports every symbol declared in
 include/primalcr.h, and its loader / CSR conversion / initial() / model I/O / partitioner agree with
 the oracle and the golden vectors.  No GPU compute is called here."""
+import ctypes
 import os
 import re
 
@@ -374,7 +375,7 @@ def test_loader_blank_lines_crlf_and_missing_final_newline(tmp_path):
     lines = [f"{u + 1} {i + 1} {int(v)}" for u, i, v in zip(user.tolist(), item.tolist(), val.tolist())]
     rng = np.random.default_rng(2)
     want = pcr.Dataset.from_triplets(R.d1, R.d2, user, item, val).csr(0)
-    for style in ("crlf", "blank", "trailing", "no_final_newline"):
+    for style in ("crlf", "blank", "trailing", "no_final_newline", "blank_tail"):
         out = list(lines)
         if style == "crlf":
             body = "\r\n".join(out) + "\r\n"
@@ -384,12 +385,16 @@ def test_loader_blank_lines_crlf_and_missing_final_newline(tmp_path):
             body = "\n\n" + "\n".join(out) + "\n\n\n"
         elif style == "trailing":
             body = "\n".join(x + ("  " if n % 7 == 0 else "") for n, x in enumerate(out)) + "\n"
+        elif style == "blank_tail":                      # white space behind the last newline is not an entry
+            body = "\n".join(out) + "\n  \t"
         else:
             body = "\n".join(out)
         d = tmp_path / style; d.mkdir()
         (d / "training.ratings").write_text(body, newline="")
         (d / "meta").write_text(f"{R.d1} {R.d2}\n{len(lines)} training.ratings\n")
         assert len(body) > (1 << 20)
+        n = ctypes.c_int64(-1)
+        assert pcr.lib().pcr_rating_file_count(str(d / "training.ratings").encode(), ctypes.byref(n)) == pcr.PCR_OK and n.value == len(lines), style
         for threads in (1, 5):
             got = pcr.Dataset.load(str(d), threads=threads).csr(0)
             assert all(np.array_equal(a, b) for a, b in zip(got, want)), (style, threads)
