@@ -289,55 +289,118 @@ def pmc_accumulate(csv_path, ctr, acc):
             acc[k]["launches_" + ctr] += 1
 
 
+PMC_READ, PMC_WRITE = "TCC_EA0_RDREQ_DRAM_32B_sum", "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum"
+# kernels of the training iteration (set-up, evaluation and probe kernels are not part of a step's traffic)
+HOT_KERNEL = re.compile(r"^(void )?k_(sddmm|spmm|prepare|vsweep|ustep|cg_|axpy|obj|fin|dots|sum_stage|unewton|vblock|p2p)")
+
+
 def pmc_per_launch(acc):
-    """{kernel: launches, raw FETCH_SIZE bytes and WRITE_SIZE bytes per launch} for the kernels seen in BOTH passes (the counters are
-    in KiB; the gfx950 doubling of FETCH_SIZE is applied where the bytes are used)."""
+    """{kernel: launches, read and written bytes per launch} from one pass of the two 32-byte-unit counters (profiles/
+    r06_dram_calib.md: TCC_EA0_RDREQ_DRAM_32B_sum x 32 B and TCC_EA0_WRREQ_WRITE_DRAM_32B_sum x 32 B are byte-exact on streamed
+    reads, writes and whole-row gathers -- 128-byte read requests count 4, 64-byte writes 2 -- and need no gfx950 correction,
+    unlike FETCH_SIZE, which tallies a 128-byte request at 64).  They are the L2s' requests to local memory: Infinity-Cache hits
+    included, like every memory-side TCC counter of this part."""
     kernels = {}
     for k, v in acc.items():
-        nf, nw = v.get("launches_FETCH_SIZE", 0), v.get("launches_WRITE_SIZE", 0)
-        if nf and nw:
-            kernels[k] = {"launches": int(max(nf, nw)), "fetch_bytes_per_launch_raw": 1024.0 * v.get("FETCH_SIZE", 0.0) / nf,
-                          "write_bytes_per_launch": 1024.0 * v.get("WRITE_SIZE", 0.0) / nw}
+        n = v.get("launches_" + PMC_READ, 0)
+        if n:
+            kernels[k] = {"launches": int(n), "read_bytes_per_launch": 32.0 * v.get(PMC_READ, 0.0) / n,
+                          "write_bytes_per_launch": 32.0 * v.get(PMC_WRITE, 0.0) / n}
     return kernels
 
 
-def live_traffic(shape, prec, r, timeout_s=170):
-    """HBM traffic of THIS box, now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE -- one counter per pass, no trace domain
-    beside it, the program directly behind "--": MI355X_MICROARCH.md) of a short replay of the same workload in a child process
-    (16 outer iterations from pcr_initial, no event timing).  Returns ({kernel name: {"launches", "fetch_bytes_per_launch_raw",
-    "write_bytes_per_launch"}}, seconds) or (None, reason).  FETCH_SIZE / WRITE_SIZE are in KiB; the gfx950 doubling of
-    FETCH_SIZE is applied where the bytes are used (analyse)."""
+def traffic_bytes(t):
+    """Fabric-side bytes of one launch from a PMC record: the exact counters of round 6, or a stored FETCH_SIZE / WRITE_SIZE pass of
+    earlier rounds (FETCH_SIZE doubled: it tallies gfx950's 128-byte read requests at 64 B, MI355X_MICROARCH.md)."""
+    if "read_bytes_per_launch" in t:
+        return int(t["read_bytes_per_launch"] + t["write_bytes_per_launch"])
+    return int(2 * t["fetch_bytes_per_launch_raw"] + t["write_bytes_per_launch"])
+
+
+def live_traffic(shape, prec, r, steps=10, warmup=5, timeout_s=170):
+    """Memory-side traffic of THIS box, now: ONE rocprofv3 --pmc pass (both 32-byte-unit DRAM counters, no trace domain beside them,
+    the program directly behind "--": MI355X_MICROARCH.md) of a short replay of the same workload in a child process (warmup +
+    steps + 1 outer iterations from pcr_initial, no event timing).  Returns ({kernel name: {"launches", "read_bytes_per_launch",
+    "write_bytes_per_launch"}}, iterations replayed, seconds) or (None, 0, reason)."""
     import collections, glob, shutil, signal
     exe = shutil.which("rocprofv3")
     if not exe:
-        return None, "rocprofv3 not found"
+        return None, 0, "rocprofv3 not found"
     t0 = time.time()
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     tmp = tempfile.mkdtemp(prefix="pcr_pmc_", dir="/tmp")
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, ctr)
-            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--shape", shape,
-                   "--precision", prec, "--rank-k", str(r), "--steps", "10", "--warmup", "5", "--no-cpu", "--no-cli", "--no-f64", "--no-netflix", "--no-rows",
-                   "--no-profile", "--no-live-traffic", "--full-record", os.path.join(tmp, "child.json")]
-            p = subprocess.Popen(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
-                                 text=True, start_new_session=True)
-            try:
-                _, err = p.communicate(timeout=max(20.0, timeout_s - (time.time() - t0)))
-            except subprocess.TimeoutExpired:
-                os.killpg(p.pid, signal.SIGKILL)              # exactly the group this call started
-                p.wait()
-                return None, f"the {ctr} pass did not finish within the time budget"
-            if p.returncode != 0:
-                return None, f"the {ctr} pass exited with {p.returncode}: {(err or '').strip()[-200:]}"
-            files = glob.glob(os.path.join(out, "*", "*counter_collection.csv"))
-            if not files:
-                return None, f"the {ctr} pass left no counter_collection.csv"
-            pmc_accumulate(files[0], ctr, acc)
+        out = os.path.join(tmp, "pmc")
+        cmd = [exe, "--pmc", PMC_READ, PMC_WRITE, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--shape", shape,
+               "--precision", prec, "--rank-k", str(r), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu", "--no-cli", "--no-f64", "--no-netflix", "--no-rows",
+               "--no-profile", "--no-live-traffic", "--no-hbm", "--full-record", os.path.join(tmp, "child.json")]
+        p = subprocess.Popen(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                             text=True, start_new_session=True)
+        try:
+            _, err = p.communicate(timeout=max(20.0, timeout_s))
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)              # exactly the group this call started
+            p.wait()
+            return None, 0, "the counter pass did not finish within the time budget"
+        if p.returncode != 0:
+            return None, 0, f"the counter pass exited with {p.returncode}: {(err or '').strip()[-200:]}"
+        files = glob.glob(os.path.join(out, "*", "*counter_collection.csv"))
+        if not files:
+            return None, 0, "the counter pass left no counter_collection.csv"
+        pmc_accumulate(files[0], PMC_READ, acc)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     kernels = pmc_per_launch(acc)
-    return (kernels, time.time() - t0) if kernels else (None, "no kernel appeared in both passes")
+    return (kernels, warmup + steps + (1 if warmup >= 1 else 0), time.time() - t0) if kernels else (None, 0, "no kernel appeared in the pass")
+
+
+# ---- the HBM side (behind the Infinity Cache): the memory controllers' activity, sampled beside a sustained replay
+# profiles/r06_umc_calib.md: /sys/class/drm/card*/device/mem_busy_percent (the SMU's average UMC activity) reads 75.4 % under a
+# 6.25 TB/s streamed read of 1 GiB, 52.4 % under a 4.37 TB/s streamed write, 57.1 % under a 4.73 TB/s copy (82.9 / 83.5 / 82.7 GB/s
+# per percent) and 0 % under 6-20 TB/s of reads that the Infinity Cache or the L2s serve (64 / 192 MiB re-read, row gathers from
+# 1.6 / 7 / 109 MB tables): it is the one figure on this box that separates HBM from the Infinity Cache.
+HBM_GBS_PER_BUSY_PERCENT = 83.0
+
+
+class HbmSampler:
+    """mem_busy_percent of THIS process's GPU, sampled every few milliseconds by a thread while the main thread runs iterations."""
+
+    def __init__(self, device):
+        import ctypes, glob
+        self.path, self.samples, self.thread, self.stop_flag = None, [], None, False
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) == 0 and buf.value:
+                bus = buf.value.decode().lower()
+                for c in glob.glob("/sys/class/drm/card*/device/mem_busy_percent"):
+                    if os.path.basename(os.path.realpath(os.path.dirname(c))).lower() == bus:
+                        self.path = c
+        except OSError:
+            pass
+
+    def available(self):
+        return self.path is not None
+
+    def _loop(self, period):
+        while not self.stop_flag:
+            try:
+                self.samples.append(int(open(self.path).read().strip()))
+            except (OSError, ValueError):
+                pass
+            time.sleep(period)
+
+    def start(self, period=0.004):
+        import threading
+        self.samples, self.stop_flag = [], False
+        self.thread = threading.Thread(target=self._loop, args=(period,), daemon=True)
+        self.thread.start()
+
+    def stop(self):
+        self.stop_flag = True
+        self.thread.join()
+        xs = self.samples[len(self.samples) // 5:]        # (the firmware's average needs a moment to reach the replay's level)
+        return (sum(xs) / len(xs), len(xs)) if xs else (None, 0)
 
 
 class Job:
@@ -466,14 +529,28 @@ def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name
         s.iterate(steps)
         barrier()
         noev = job.allmax(time.perf_counter() - t1)
-    out = dict(secs=secs, secs_noevents=noev, create_s=t_create, objs=objs, inner=inner, prof=prof, launches=launches, scope=scope, prof_period=prof_period, cold=cold,
+    # the HBM side: >= 1 s of whole iterations back to back with the memory controllers' activity sampled beside them (HbmSampler)
+    hb = None
+    if args.hbm and N == 1 and not count_rows and steps > 0:
+        smp = HbmSampler(job.device)
+        if smp.available():
+            n_rep = max(3, min(5000, int(1.0 / max(secs / steps, 1e-6)) + 1))
+            barrier()
+            smp.start()
+            t2 = time.perf_counter()
+            s.iterate(n_rep)
+            barrier()
+            dt = time.perf_counter() - t2
+            bp, ns = smp.stop()
+            hb = dict(busy_percent=bp, samples=ns, steps=n_rep, secs=dt)
+    out = dict(secs=secs, secs_noevents=noev, create_s=t_create, objs=objs, inner=inner, prof=prof, launches=launches, scope=scope, prof_period=prof_period, cold=cold, hbm=hb,
                u_rows=s.counter("ustep_row_gathers") - rows0, rows_by_class=rows_by_class, steps=steps,
                te=(te_err, te_ndcg), tr=(tr_err, tr_ndcg), comm_nranks=comm_n, shard=shard_now)
     s.close()
     return out
 
 
-def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False, live=None):
+def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False, live=None, live_iters=0):
     """Roofline blocks of one timed run.  wl: dict(d1, d2, nnz, r) of the JOB; run["shard"] is this rank's part."""
     secs, inner, prof, steps = run["secs"], run["inner"], run["prof"], run["steps"]
     d1, d2, nnz, r = wl["d1"], wl["d2"], wl["nnz"], wl["r"]
@@ -521,9 +598,7 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False, live=No
                          any(slot_kernel_match(other, kn, prec_name) and slot_kernel_match(name, kn, prec_name) for kn in traffic))
             for kname, t in traffic.items():
                 if not shared and slot_kernel_match(name, kname, prec_name):
-                    # MI355X_MICROARCH.md (HBM): FETCH_SIZE counts wide coalesced reads at half their bytes on gfx950 ->
-                    # doubled; WRITE_SIZE is exact
-                    tr = int(2 * t["fetch_bytes_per_launch_raw"] + t["write_bytes_per_launch"])
+                    tr = traffic_bytes(t)
             # row gathers of one launch: one ld*esz-byte factor row per rating and half-pass
             g_rows = {"sddmm": nnz_b, "spmm": nnz_b}.get(cls)
             if cls == "ustep" and name in rows_by_class and run["launches"][name]:
@@ -549,9 +624,10 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False, live=No
                 "launches_timed": kd["timed_launches"], "algorithmic_bytes_per_launch": kd["algorithmic_bytes"],
                 "share_of_gpu_time": kd["gpu_time_share"], "binding": kd.get("binding"),
                 "traffic_source": (None if kd["traffic_bytes"] is None else
-                                   "live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes started by this run on this box (child "
-                                   "processes replaying 16 iterations of the workload), per launch, 2 x FETCH_SIZE + WRITE_SIZE "
-                                   "(MI355X_MICROARCH.md)" if traffic_src == "live" else
+                                   f"live: one rocprofv3 --pmc {PMC_READ} {PMC_WRITE} pass started by this run on this box (a child "
+                                   "process replaying the workload), per launch, 32 B x (reads + writes): the L2s' requests to local "
+                                   "memory, byte-exact (profiles/r06_dram_calib.md), Infinity-Cache hits INCLUDED -- the HBM side is "
+                                   "'hbm'" if traffic_src == "live" else
                                    (traffic_src or f"profiles/{TRAFFIC_FILE}") + ": stored rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                    "command (separate runs), per launch, 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md); not "
                                    "measured by this run"),
@@ -591,6 +667,36 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False, live=No
                                              "solver's stream: step time minus the U step's wall time; gather_GBs = (1 SpMM + n_cg x (SDDMM + "
                                              "SpMM) + n_ls SDDMM) x ratings x row bytes / that time (the SpMM's user tiles are cut to one "
                                              "XCD's L2; the SDDMM gathers the item table, or user tiles when the item table is beyond the L2s)")
+    # The HBM side of the roofline (north star: "achieved-HBM-GB/s against gfx950 peak").  No rocprofv3 counter of this part sees
+    # past the Infinity Cache (profiles/r06_dram_calib.md); the memory controllers' activity does (HbmSampler): sampled beside a
+    # sustained replay of whole iterations straight after the timed region.  fabric = what the L2s asked local memory for per
+    # iteration (the live counter pass: every kernel of the training step, Infinity-Cache hits included).
+    hbm, hb = None, run.get("hbm")
+    fabric_it = None
+    if live and live_iters:
+        fabric_it = sum(traffic_bytes(t) * t["launches"] for k, t in live.items() if HOT_KERNEL.match(k)) / live_iters
+    if hb and hb.get("busy_percent") is not None:
+        rate = hb["busy_percent"] * HBM_GBS_PER_BUSY_PERCENT
+        per_it = rate * 1e9 * hb["secs"] / hb["steps"]
+        hbm = {"busy_percent": round(hb["busy_percent"], 2), "achieved_GBs": round(rate, 1), "peak": HBM_PEAK_GBS, "frac": round(rate / HBM_PEAK_GBS, 5),
+               "bytes_per_iteration": int(per_it), "samples": hb["samples"], "replay_steps": hb["steps"], "replay_ms_per_step": round(1e3 * hb["secs"] / hb["steps"], 4),
+               "resolution_GBs": HBM_GBS_PER_BUSY_PERCENT,
+               "fabric_bytes_per_iteration": None if fabric_it is None else int(fabric_it),
+               "mall_served_frac": None if not fabric_it else round(max(0.0, 1.0 - per_it / fabric_it), 4),
+               "algorithmic_bytes_per_iteration": None,
+               "method": "mem_busy_percent of this GPU (the SMU's average memory-controller activity, whole percent) sampled every 4 ms "
+                         f"beside {hb['steps']} back-to-back iterations, x {HBM_GBS_PER_BUSY_PERCENT:g} GB/s per percent (calibrated on streamed "
+                         "reads / writes / copies of 1 GiB and on Infinity-Cache-resident re-reads, which read 0 %: profiles/r06_umc_calib.md); "
+                         "fabric_bytes = the L2s' requests to local memory per iteration from the live counter pass, Infinity-Cache hits "
+                         "included; mall_served_frac = 1 - HBM / fabric"}
+        if roof:
+            roof["hbm_achieved_GBs"] = hbm["achieved_GBs"]
+            roof["hbm_bytes"] = int(rate * 1e9 * roof["avg_launch_us"] * 1e-6)       # HBM bytes delivered chip-wide during one launch's duration
+            roof["mall_served_frac"] = hbm["mall_served_frac"]
+            roof["hbm_note"] = ("hbm_achieved_GBs: what the memory controllers delivered while whole iterations ran back to back (see 'hbm'); "
+                                "hbm_bytes = that rate x this kernel's average launch duration -- an upper bound of its own share, the "
+                                "length classes run side by side; mall_served_frac: of the bytes the L2s asked local memory for per "
+                                "iteration, the part the Infinity Cache served")
     passes = (1 + (inner["cg_v"] + inner["ls_v"]) / steps) + (1 + (inner["cg_u"] + inner["ls_u"]) / steps / max(d1, 1))
     # SURVEY 8d, the whole-iteration figure: compulsory bytes W of one outer iteration with ideal caching (esz-byte factors,
     # int32 item, uint8 level, esz-byte m, uint32 permutation) at the EXECUTED inner counts, over the measured time per
@@ -637,8 +743,10 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False, live=No
                     "vector_bytes": int(d2 * ld * esz), "vector_allreduces_per_step": round(1 + n_cg, 2),
                     "scalar_allreduces_per_step": round(per_step - (1 + n_cg) * wl.get("n_rng", 1), 2),
                     "us_per_step": round(1e3 * ms / n * per_step, 1), "share_of_step": round(ms / n * per_step / (1e3 * secs / steps), 4)}
+    if hbm:
+        hbm["algorithmic_bytes_per_iteration"] = int(W)
     return dict(roofline=roof, roofline_phase=roof_phase, roofline_iteration=it_roof, gather=gather, kernels=kernels,
-                passes_per_step=passes, exchange=exchange)
+                passes_per_step=passes, exchange=exchange, hbm=hbm)
 
 
 def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=("f32", "f64"), profile=True, cpu=True,
@@ -686,12 +794,12 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
     run = runs[main_p]
     secs, objs, inner = run["secs"], run["objs"], run["inner"]
     tkey = f"{shape}:{main_p}" if (users is None and nnz is None and N == 1 and r == (200 if shape == "yahoo" else 100)) else None
-    live, live_note = None, None
-    if args.live_traffic and N == 1 and profile and tkey and shape == "ml1m":
-        live, took = live_traffic(shape, main_p, r)
-        live_note = f"{took:.0f} s for the two passes" if live else f"not available ({took}): stored passes used"
-        log(f"[traffic] live rocprofv3 --pmc passes: {live_note}")
-    an = analyse(run, run["rows"], wl, main_p, N, tkey, verbose, live)
+    live, live_iters = None, 0
+    if args.live_traffic and N == 1 and profile and tkey:
+        lt_steps, lt_warm = (10, 5) if shape == "ml1m" else (3, 1)
+        live, live_iters, took = live_traffic(shape, main_p, r, lt_steps, lt_warm, timeout_s=170 if shape == "ml1m" else 600)
+        log("[traffic] live rocprofv3 --pmc pass: " + (f"{took:.0f} s, {live_iters} iterations replayed" if live else f"not available ({took}): stored passes used"))
+    an = analyse(run, run["rows"], wl, main_p, N, tkey, verbose, live, live_iters)
     value = n_pairs * steps / secs
     rec = {
         "value": value, "unit": "pairs/s", "ms_per_step": 1e3 * secs / steps, "s_per_iter": secs / steps, "steps": steps, "warmup": warmup,
@@ -711,22 +819,22 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
         "comm_nranks": run["comm_nranks"], "shards": bounds, "exchange_profile": an["exchange"],
         "cold_start": run["cold"], "ms_per_step_first5": run["cold"]["ms_per_step"] if run["cold"] and run["cold"]["iterations"] == 5 else None,
         "roofline": an["roofline"], "roofline_phase": an["roofline_phase"], "roofline_iteration": an["roofline_iteration"],
-        "gather": an["gather"], "kernels": an["kernels"],
+        "gather": an["gather"], "kernels": an["kernels"], "hbm": an["hbm"],
     }
     if "f64" in runs and main_p == "f32":
         # the reference computes in fp64 throughout: the same K steps with fp64 storage, same clock, same barriers
         r64 = runs["f64"]
-        live64 = None
-        if live:                                   # (the fp32 passes worked on this box: the same two passes for the fp64 leg)
-            live64, took = live_traffic(shape, "f64", r)
-            log(f"[traffic] live rocprofv3 --pmc passes, fp64 leg: " + (f"{took:.0f} s" if live64 else f"not available ({took}): stored passes used"))
-        a64 = analyse(r64, r64["rows"], wl, "f64", N, f"{shape}:f64" if tkey else None, live=live64)
+        live64, live64_iters = None, 0
+        if live and shape == "ml1m":               # (the fp32 pass worked on this box: the same pass for the fp64 leg)
+            live64, live64_iters, took = live_traffic(shape, "f64", r)
+            log(f"[traffic] live rocprofv3 --pmc pass, fp64 leg: " + (f"{took:.0f} s" if live64 else f"not available ({took}): stored passes used"))
+        a64 = analyse(r64, r64["rows"], wl, "f64", N, f"{shape}:f64" if tkey else None, live=live64, live_iters=live64_iters)
         rec["f64"] = {"dtype": "f64", "ms_per_step": 1e3 * r64["secs"] / steps,
                       "ms_per_step_noevents": None if not r64.get("secs_noevents") else 1e3 * r64["secs_noevents"] / steps, "value": n_pairs * steps / r64["secs"], "cold_start": r64["cold"],
                       "unit": "pairs/s", "ndcg10_test": r64["te"][1], "pairwise_error_test": r64["te"][0],
                       "objective": r64["objs"][-1], "inner_per_step": {k: v / steps for k, v in r64["inner"].items()},
                       "roofline": a64["roofline"], "roofline_phase": a64["roofline_phase"], "roofline_iteration": a64["roofline_iteration"],
-                      "gather": a64["gather"], "kernels": a64["kernels"],
+                      "gather": a64["gather"], "kernels": a64["kernels"], "hbm": a64["hbm"],
                       "note": "second timed run of the same workload with U, V, m and the CG vectors stored in fp64 (the reference's "
                               "arithmetic type); 'value' above is the fp32-storage / fp64-accumulation run the north star allows "
                               "('within fp32 tolerance')"}
@@ -785,7 +893,17 @@ def _roof(rf):
             "avg_launch_us": rf.get("avg_launch_us"), "launches_timed": rf.get("launches_timed"),
             "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"), "share_of_gpu_time": rf.get("share_of_gpu_time"),
             "binding": {"level": b.get("level"), "ceiling_GBs": b.get("ceiling_GBs"), "achieved_GBs": b.get("achieved_GBs"),
-                        "frac": b.get("frac")} if b else None}
+                        "frac": b.get("frac")} if b else None,
+            "hbm_achieved_GBs": rf.get("hbm_achieved_GBs"), "hbm_bytes": rf.get("hbm_bytes"), "mall_served_frac": rf.get("mall_served_frac")}
+
+
+def _hbm(h):
+    """The HBM side of an iteration, in six numbers."""
+    if not h:
+        return None
+    return {"busy_percent": h.get("busy_percent"), "achieved_GBs": h.get("achieved_GBs"), "frac": h.get("frac"),
+            "bytes_per_iteration": h.get("bytes_per_iteration"), "fabric_bytes_per_iteration": h.get("fabric_bytes_per_iteration"),
+            "mall_served_frac": h.get("mall_served_frac")}
 
 
 def _cpu(cb):
@@ -848,6 +966,7 @@ def compact_line(full, full_record_path=None):
                                   "frac": it.get("frac")} if it else None
     line["gather"] = {"level": ga.get("level"), "half_passes": ga.get("half_passes_per_iteration"), "achieved_GBs": ga.get("achieved_GBs"),
                       "ceiling_GBs": ga.get("ceiling_GBs"), "frac": ga.get("frac"), "u_side_counted": ga.get("u_side_counted", True)} if ga else None
+    line["hbm"] = _hbm(g("hbm"))
     line["roofline_phase"] = _phases(g("roofline_phase"))
     line["top_kernels"] = _top_kernels(g("kernels"))
     line["profile_overhead_pct"] = _r(g("profile_overhead_pct"), 3)
@@ -868,7 +987,7 @@ def compact_line(full, full_record_path=None):
                        "roofline_phase": {k: {"wall_us": v.get("wall_us_per_step"), "frac": v.get("frac")}
                                           for k, v in (f64.get("roofline_phase") or {}).items()} or None,
                        "roofline_iteration_frac": it64.get("frac"),
-                       "gather_frac": (f64.get("gather") or {}).get("frac")}
+                       "gather_frac": (f64.get("gather") or {}).get("frac"), "hbm": _hbm(f64.get("hbm"))}
     nf = g("netflix")
     if nf and nf.get("error"):
         line["netflix"] = {"error": str(nf["error"])[:300]}          # the second leg failed: the headline above stands
@@ -882,6 +1001,7 @@ def compact_line(full, full_record_path=None):
                                         "traffic_over_algorithmic": rf.get("traffic_over_algorithmic")} if rf else None,
                            "roofline_iteration_frac": (nf.get("roofline_iteration") or {}).get("frac"),
                            "gather": {"level": (nf.get("gather") or {}).get("level"), "frac": (nf.get("gather") or {}).get("frac")},
+                           "hbm": _hbm(nf.get("hbm")),
                            "f64_ms_per_step": _r(nf64.get("ms_per_step"), 6),
                            # (timed on a user prefix of the shape: compare pairs/s, not s_per_iter with ms_per_step)
                            "cpu_baseline": {"value": _r(ncb.get("value"), 6), "cores": ncb.get("cores"), "kind": ncb.get("kind"),
@@ -894,7 +1014,7 @@ def compact_line(full, full_record_path=None):
             nb["workload"] = nf.get("workload_short") or f"configs[3] Netflix-shaped, k=100, user-sharded x{g('n_gpus')}"
             for drop in ("cpu_baseline", "speedup_vs_cpu_baseline", "f64_ms_per_step", "solver_create_s"):
                 nb.pop(drop, None)
-            nb.update({"scaling": nf.get("scaling"), "comm_nranks": nf.get("comm_nranks"),
+            nb.update({"scaling": nf.get("scaling"), "comm_nranks": nf.get("comm_nranks"), "objective": _r(nf.get("objective"), 9),
                        "shards": nf.get("shards") if nf.get("shards") and len(nf["shards"]) <= 8 else None, "exchange": nf.get("exchange_profile")})
     cli = g("cli")
     if cli:
@@ -908,6 +1028,9 @@ def compact_line(full, full_record_path=None):
     size = lambda: len(json.dumps(line, separators=(",", ":")))
     if size() >= LINE_CAP and len(cfg.get("workload") or "") > 240:
         cfg["workload"] = cfg["workload"][:240]
+    for drop in ("hbm_achieved_GBs", "hbm_bytes", "mall_served_frac"):          # (the f64 leg's roofline repeats them in its own 'hbm')
+        if f64 and line.get("f64", {}).get("roofline"):
+            line["f64"]["roofline"].pop(drop, None)
     for victim in ("top_kernels", "roofline_phase", "shards", "inner_per_step", "gather", "roofline_iteration", "cold_start", "exchange",
                    "cli", "netflix", "f64"):
         if size() < LINE_CAP:
@@ -1123,6 +1246,8 @@ def main():
     ap.add_argument("--no-live-traffic", dest="live_traffic", action="store_false",
                     help="do not start the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic on this box "
                          "(default N = 1 ml1m run only; the stored passes of profiles/ are used instead)")
+    ap.add_argument("--no-hbm", dest="hbm", action="store_false",
+                    help="skip the sustained replay (>= 1 s of iterations) beside which the memory controllers' activity is sampled: the HBM side of the roofline")
     ap.add_argument("--full-line", action="store_true", help="developer tools only: print the full record as the stdout line (tens of KB)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--fault-netflix", type=int, default=None, help="test hook: that rank raises inside the Netflix-shaped leg of an N > 1 run (the line must "

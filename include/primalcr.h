@@ -195,6 +195,11 @@ int pcr_partition_users(const int64_t *index, int64_t d1, int nparts, int64_t *b
  *                   fine-grained device memory for its exchange boxes, EVERY rank takes the host-synchronised path.)
  *   p2p_timeout_ms  wall-clock deadline of one device-driven exchange (default 20000): a rank whose peers do not arrive in time
  *                   reports PCR_ERR_COMM, poisons its answers (no rank consumes a made-up sum) and raises the job's error flag
+ *   p2p_queue_budget   hardware queues one device maps at once for all its processes (default 24: gfx950 under the kernel driver's
+ *                   scheduler; 8 of them are left to processes this job cannot see).  Only matters when several ranks SHARE a device
+ *                   (a rehearsal): every rank publishes the queues its process holds; past the budget kernels of different processes
+ *                   no longer run side by side (0.5 us -> 7-11 ms per dependent hand-off, tools/ubench/queue_budget_probe.hip), so
+ *                   the device-driven exchange is switched off for the whole job (host-synchronised exchange, one line on stderr)
  *   count_rows      1 = the U-step kernels count the rows of V they gather (pcr_solver_counter; a diagnostic that
  *                   costs the short-user classes 10-20 %, so off by default)
  *   debug           1 = print launch decisions to stderr

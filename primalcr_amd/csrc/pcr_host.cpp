@@ -351,7 +351,7 @@ extern "C" int pcr_dataset_from_csr(int64_t d1, int64_t d2, const int64_t* index
 static std::map<std::string, std::string>& tune_table() { static thread_local std::map<std::string, std::string> t; return t; }
 static const char* const TUNE_KEYS[] = {"ustep_mode", "cluster_k", "cluster_users", "ubins", "ustep_gram", "spmm_tiles", "spmm_chunk", "sddmm_csc",
                                         "lanes", "pipeline", "window_cache", "prepare_merged", "resort_window", "allreduce_chunks", "p2p_ll",
-                                        "p2p_timeout_ms", "count_rows", "debug", "win16", "ustep_win_lds", "plan_key64", "ustep_newton", "vblock_users", "fault_cluster_member", "fault_p2p_skip", "fault_p2p_coarse", nullptr};
+                                        "p2p_timeout_ms", "p2p_queue_budget", "count_rows", "debug", "win16", "ustep_win_lds", "plan_key64", "ustep_newton", "vblock_users", "fault_cluster_member", "fault_p2p_skip", "fault_p2p_coarse", nullptr};
 extern "C" int pcr_tune(const char* key, const char* value) {
     if (!key) { pcr_set_error("pcr_tune: null key"); return PCR_ERR_ARG; }
     bool known = false;

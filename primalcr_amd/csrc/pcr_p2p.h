@@ -55,7 +55,16 @@
 
 #define PCR_P2P_MAXR 16
 
-#define PCR_P2P_MAGIC 0x50435250325035ull     // "PCRP2P5"
+#define PCR_P2P_MAGIC 0x50435250325036ull     // "PCRP2P6"
+// Hardware queues one device maps at once for all its processes (gfx950 under the kernel driver's firmware scheduler: 4 pipes x
+// 8 queues of the first compute micro-engine, 8 of them the kernel driver's own).  Past it the scheduler time-slices the queues
+// -- waves are saved and restored -- and kernels that WAIT FOR EACH OTHER (k_p2p_ll) advance one phase per rotation instead of
+// per microsecond: tools/ubench/queue_budget_probe.hip, NOTES.md round 6.  Ranks that share a device publish what they hold; a
+// device over this budget sends every rank to the host-synchronised exchange, which needs no two kernels resident together.
+#define PCR_P2P_QUEUE_BUDGET 24
+// ... of which this many are left to whoever else is on the device and cannot be seen from here (a host application's other HIP
+// contexts, a test runner's: their idle queues take slots too)
+#define PCR_P2P_QUEUE_RESERVE 8
 struct P2PCtl {                               // in POSIX shared memory, created (O_EXCL) and zero-filled by rank 0
     std::atomic<uint64_t> magic;              // written LAST by rank 0: the block is ready
     uint64_t created_ns;                      // CLOCK_REALTIME at creation: a block older than the rendezvous time-out is a dead job's
@@ -68,6 +77,8 @@ struct P2PCtl {                               // in POSIX shared memory, created
     hipIpcMemHandle_t ll_handle[PCR_P2P_MAXR];        // the boxes of the device-driven exchange (an allocation of their own)
     uint64_t ll_bytes[PCR_P2P_MAXR];
     uint32_t ll_ok[PCR_P2P_MAXR];                     // 1 = that rank holds FINE-GRAINED boxes (written before posted[] is raised)
+    uint32_t queues[PCR_P2P_MAXR];                    // hardware queues that rank's process holds on its device (before posted[] too)
+    char bus[PCR_P2P_MAXR][24];                       // PCI address of that rank's device: equal strings = one GPU shared
 };
 
 template <typename X> struct P2PPtrs { const X* p[PCR_P2P_MAXR]; };
@@ -105,7 +116,13 @@ __device__ __forceinline__ void ll_put(unsigned long long* dst, double v, unsign
     __hip_atomic_store(dst + 1, ((unsigned long long)seq << 32) | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 #define PCR_LL_POISON 0x80000000u              // top bit of a word's tag: "the rank that owed this word gave up" (seq stays below it)
-struct LLWait { long long deadline; bool dead; };      // per thread: wall_clock64 deadline of the kernel; dead = it has failed
+// per thread: wall_clock64 deadline of the kernel; dead = it has failed; phase / peer / idx = what it is waiting for (1 = rank
+// `peer`'s contribution to element idx of this rank's slice, 2 = owner `peer`'s answer for element idx)
+struct LLWait { long long deadline; bool dead; int phase, peer; long long idx; };
+// err[0] = raised; err[1..3] = phase, peer and element of the FIRST wait of this rank that failed; phase 3 = it met a poison word
+// (the peer had given up first).  Pinned host memory, written at system scope; the detail is a diagnosis, not a protocol word: two
+// threads failing in the same microsecond may both write it.
+#define PCR_LL_ERR_WORDS 4
 // one word carrying this call's seq -- or 0 with the thread dead and *err raised: the deadline passed, the word is poisoned, or
 // another thread of this rank has already failed.  A dead thread returns at once.
 __device__ __forceinline__ unsigned ll_word(const unsigned long long* src, unsigned seq, int* err, LLWait& w) {
@@ -114,9 +131,14 @@ __device__ __forceinline__ unsigned ll_word(const unsigned long long* src, unsig
         const unsigned long long x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned tag = (unsigned)(x >> 32);
         if (tag == seq) return (unsigned)x;
-        if (tag == (seq | PCR_LL_POISON) ||
-            // (every 4096 polls, ~0.4 ms: the error word lives in pinned HOST memory -- thousands of waiting threads must not read it often)
-            ((spins & 4095u) == 0 && ((long long)wall_clock64() - w.deadline > 0 || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0))) {
+        const bool poison = tag == (seq | PCR_LL_POISON);
+        // (every 4096 polls, ~0.4 ms: the error word lives in pinned HOST memory -- thousands of waiting threads must not read it often)
+        if (poison || ((spins & 4095u) == 0 && ((long long)wall_clock64() - w.deadline > 0 || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0))) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {          // the first failure of this rank says what it waited for
+                __hip_atomic_store(err + 1, poison ? 3 : w.phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(err + 2, w.peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(err + 3, (int)(w.idx & 0x7fffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             w.dead = true;
             return 0u;
@@ -138,19 +160,23 @@ __global__ __launch_bounds__(256) void k_p2p_ll(X* __restrict__ buf, int64_t n, 
                                                 P2PLLPtrs ll, unsigned seq, int* err, long long budget_ticks) {
     constexpr int W = LLWords<X>::W;
     const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x, dt = (int64_t)gridDim.x * 256;
-    LLWait wt{(long long)wall_clock64() + budget_ticks, false};
+    LLWait wt{(long long)wall_clock64() + budget_ticks, false, 0, 0, 0};
     for (int64_t i = t0; i < n; i += dt) {                                           // scatter
         const int64_t q = i / per;
         ll_put(ll.inbox[q] + ((int64_t)me * box_stride + (i - q * per)) * W, buf[i], seq);
     }
     const int64_t lo = per * me < n ? per * me : n, hi = lo + per < n ? lo + per : n;
     for (int64_t j = lo + t0; j < hi; j += dt) {                                     // reduce my slice, answer everybody
+        wt.phase = 1; wt.peer = 0; wt.idx = j;
         X s = ll_get(ll.inbox[me] + (j - lo) * W, seq, err, wt, X());
-        for (int r = 1; r < nranks; ++r) s += ll_get(ll.inbox[me] + ((int64_t)r * box_stride + (j - lo)) * W, seq, err, wt, X());
+        for (int r = 1; r < nranks; ++r) { wt.peer = r; s += ll_get(ll.inbox[me] + ((int64_t)r * box_stride + (j - lo)) * W, seq, err, wt, X()); }
         // (a dead thread has no sum: it answers with poison, so that every rank fails this call instead of consuming garbage)
         for (int p = 0; p < nranks; ++p) ll_put(ll.outbox[p] + j * W, wt.dead ? X(0) : s, wt.dead ? (seq | PCR_LL_POISON) : seq);
     }
-    for (int64_t i = t0; i < n; i += dt) buf[i] = ll_get(ll.outbox[me] + i * W, seq, err, wt, X());      // gather
+    for (int64_t i = t0; i < n; i += dt) {                                           // gather
+        wt.phase = 2; wt.peer = (int)(i / per); wt.idx = i;
+        buf[i] = ll_get(ll.outbox[me] + i * W, seq, err, wt, X());
+    }
 }
 
 struct P2PComm {
@@ -168,6 +194,12 @@ struct P2PComm {
     bool fault_coarse = false;                // test hook (pcr_tune "fault_p2p_coarse"): pretend the fine-grained allocation failed on this rank
     bool debug = false;
     int ll_calls = 0;
+    // what this rank's process holds on its device, for the budget ranks that share a device must keep (PCR_P2P_QUEUE_BUDGET)
+    int my_queues = 1;
+    int queue_budget = PCR_P2P_QUEUE_BUDGET;
+    int ranks_on_my_device = 1, queues_on_my_device = 1;
+    bool ll_off_by_budget = false;            // the device-driven exchange was switched off for the whole job by that budget
+    std::string note;                         // ... and why, in words (pcr_solver_comm_init_p2p prints it once, on rank 0)
     std::string err;
     // device-driven exchange (k_p2p_ll): two box sets in this rank's buffer, one for vectors of at most ll_elems elements of elt
     // bytes, one for the scalars; per-set sequence numbers; an error word the kernels raise, in pinned host memory
@@ -268,8 +300,8 @@ struct P2PComm {
             ll_outofs[0] = ll_off[0] + (size_t)nranks * ll_per * W * 8;
             ll_off[1] = (ll_outofs[0] + ll_elems * W * 8 + 255) & ~(size_t)255;
             ll_outofs[1] = ll_off[1] + (size_t)nranks * sper * 2 * 8;
-            if (hipHostMalloc((void**)&ll_err, sizeof(int)) != hipSuccess) return fail("hipHostMalloc of the exchange's error word failed");
-            *ll_err = 0;
+            if (hipHostMalloc((void**)&ll_err, PCR_LL_ERR_WORDS * sizeof(int)) != hipSuccess) return fail("hipHostMalloc of the exchange's error word failed");
+            for (int w = 0; w < PCR_LL_ERR_WORDS; ++w) ll_err[w] = 0;
         }
         if (hipMalloc((void**)&xbuf, total_bytes()) != hipSuccess) return fail("hipMalloc of the exchange buffer failed");
         if (hipMemset(xbuf, 0, total_bytes()) != hipSuccess) return fail("hipMemset of the exchange buffer failed");
@@ -296,6 +328,14 @@ struct P2PComm {
         // an environment prerequisite of the ROCm runtime, listed in include/primalcr.h; the library itself reads no variable)
         if (hipIpcGetMemHandle(&ctl->handle[rank], xbuf) != hipSuccess) return fail("hipIpcGetMemHandle failed (on dmabuf-only hosts run with HSA_ENABLE_IPC_MODE_LEGACY=0)");
         ctl->bytes[rank] = total_bytes();
+        {   // which GPU this rank is on and what it holds there (ranks that share a GPU share its hardware queues)
+            char bus[24] = {};
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess || !bus[0]) snprintf(bus, sizeof bus, "rank-%d", rank);
+            bus[sizeof bus - 1] = 0;
+            memcpy(ctl->bus[rank], bus, sizeof bus);
+            ctl->queues[rank] = (uint32_t)std::max(1, my_queues);
+        }
         ctl->posted[rank].store(1, std::memory_order_release);
         const auto t0 = std::chrono::steady_clock::now();
         for (int r = 0; r < nranks; ++r)
@@ -304,6 +344,24 @@ struct P2PComm {
                 if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return fail("rendezvous timed out");
                 std::this_thread::yield();
             }
+        {   // (posted[] was raised after bus[] / queues[]: every rank computes the same sums from the same words)
+            int worst_n = 1, worst_q = 0, worst_r = rank;
+            for (int a = 0; a < nranks; ++a) {
+                int n_same = 0, q_sum = 0;
+                for (int b = 0; b < nranks; ++b)
+                    if (strncmp(ctl->bus[a], ctl->bus[b], sizeof ctl->bus[a]) == 0) { ++n_same; q_sum += (int)ctl->queues[b]; }
+                if (a == rank) { ranks_on_my_device = n_same; queues_on_my_device = q_sum; }
+                if (n_same > 1 && q_sum > worst_q) { worst_n = n_same; worst_q = q_sum; worst_r = a; }
+            }
+            if (worst_n > 1 && worst_q > queue_budget - PCR_P2P_QUEUE_RESERVE && ll_max_bytes) {
+                ll_max_bytes = 0;
+                ll_off_by_budget = true;
+                char bus[25] = {};
+                memcpy(bus, ctl->bus[worst_r], 24);
+                note = std::to_string(worst_n) + " ranks share device " + bus + " and hold " + std::to_string(worst_q) + " hardware queues on it together (the device maps " +
+                       std::to_string(queue_budget) + " at once, " + std::to_string(PCR_P2P_QUEUE_RESERVE) + " are left to other processes): kernels that wait for each other are not guaranteed to run side by side there -- every exchange of this job is host-synchronised";
+            }
+        }
         if (ll_max_bytes) {       // posted[] was raised after ll_ok[]: every rank takes the same decision from the same words
             bool all_ok = true;
             for (int r = 0; r < nranks; ++r) all_ok = all_ok && ctl->ll_ok[r] == 1;
@@ -395,8 +453,16 @@ struct P2PComm {
     bool exchange_failed() { if (ll_err && *ll_err) { fail(timeout_text()); return true; } return false; }
     // (how far this rank had come says which exchange the job stalled in: the counts are the same on every rank of a healthy job)
     std::string timeout_text() const {
+        std::string what;
+        if (ll_err) {
+            const int phase = ll_err[1], peer = ll_err[2], idx = ll_err[3];
+            if (phase == 1) what = "; first missing word: rank " + std::to_string(peer) + "'s contribution to element " + std::to_string(idx) + " of this rank's slice (that rank's kernel never stored it)";
+            else if (phase == 2) what = "; first missing word: owner rank " + std::to_string(peer) + "'s sum for element " + std::to_string(idx) + " (that rank's kernel never answered)";
+            else if (phase == 3) what = "; a peer's poison word arrived first (rank " + std::to_string(peer) + " was the one waited for: it, or a rank it waited for, had given up)";
+        }
         return "a device-driven exchange timed out waiting for a peer rank (rank " + std::to_string(rank) + " of " + std::to_string(nranks) + " had launched " +
-               std::to_string(ll_seq[0]) + " vector and " + std::to_string(ll_seq[1]) + " scalar exchanges; deadline " + std::to_string((int)(ll_timeout_s * 1e3)) + " ms)";
+               std::to_string(ll_seq[0]) + " vector and " + std::to_string(ll_seq[1]) + " scalar exchanges; deadline " + std::to_string((int)(ll_timeout_s * 1e3)) + " ms" +
+               what + "; " + std::to_string(ranks_on_my_device) + " rank(s) on this device holding " + std::to_string(queues_on_my_device) + " hardware queues)";
     }
 
     // Closing rendezvous: the last all-reduce launched its reduce / gather kernel asynchronously after its last host barrier, so a

@@ -151,7 +151,7 @@ struct pcr_solver {
 struct Tune {
     int lanes = 0, spmm_chunk = 0, spmm_tiles = 0, sddmm_csc = -1, ustep_mode = 0, cluster_k = 4, cluster_users = 0, window_cache = 1,
         prepare_merged = -1, pipeline = 1, debug = 0, fault_cluster_member = 0, ustep_gram = -1, count_rows = 0, allreduce_chunks = 0,
-        resort_window = 8, p2p_ll = 16, p2p_timeout_ms = 20000, fault_p2p_skip = 0, fault_p2p_coarse = 0, win16 = 1, ustep_win_lds = 1, plan_key64 = 0, ustep_newton = 0, vblock_users = 0;
+        resort_window = 8, p2p_ll = 16, p2p_timeout_ms = 20000, p2p_queue_budget = 0, fault_p2p_skip = 0, fault_p2p_coarse = 0, win16 = 1, ustep_win_lds = 1, plan_key64 = 0, ustep_newton = 0, vblock_users = 0;
     std::string ubins;
     void read() {
         lanes = pcr_tune_int("lanes", 0); spmm_chunk = pcr_tune_int("spmm_chunk", 0); spmm_tiles = pcr_tune_int("spmm_tiles", 0);
@@ -163,7 +163,7 @@ struct Tune {
         allreduce_chunks = pcr_tune_int("allreduce_chunks", 0);
         resort_window = pcr_tune_int("resort_window", 8); p2p_ll = pcr_tune_int("p2p_ll", 16);
         p2p_timeout_ms = pcr_tune_int("p2p_timeout_ms", 20000); fault_p2p_skip = pcr_tune_int("fault_p2p_skip", 0);
-        fault_p2p_coarse = pcr_tune_int("fault_p2p_coarse", 0);
+        fault_p2p_coarse = pcr_tune_int("fault_p2p_coarse", 0); p2p_queue_budget = pcr_tune_int("p2p_queue_budget", 0);
         win16 = pcr_tune_int("win16", 1); ustep_win_lds = pcr_tune_int("ustep_win_lds", 1); plan_key64 = pcr_tune_int("plan_key64", 0); ustep_newton = pcr_tune_int("ustep_newton", 0); vblock_users = pcr_tune_int("vblock_users", 0);
         ubins.clear(); pcr_tune_get("ubins", &ubins);
     }
@@ -2141,11 +2141,26 @@ struct Solver final : pcr_solver {
         p2p->ll_timeout_s = std::max(1, tune.p2p_timeout_ms) / 1e3;
         p2p->fault_skip_call = rank == nranks - 1 ? tune.fault_p2p_skip : 0; p2p->fault_coarse = rank == nranks - 1 && tune.fault_p2p_coarse != 0;     // (test hooks: the last rank misbehaves)
         p2p->debug = tune.debug != 0;
+        {   // Hardware queues this process holds on its device: the runtime folds the streams of one priority onto at most 4 hardware
+            // queues; the null stream (memsets, synchronous copies) is a normal-priority stream, and the runtime keeps a queue of its
+            // own for copy kernels.  Published in the control block: ranks that share a GPU share its 24 queue slots (pcr_p2p.h).
+            int normal = 2 + (ar_st ? 1 : 0), high = (hi ? 1 : 0) + (int)hi_spare.size();
+            for (int i = 0; i < NSIDE; ++i) normal += side[i] ? 1 : 0;
+            p2p->my_queues = std::min(4, normal) + std::min(4, high) + 1;
+            if (tune.p2p_queue_budget > 0) p2p->queue_budget = tune.p2p_queue_budget;
+        }
         if (!p2p->init(shm_name, rank, nranks, (size_t)d2 * geo.ld, sizeof(T), (size_t)std::max(0, tune.p2p_ll) << 20)) {
             pcr_set_error("p2p communicator: " + p2p->err);
             p2p.reset();
             return PCR_ERR_COMM;
         }
+        if (p2p->ranks_on_my_device > 1 && nlane > 1) {
+            // peers on this GPU (a rehearsal of the N-rank job on fewer GPUs): keep to the solver's stream -- length classes of several
+            // ranks side by side on one device's CUs gain nothing, and every lane is a hardware queue the ranks have to share
+            nlane = 1;
+            if (tune.debug) fprintf(stderr, "[pcr] p2p rank %d: %d ranks on this device -- the U step's classes stay on the solver's stream\n", rank, p2p->ranks_on_my_device);
+        }
+        if (!p2p->note.empty() && rank == 0) fprintf(stderr, "[pcr] p2p: %s\n", p2p->note.c_str());
         return PCR_OK;
     }
     // a rank that fails leaves the job: its peers must not wait for it

@@ -34,6 +34,8 @@ inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static thread_local const char* g_mock_bus = "0000:05:00.0";        // the harness gives every "rank" (thread) its device
+inline hipError_t hipDeviceGetPCIBusId(char* b, int n, int) { strncpy(b, g_mock_bus, (size_t)n - 1); b[n - 1] = 0; return hipSuccess; }
 inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 100000; return hipSuccess; }
 inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) { memset(h, 0, sizeof *h); memcpy(h->reserved, &p, sizeof p); return hipSuccess; }
 inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) { memcpy(p, h.reserved, sizeof *p); return hipSuccess; }

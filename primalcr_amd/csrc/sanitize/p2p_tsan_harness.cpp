@@ -9,7 +9,11 @@
 //      vector all-reduces on the host-synchronised path (four barriers each), finalize, destroy;
 //   2. the same with one rank reporting an error mid-way: every other rank must leave its barrier with an error, none may hang;
 //   3. a rank that never shows up: the others time out of the rendezvous;
-//   4. 8 ranks (the target machine) and 16 (the control block's table size) through scenario 1; 17 ranks are refused.
+//   4. 8 ranks (the target machine) and 16 (the control block's table size) through scenario 1; 17 ranks are refused;
+//   5. the queue budget of ranks that share a device (NOTES.md round 6: past 24 hardware queues per GPU, kernels of different
+//      processes stop running side by side): 4 ranks on one device holding 9 queues each -> every rank switches the
+//      device-driven exchange off and says why; 4 x 4 queues -> it stays on; 8 ranks on 8 devices holding 9 each -> on;
+//      two devices, one of them shared by three ranks over the budget -> off on EVERY rank (one decision per job).
 // Exit code 0 and no "WARNING: ThreadSanitizer" on stderr = clean (tests/test_sanitizers.py).
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -75,8 +79,40 @@ static int run_job(const char* name, int N, int fail_rank, int absent_rank, doub
     return ok.load() * 100 + failed.load();
 }
 
+// scenario 5: ranks as threads, each on the device `bus_of(r)` with `queues` hardware queues; returns how many ranks ended with the
+// device-driven exchange ON (x 100) + how many carry the budget's note
+static int run_budget(const char* name, int N, int queues, const char* (*bus_of)(int)) {
+    std::vector<std::thread> th;
+    std::atomic<int> on{0}, noted{0}, failed{0};
+    for (int r = 0; r < N; ++r)
+        th.emplace_back([&, r]() {
+            g_mock_bus = bus_of(r);
+            P2PComm c;
+            c.timeout_s = 30.0;
+            c.my_queues = queues;
+            if (!c.init(name, r, N, 1000, 4, (size_t)1 << 20)) { failed++; return; }
+            if (c.ll_max_bytes) on++;
+            if (c.ll_off_by_budget && !c.note.empty() && c.note.find("hardware queues") != std::string::npos) noted++;
+        });
+    for (auto& t : th) t.join();
+    fprintf(stderr, "[harness] %-28s ranks %d x %d queues: device-driven exchange on for %d, switched off by the budget on %d, %d failed\n", name, N, queues,
+            on.load(), noted.load(), failed.load());
+    return failed.load() ? -1 : on.load() * 100 + noted.load();
+}
+static const char* one_device(int) { return "0000:05:00.0"; }
+static const char* own_device(int r) {
+    static const char* b[16] = {"0000:05:00.0", "0000:15:00.0", "0000:25:00.0", "0000:35:00.0", "0000:45:00.0", "0000:55:00.0", "0000:65:00.0", "0000:75:00.0",
+                                "0000:85:00.0", "0000:95:00.0", "0000:a5:00.0", "0000:b5:00.0", "0000:c5:00.0", "0000:d5:00.0", "0000:e5:00.0", "0000:f5:00.0"};
+    return b[r & 15];
+}
+static const char* three_and_one(int r) { return r < 3 ? "0000:05:00.0" : "0000:15:00.0"; }
+
 int main() {
     int bad = 0;
+    if (run_budget("/pcr_tsan_b1", 4, 9, one_device) != 4) bad |= 64;          // 36 queues on one GPU: off everywhere, every rank knows why
+    if (run_budget("/pcr_tsan_b2", 4, 4, one_device) != 400) bad |= 128;       // 16: within the budget less its reserve
+    if (run_budget("/pcr_tsan_b3", 8, 9, own_device) != 800) bad |= 256;       // one rank per GPU: nothing is shared, nothing is summed
+    if (run_budget("/pcr_tsan_b4", 4, 9, three_and_one) != 4) bad |= 512;      // 27 on the shared device: the whole job leaves the device-driven path
     {   // a dead job's block under the name: magic set, old creation time, an error flag, posted words
         const char* name = "/pcr_tsan_h1";
         shm_unlink(name);

@@ -90,9 +90,17 @@ def test_a_rank_that_dies_is_named_and_takes_the_job_down(n, fault, want):
 def test_two_ranks_on_one_gpu_equal_one_rank():
     users, nnz, r, steps, warmup = 2000, 250000, 100, 2, 1
     p = run_bench("--gpus", "2", "--comm", "p2p", "--devices", "0,0", "--rendezvous", "gloo", "--steps", str(steps), "--warmup",
-                  str(warmup), "--users", str(users), "--nnz", str(nnz), "--no-cpu", "--no-f64", "--all-legs")   # (--all-legs: with the row-counting replay)
+                  str(warmup), "--users", str(users), "--nnz", str(nnz), "--no-cpu", "--no-f64", "--all-legs",   # (--all-legs: with the row-counting replay)
+                  "--netflix-users", "6000", "--netflix-nnz", "600000")
     assert p.returncode == 0, p.stderr[-3000:]
+    assert len([l for l in p.stdout.strip().split("\n") if l.startswith("{")]) == 1          # ONE line per run, whatever the legs
     line = json.loads(p.stdout.strip().split("\n")[-1])
+    # configs[3] in the N > 1 line: the Netflix-shaped set cut into 2 nnz-balanced user ranges (strong scaling), its own exchange block
+    nf = line["netflix"]
+    assert "error" not in nf and nf["scaling"] == "strong" and nf["comm_nranks"] == 2 and nf["steps"] == 3 and nf["ms_per_step"] > 0 and nf["value"] > 0
+    assert len(nf["shards"]) == 2 and nf["shards"][0][0] == 0 and nf["shards"][1][0] == nf["shards"][0][1] and nf["shards"][0][1] + nf["shards"][1][1] == 6000
+    assert sum(sh[2] for sh in nf["shards"]) == 600000 and abs(nf["shards"][0][2] - 300000) < 6000           # balanced by ratings, not by users
+    assert nf["exchange"]["vector_bytes"] == 17770 * 100 * 4 and nf["exchange"]["allreduces_per_step"] >= 3 and "x2" in nf["workload"]
     assert line["n_gpus"] == 2 and line["comm_nranks"] == 2 and line["scaling"] == "weak" and line["config"]["exchange"] == "p2p"
     assert line["steps"] == steps and line["warmup"] == warmup
     assert line["shards"] == [[0, users, nnz], [users, users, nnz]]
@@ -128,6 +136,24 @@ def test_two_ranks_on_one_gpu_equal_one_rank():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
+def test_a_failing_netflix_leg_never_costs_the_headline():
+    """the second leg of an N > 1 run is wrapped -- a rank that fails inside it (the hook raises on rank 1, so
+    rank 0 is left waiting in the leg's first collective) yields netflix = {"error": ...} in the ONE line, with the ml1m record
+    (value, shards, exchange) intact and exit code 0; nobody is left on the GPU."""
+    import time
+    t0 = time.time()
+    p = run_bench("--gpus", "2", "--comm", "p2p", "--devices", "0,0", "--rendezvous", "gloo", "--steps", "2", "--warmup", "1", "--users", "800",
+                  "--nnz", "100000", "--no-cpu", "--no-f64", "--no-rows", "--netflix-users", "3000", "--netflix-nnz", "200000", "--fault-netflix", "1")
+    assert p.returncode == 0 and time.time() - t0 < 300, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] > 0 and line["n_gpus"] == 2 and line["comm_nranks"] == 2 and line["shards"] == [[0, 800, 100000], [800, 800, 100000]]
+    assert "fault hook" in line["netflix"]["error"] and "rank 1" in line["netflix"]["error"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
 def test_five_ranks_on_one_gpu_through_the_bench_launcher():
     """The widest job this pool lets a test start: its process guard allows 6 processes on the card, this pytest process holds
     one (NOTES.md, round 5: that guard -- 6 ranks + the torch.distributed.run agent = 7 -- is what ended round 4's 6-rank
@@ -136,7 +162,7 @@ def test_five_ranks_on_one_gpu_through_the_bench_launcher():
     one ONE solver reaches on the same 5 x 500 users."""
     n, users, nnz, steps, warmup = 5, 500, 60000, 2, 1
     p = run_bench("--gpus", str(n), "--comm", "p2p", "--devices", ",".join(["0"] * n), "--rendezvous", "gloo", "--steps", str(steps),
-                  "--warmup", str(warmup), "--users", str(users), "--nnz", str(nnz), "--no-cpu", "--no-f64", "--no-rows")
+                  "--warmup", str(warmup), "--users", str(users), "--nnz", str(nnz), "--no-cpu", "--no-f64", "--no-rows", "--no-netflix")
     assert p.returncode == 0, p.stderr[-3000:]
     assert f"starting {n} ranks (direct children" in p.stderr
     line = json.loads(p.stdout.strip().split("\n")[-1])
@@ -184,7 +210,7 @@ def test_two_ranks_under_the_drivers_launcher():
     scaling curve: bench.py is one of the ranks (RANK / WORLD_SIZE from the launcher), rank 0 prints the one line.  Two ranks on the
     one GPU through the peer-to-peer exchange; the line equals the one bench.py's own launcher gives for the same job."""
     common = ("--comm", "p2p", "--devices", "0,0", "--rendezvous", "gloo", "--steps", "2", "--warmup", "1", "--users", "800", "--nnz", "100000",
-              "--no-cpu", "--no-f64", "--no-rows")
+              "--no-cpu", "--no-f64", "--no-rows", "--netflix-users", "3000", "--netflix-nnz", "200000")
     a = run_bench_under_torchrun(2, *common)
     assert a.returncode == 0, a.stderr[-3000:]
     assert "starting 2 ranks" not in a.stderr
@@ -194,6 +220,8 @@ def test_two_ranks_under_the_drivers_launcher():
     lb = json.loads(b.stdout.strip().split("\n")[-1])
     for line in (la, lb):
         assert "error" not in line and line["n_gpus"] == 2 and line["comm_nranks"] == 2 and line["shards"] == [[0, 800, 100000], [800, 800, 100000]]
+        assert "error" not in line["netflix"] and line["netflix"]["comm_nranks"] == 2          # both launchers carry the strong-scaling leg
+    assert la["netflix"]["shards"] == lb["netflix"]["shards"] and la["netflix"]["objective"] == lb["netflix"]["objective"]
     assert la["objective"] == lb["objective"] and la["ndcg10_test"] == lb["ndcg10_test"] and la["inner_per_step"] == lb["inner_per_step"]
 
 
@@ -214,7 +242,7 @@ def test_two_physical_gpus_equal_one_rank(comm, chunks):
     where a second GPU exists: when there is one, hold them to the one-rank trajectory."""
     users, nnz, steps, warmup = 2000, 250000, 2, 1
     common = ["--steps", str(steps), "--warmup", str(warmup), "--users", str(users), "--nnz", str(nnz), "--no-cpu", "--no-f64", "--precision", "f64",
-              "--no-profile"]
+              "--no-profile", "--no-netflix"]
     two = run_bench("--gpus", "2", "--comm", comm, "--tune", f"allreduce_chunks={chunks}", *common)
     assert two.returncode == 0, two.stderr[-3000:]
     a = json.loads(two.stdout.strip().split("\n")[-1])
@@ -310,34 +338,50 @@ def test_stdout_line_is_compact_and_carries_what_the_driver_reads():
     assert small["roofline"] and small["cpu_baseline"] and "top_kernels" not in small and "roofline_phase" not in small
 
 
-def test_live_pmc_passes_are_summed_per_kernel_and_priced_per_launch(tmp_path):
-    """roofline.traffic of the default run comes from two rocprofv3 --pmc passes the bench starts itself: their per-dispatch CSVs are
-    summed per kernel symbol, divided by the dispatches of the pass (KiB -> bytes), and a slot is priced 2 x FETCH_SIZE + WRITE_SIZE
-    (MI355X_MICROARCH.md: gfx950 counts wide coalesced reads at half their bytes)."""
+def test_live_pmc_pass_is_summed_per_kernel_and_priced_per_launch(tmp_path):
+    """roofline.traffic of the default run comes from ONE rocprofv3 --pmc pass the bench starts itself (both 32-byte-unit counters,
+    byte-exact per profiles/r06_dram_calib.md): the per-dispatch CSV is summed per kernel symbol and divided by the dispatches; a
+    slot is priced 32 B x (reads + writes).  The HBM side comes from the memory controllers' activity beside a sustained replay:
+    busy % x 83 GB/s, bytes per iteration, and the part of the fabric-side bytes the Infinity Cache served."""
     import collections
     sys.path.insert(0, ROOT)
     import bench
     name = "void k_ustep<float, 256, false, 1, false, 4, 1>(Shard<float>, Geo, int const*)"
     head = "Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n"
     rows = lambda ctr, vals, kname=name: "".join(f'{i},{i},1,1,1,1,51200,7,"{kname}",256,0,0,128,0,96,{ctr},{v},0,1\n' for i, v in enumerate(vals, 1))
-    (tmp_path / "f.csv").write_text(head + rows("FETCH_SIZE", [4096, 4096, 4096 + 8]) + rows("FETCH_SIZE", [1], "k_nop()"))
-    (tmp_path / "w.csv").write_text(head + rows("WRITE_SIZE", [10240, 10240]))
+    (tmp_path / "p.csv").write_text(head + rows(bench.PMC_READ, [300000, 300000, 300000 + 96]) + rows(bench.PMC_WRITE, [320000, 320000, 320000]) +
+                                    rows(bench.PMC_READ, [4], "k_nop()") + rows(bench.PMC_WRITE, [0], "k_nop()"))
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
-    bench.pmc_accumulate(str(tmp_path / "f.csv"), "FETCH_SIZE", acc)
-    bench.pmc_accumulate(str(tmp_path / "w.csv"), "WRITE_SIZE", acc)
+    bench.pmc_accumulate(str(tmp_path / "p.csv"), bench.PMC_READ, acc)
     k = bench.pmc_per_launch(acc)
-    assert list(k) == [name]                                        # k_nop appeared in one pass only
-    assert k[name]["launches"] == 3 and k[name]["fetch_bytes_per_launch_raw"] == pytest.approx(1024 * (3 * 4096 + 8) / 3)
-    assert k[name]["write_bytes_per_launch"] == 1024 * 10240
+    assert set(k) == {name, "k_nop()"}
+    assert k[name]["launches"] == 3 and k[name]["read_bytes_per_launch"] == pytest.approx(32 * (3 * 300000 + 96) / 3)
+    assert k[name]["write_bytes_per_launch"] == 32 * 320000
+    assert bench.traffic_bytes(k[name]) == int(k[name]["read_bytes_per_launch"] + k[name]["write_bytes_per_launch"])
+    # a stored FETCH_SIZE / WRITE_SIZE pass of earlier rounds keeps its gfx950 doubling
+    assert bench.traffic_bytes({"fetch_bytes_per_launch_raw": 100.0, "write_bytes_per_launch": 50.0}) == 250
     assert bench.slot_kernel_match("ustep/256.1024#1", name, "f32") and not bench.slot_kernel_match("ustep/256.512", name, "f32")
     prof = {"ustep/256.1024#1": (2.0, 5), "wall:ustep": (2.5, 5)}
     run = dict(secs=0.03, inner={"cg_v": 200, "ls_v": 20, "cg_u": 290000, "ls_u": 120800}, prof=prof, steps=20, prof_period=16,
                launches={"ustep/256.1024#1": 20, "wall:ustep": 20}, scope={"ustep/256.1024#1": (135301, 200), "wall:ustep": (-1, -1)},
-               shard=(0, 6040, 939809))
-    an = bench.analyse(run, None, dict(d1=6040, d2=3952, nnz=939809, r=100), "f32", 1, None, live=k)
+               shard=(0, 6040, 939809), hbm=dict(busy_percent=0.05, samples=200, steps=700, secs=1.05))
+    an = bench.analyse(run, None, dict(d1=6040, d2=3952, nnz=939809, r=100), "f32", 1, None, live=k, live_iters=3)
     rf = an["roofline"]
-    assert rf["traffic"] == int(2 * k[name]["fetch_bytes_per_launch_raw"] + k[name]["write_bytes_per_launch"]) and rf["traffic_source"].startswith("live")
+    assert rf["traffic"] == bench.traffic_bytes(k[name]) and rf["traffic_source"].startswith("live")
     assert rf["traffic_over_algorithmic"] == pytest.approx(rf["traffic"] / rf["algorithmic_bytes_per_launch"], abs=0.01)
+    h = an["hbm"]
+    assert h["achieved_GBs"] == pytest.approx(0.05 * 83.0, abs=0.06) and h["frac"] == pytest.approx(0.05 * 83.0 / 8000, abs=1e-5)
+    assert h["bytes_per_iteration"] == pytest.approx(0.05 * 83.0e9 * 1.05 / 700, rel=1e-6)
+    assert h["fabric_bytes_per_iteration"] == bench.traffic_bytes(k[name])               # 3 launches / 3 iterations; k_nop is no kernel of the step
+    assert h["mall_served_frac"] == pytest.approx(1 - h["bytes_per_iteration"] / h["fabric_bytes_per_iteration"], abs=1e-4)
+    assert rf["hbm_achieved_GBs"] == h["achieved_GBs"] and rf["mall_served_frac"] == h["mall_served_frac"]
+    assert rf["hbm_bytes"] == pytest.approx(0.05 * 83.0e9 * rf["avg_launch_us"] * 1e-6, rel=1e-3)
+    line = bench.compact_line({"roofline": rf, "hbm": h, "config": {}})
+    assert line["roofline"]["hbm_achieved_GBs"] == h["achieved_GBs"] and line["hbm"]["mall_served_frac"] == h["mall_served_frac"]
+    # no sampler on the box (or --no-hbm): the fields are null, never zero
+    run["hbm"] = None
+    an = bench.analyse(run, None, dict(d1=6040, d2=3952, nnz=939809, r=100), "f32", 1, None, live=k, live_iters=3)
+    assert an["hbm"] is None and "hbm_achieved_GBs" not in an["roofline"] and bench._roof(an["roofline"])["hbm_achieved_GBs"] is None
 
 
 def test_uncounted_gather_figures_are_null_not_zero():

@@ -583,6 +583,29 @@ def test_gpus_option_a_signal_to_the_parent_ends_the_whole_job(tmp_path):
 
 
 @pytest.mark.gpu
+def test_gpus_option_ranks_sharing_a_device_past_its_queue_budget_take_the_host_synchronised_exchange(tmp_path):
+    """NOTES.md round 6: one GPU maps 24 hardware queues at once for ALL its processes; past that, kernels of different processes
+    are time-sliced instead of resident together and a hand-off between them costs 7-11 ms instead of 0.5 us (tools/ubench/
+    queue_budget_probe.hip) -- the layout in which four workers on one GPU once ran into the 20 s deadline of the device-driven
+    exchange.  Every rank publishes the queues it holds; four ranks with four lanes each are over the budget, so the job switches to
+    the host-synchronised exchange as a whole, says so once, and still reproduces the one-process model."""
+    g, meta, d = golden_dir("mid5", tmp_path)
+    base = [TRAIN, "-k", str(int(g["r"])), "-l", "2.5", "-t", "2", "--f64"]
+    one = run(base + [d, "one.model"], tmp_path)
+    four = run(base + ["--gpus", "4", "--devices", "0,0,0,0", "--comm", "p2p", "--tune", "lanes=4", d, "four.model"], tmp_path)
+    assert one.returncode == 0 and four.returncode == 0, four.stderr[-2000:]
+    notes = re.findall(r"^\[pcr\] p2p: (\d+) ranks share device \S+ and hold (\d+) hardware queues", four.stderr, re.M)
+    assert len(notes) == 1 and int(notes[0][0]) == 4 and int(notes[0][1]) > 16, four.stderr[-2000:]
+    assert "every exchange of this job is host-synchronised" in four.stderr
+    a = np.frombuffer(open(tmp_path / "one.model", "rb").read(), np.float64)
+    b = np.frombuffer(open(tmp_path / "four.model", "rb").read(), np.float64)
+    assert a.shape == b.shape and np.nanmax(np.abs(a[2:] - b[2:])) < 1e-9 * np.nanmax(np.abs(a[2:]))
+    # within the budget (one stream per rank, what the CLI chooses by itself for ranks that share a device): no note, device-driven
+    quiet = run(base + ["--gpus", "3", "--devices", "0,0,0", "--comm", "p2p", d, "three.model"], tmp_path)
+    assert quiet.returncode == 0 and "[pcr] p2p:" not in quiet.stderr, quiet.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_a_side_file_that_cannot_be_written_is_an_error(tmp_path):
     """pmf-train.cpp:276-295 writes U.txt / V.txt after training and ignores a failure; the drop-in CLI must not report success for a
     run whose outputs are missing: U.txt is a directory here, the run ends with a message and a non-zero exit code."""

@@ -47,6 +47,30 @@ def read(path):
         return None
 
 
+def accumulators():
+    """(timestamp, gfx_activity_acc, mem_activity_acc) of rocm_smi device 0 -- the accumulating twins of the two percentages
+    (`rocm-smi --showmemuse`: "Memory Activity"), or None."""
+    import ctypes
+    try:
+        L = ctypes.CDLL("librocm_smi64.so")
+        if not getattr(accumulators, "up", False):
+            if L.rsmi_init(ctypes.c_uint64(0)) != 0:
+                return None
+            accumulators.up = True
+
+        class Ctr(ctypes.Structure):
+            _fields_ = [("type", ctypes.c_int), ("val", ctypes.c_uint64)]
+        arr = (Ctr * 2)()
+        arr[0].type, arr[1].type = 0, 1
+        ts = ctypes.c_uint64(0)
+        if L.rsmi_utilization_count_get(ctypes.c_uint32(0), arr, ctypes.c_uint32(2), ctypes.byref(ts)) != 0:
+            return None
+        return ts.value, arr[0].val, arr[1].val
+    except OSError:
+        return None
+
+
+acc0 = accumulators()
 t0 = time.time()
 p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 samples = []
@@ -58,6 +82,7 @@ while p.poll() is None:
     time.sleep(period)
 so, se = p.communicate()
 wall = time.time() - t0
+acc1 = accumulators()
 lo, hi = int(len(samples) * 0.1), max(int(len(samples) * 0.9), 1)
 mid = samples[lo:hi] or samples
 rec = {"card_of_hip_device_0": mine.split("/")[4] if mine else None, "command": " ".join(cmd)[:300], "wall_s": round(wall, 3), "samples": len(samples), "period_ms": period * 1e3, "returncode": p.returncode, "cards": {}}
@@ -67,6 +92,9 @@ for i, c in enumerate(cards):
     if mem and (max(mem) > 0 or (gpu and max(gpu) > 0)):
         rec["cards"][c.split("/")[4]] = {"mem_busy_mean": round(statistics.mean(mem), 2), "mem_busy_median": statistics.median(mem), "mem_busy_max": max(mem),
                                          "gpu_busy_mean": round(statistics.mean(gpu), 2) if gpu else None}
+if acc0 and acc1:
+    rec["accumulators"] = {"timestamp_delta": acc1[0] - acc0[0], "gfx_activity_delta": acc1[1] - acc0[1], "mem_activity_delta": acc1[2] - acc0[2],
+                           "mem_activity_per_s": round((acc1[2] - acc0[2]) / wall, 1)}
 last = [l for l in so.strip().split("\n") if l.startswith("{")]
 if last:
     try:
