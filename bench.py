@@ -247,6 +247,9 @@ def cli_leg(data_dir, r, lam, iters=10, ref_iters=None, ref_predict=1, threads=N
         m = re.search(r"^\[timing\] (.*)$", p.stderr, re.M)
         ph = {k: float(v) for k, v in (kv.split("=") for kv in m.group(1).split())} if m else {}
         out.update({k: ph.get(k) for k in ("load_s", "init_s", "create_s", "train_s", "iter_s", "eval_s", "write_s")})
+        mc = re.search(r"^\[timing-create\] (.*)$", p.stderr, re.M)       # where create_s went: runtime wait, the library's set-up phases, factor upload
+        if mc:
+            out["create_split"] = {k: float(v) for k, v in (kv.split("=") for kv in mc.group(1).split())}
         out["process_s"] = ph.get("wall_s")              # main() start to end; wall_s - process_s = fork / exec / library + code-object load / exit
         out["model_bytes"] = os.path.getsize(os.path.join(td, "ours.model"))
         out.update(last_metrics(p.stdout))
@@ -359,7 +362,10 @@ def live_traffic(shape, prec, r, steps=10, warmup=5, timeout_s=170):
 # 6.25 TB/s streamed read of 1 GiB, 52.4 % under a 4.37 TB/s streamed write, 57.1 % under a 4.73 TB/s copy (82.9 / 83.5 / 82.7 GB/s
 # per percent) and 0 % under 6-20 TB/s of reads that the Infinity Cache or the L2s serve (64 / 192 MiB re-read, row gathers from
 # 1.6 / 7 / 109 MB tables): it is the one figure on this box that separates HBM from the Infinity Cache.
-HBM_GBS_PER_BUSY_PERCENT = 83.0
+# The same activity as an accumulating counter (rocm_smi's "Memory Activity", percent x milliseconds): 76.3 / 53.2 / 63.3 % under
+# 6.26 / 4.36 TB/s and the 1 GiB gather (82.0 GB/s per percent), 11 counts per second when idle or Infinity-Cache-resident -- a
+# resolution of 0.001 % over a second where the sampled percentage has 1 %.  The sampler reads it before and after the replay.
+HBM_GBS_PER_BUSY_PERCENT = 82.5
 
 
 class HbmSampler:
@@ -379,8 +385,40 @@ class HbmSampler:
         except OSError:
             pass
 
+        # rocm_smi's accumulating twin of that percentage, for the device with the same PCI address
+        self.smi, self.smi_dev = None, None
+        try:
+            L = ctypes.CDLL("librocm_smi64.so")
+            if self.path and L.rsmi_init(ctypes.c_uint64(0)) == 0:
+                n = ctypes.c_uint32(0)
+                L.rsmi_num_monitor_devices(ctypes.byref(n))
+                want = os.path.basename(os.path.realpath(os.path.dirname(self.path))).lower()
+                for dv in range(n.value):
+                    bdf = ctypes.c_uint64(0)
+                    if L.rsmi_dev_pci_id_get(ctypes.c_uint32(dv), ctypes.byref(bdf)) == 0:
+                        b = bdf.value
+                        if f"{(b >> 32) & 0xffffffff:04x}:{(b >> 8) & 0xff:02x}:{(b >> 3) & 0x1f:02x}.{b & 7:x}" == want:
+                            self.smi, self.smi_dev = L, dv
+        except OSError:
+            pass
+
     def available(self):
         return self.path is not None
+
+    def mem_activity_acc(self):
+        """rocm_smi's accumulated memory-controller activity (percent x ms) of this GPU, or None."""
+        if self.smi is None:
+            return None
+        import ctypes
+
+        class Ctr(ctypes.Structure):
+            _fields_ = [("type", ctypes.c_int), ("val", ctypes.c_uint64)]
+        arr = (Ctr * 1)()
+        arr[0].type = 1                                   # RSMI_COARSE_GRAIN_MEM_ACTIVITY
+        ts = ctypes.c_uint64(0)
+        if self.smi.rsmi_utilization_count_get(ctypes.c_uint32(self.smi_dev), arr, ctypes.c_uint32(1), ctypes.byref(ts)) != 0:
+            return None
+        return int(arr[0].val)
 
     def _loop(self, period):
         while not self.stop_flag:
@@ -536,13 +574,20 @@ def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name
         if smp.available():
             n_rep = max(3, min(5000, int(1.0 / max(secs / steps, 1e-6)) + 1))
             barrier()
+            time.sleep(0.05)                              # (the accumulator ticks in milliseconds: start from a quiet device)
+            a0 = smp.mem_activity_acc()
             smp.start()
             t2 = time.perf_counter()
             s.iterate(n_rep)
             barrier()
             dt = time.perf_counter() - t2
             bp, ns = smp.stop()
-            hb = dict(busy_percent=bp, samples=ns, steps=n_rep, secs=dt)
+            time.sleep(0.01)
+            a1 = smp.mem_activity_acc()
+            src = "sampled"
+            if a0 is not None and a1 is not None and a1 >= a0:
+                bp, src = (a1 - a0) / (1e3 * dt), "accumulated"       # percent x ms over the replay's milliseconds
+            hb = dict(busy_percent=bp, samples=ns, steps=n_rep, secs=dt, source=src)
     out = dict(secs=secs, secs_noevents=noev, create_s=t_create, objs=objs, inner=inner, prof=prof, launches=launches, scope=scope, prof_period=prof_period, cold=cold, hbm=hb,
                u_rows=s.counter("ustep_row_gathers") - rows0, rows_by_class=rows_by_class, steps=steps,
                te=(te_err, te_ndcg), tr=(tr_err, tr_ndcg), comm_nranks=comm_n, shard=shard_now)
@@ -680,12 +725,15 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False, live=No
         per_it = rate * 1e9 * hb["secs"] / hb["steps"]
         hbm = {"busy_percent": round(hb["busy_percent"], 2), "achieved_GBs": round(rate, 1), "peak": HBM_PEAK_GBS, "frac": round(rate / HBM_PEAK_GBS, 5),
                "bytes_per_iteration": int(per_it), "samples": hb["samples"], "replay_steps": hb["steps"], "replay_ms_per_step": round(1e3 * hb["secs"] / hb["steps"], 4),
-               "resolution_GBs": HBM_GBS_PER_BUSY_PERCENT,
+               "resolution_GBs": HBM_GBS_PER_BUSY_PERCENT if hb.get("source") != "accumulated" else round(HBM_GBS_PER_BUSY_PERCENT / (1e3 * hb["secs"]), 3),
+               "source": hb.get("source", "sampled"),
                "fabric_bytes_per_iteration": None if fabric_it is None else int(fabric_it),
                "mall_served_frac": None if not fabric_it else round(max(0.0, 1.0 - per_it / fabric_it), 4),
                "algorithmic_bytes_per_iteration": None,
-               "method": "mem_busy_percent of this GPU (the SMU's average memory-controller activity, whole percent) sampled every 4 ms "
-                         f"beside {hb['steps']} back-to-back iterations, x {HBM_GBS_PER_BUSY_PERCENT:g} GB/s per percent (calibrated on streamed "
+               "method": "the SMU's average memory-controller activity of this GPU beside "
+                         f"{hb['steps']} back-to-back iterations -- rocm_smi's accumulating 'Memory Activity' counter (percent x ms) read before and "
+                         "after the replay ('accumulated'), else /sys/class/drm/card*/device/mem_busy_percent sampled every 4 ms ('sampled', whole "
+                         f"percent) -- x {HBM_GBS_PER_BUSY_PERCENT:g} GB/s per percent (calibrated on streamed "
                          "reads / writes / copies of 1 GiB and on Infinity-Cache-resident re-reads, which read 0 %: profiles/r06_umc_calib.md); "
                          "fabric_bytes = the L2s' requests to local memory per iteration from the live counter pass, Infinity-Cache hits "
                          "included; mall_served_frac = 1 - HBM / fabric"}
@@ -1023,6 +1071,9 @@ def compact_line(full, full_record_path=None):
                                                       "reference_wall_s", "speedup_wall", "largest_phase")}
         line["cli"].update({"ndcg10_test": _r(cli.get("ndcg10_test"), 6), "reference_ndcg10_test": _r(ref.get("ndcg10_test"), 6),
                             "error": cli.get("error")})
+        if cli.get("create_split"):                      # the three largest parts of create_s (all of them in the full record)
+            top = sorted(cli["create_split"].items(), key=lambda kv: -kv[1])[:4]
+            line["cli"]["create_split"] = {k: _r(v, 3) for k, v in top if k != "solver_create_s"}
     line["full_record"] = full_record_path
     # the cap: drop optional blocks (least important first) rather than ever print a line the driver cannot keep
     size = lambda: len(json.dumps(line, separators=(",", ":")))
@@ -1192,7 +1243,14 @@ class SecondLeg:
             import traceback
             traceback.print_exc()
             why = f"{type(e).__name__}: {e}"[:300]
-            self.note(why)
+            try:                                # (a peer that failed FIRST has left its note: this rank's own error -- a reset connection,
+                first = open(self.flag).read().strip().split("\n")[0]      # a poisoned exchange -- is only the echo of it)
+            except OSError:
+                first = ""
+            if first:
+                why = first
+            else:
+                self.note(why)
             self.leave(why)
         self.done.set()
         self.thread.join()
@@ -1365,6 +1423,14 @@ def guarded_main():
     """Every way a rank can stop says why: `[rank q] ...` with the traceback on stderr, a non-zero exit code, and -- on rank 0,
     whose stdout is the one a driver reads -- {"error": ...} as the last stdout line."""
     rank = os.environ.get("RANK", "0")
+
+    def let_rank0_speak():
+        # A launcher (torch.distributed.run) answers the first non-zero exit code with SIGTERM to every other rank: a rank other
+        # than 0 that fails for a reason ALL ranks share (no GPU visible, a missing library) waits a moment, so that rank 0's
+        # {"error": ...} line -- the one a driver reads -- is out before the launcher takes rank 0 down.
+        if rank != "0":
+            sys.stdout.flush(); sys.stderr.flush()
+            time.sleep(1.5)
     try:
         main()
     except SystemExit as e:
@@ -1372,6 +1438,7 @@ def guarded_main():
             log(f"[rank {rank}] {e.code}")
             if rank == "0":
                 error_line(str(e.code), rank=0)
+            let_rank0_speak()
             sys.exit(1)
         raise
     except BaseException as e:                   # (KeyboardInterrupt / SIGTERM-as-exception included)
@@ -1381,6 +1448,7 @@ def guarded_main():
         if rank == "0":
             error_line(f"{type(e).__name__}: {e}"[:500], rank=0)
         sys.stdout.flush(); sys.stderr.flush()
+        let_rank0_speak()
         os._exit(1)                              # (not sys.exit: a rank blocked peers' collectives must not wait in atexit handlers)
 
 

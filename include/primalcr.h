@@ -264,6 +264,10 @@ int pcr_solver_comm_nranks(pcr_solver *s);
  *                        name, e.g. "ustep/256.512"; pcr_solver_ustep_classes lists them, comma-separated) */
 int pcr_solver_counter(pcr_solver *s, const char *name, double *value);
 int pcr_solver_ustep_classes(pcr_solver *s, char *buf, int64_t cap);
+/* Where pcr_solver_create's wall time went -- the unit the reference spends in convert() (util.cpp:219-274) and this library in
+ * uploads, the set-up built on the device and the stream probes: phase i (0, 1, ...) of the creation, in order; *name points
+ * into the solver (valid until it is destroyed).  PCR_ERR_ARG past the last phase.  omp-pmf-train --timing prints the list. */
+int pcr_solver_setup_phase(const pcr_solver *s, int i, const char **name, double *ms);
 /* Shard-local mode for a solver created with nranks > 1 and no communicator: every collective
  * becomes a no-op, so pcr_obtain_g / pcr_compute_Ha / pcr_objective return THIS SHARD'S PARTIAL
  * (rank 0 carries the lambda term).  Lets a host application combine shards itself, and lets one

@@ -101,6 +101,7 @@ def lib():
     L.pcr_solver_comm_init_p2p.argtypes = [vp, C.c_char_p]
     L.pcr_solver_comm_nranks.argtypes = [vp]
     L.pcr_solver_counter.argtypes = [vp, C.c_char_p, C.POINTER(cd)]
+    L.pcr_solver_setup_phase.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(cd)]
     L.pcr_solver_ustep_classes.argtypes = [vp, C.c_char_p, i64]
     L.pcr_solver_set_local_only.argtypes = [vp, ci]
     L.pcr_solver_shard.argtypes = [vp] + [C.POINTER(i64)] * 3
@@ -321,6 +322,14 @@ class Solver:
         v = C.c_double()
         _chk(lib().pcr_solver_counter(self._h, name.encode(), v))
         return v.value
+
+    def setup_phases(self):
+        """[(phase, ms)] of pcr_solver_create, in order."""
+        out, i = [], 0
+        name, ms = C.c_char_p(), C.c_double()
+        while lib().pcr_solver_setup_phase(self._h, i, C.byref(name), C.byref(ms)) == PCR_OK:
+            out.append((name.value.decode(), ms.value)); i += 1
+        return out
 
     def ustep_classes(self):
         """Profile slot names of the U step's length classes on this rank."""

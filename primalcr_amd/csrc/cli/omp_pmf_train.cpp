@@ -473,13 +473,26 @@ int main(int argc, char** argv) {
     auto t0 = std::chrono::steady_clock::now();
     (void)lap();
     if (warm.joinable()) warm.join();
+    const double warm_wait_s = lap();                     // what was left of HIP runtime initialisation + code-object load after load / init
     pcr_solver* s = nullptr;
     if (!devices.empty()) param.device = devices[0];
     if (pcr_solver_create(ds, &param, 0, 1, &s) != PCR_OK) { fprintf(stderr, "solver: %s\n", pcr_last_error()); return 1; }
     hold.s = s;
     auto fail = [](const char* what) { fprintf(stderr, "%s: %s\n", what, pcr_last_error()); return 1; };
+    const double solver_s = lap();                        // pcr_solver_create alone (its phases: pcr_solver_setup_phase)
     if (pcr_solver_set_factors(s, U.data(), V.data()) != PCR_OK) return fail("set_factors");
-    create_s = lap();
+    create_s = warm_wait_s + solver_s + lap();
+    if (timing) {
+        // where solver creation went: the join with the thread that brought the HIP runtime up, then the library's own phases
+        fprintf(stderr, "[timing-create] wait_for_runtime_s=%.4f solver_create_s=%.4f set_factors_s=%.4f", warm_wait_s, solver_s, create_s - solver_s - warm_wait_s);
+        const char* name = nullptr; double ms = 0.0;
+        for (int ph = 0; pcr_solver_setup_phase(s, ph, &name, &ms) == PCR_OK; ++ph) {
+            std::string key = name;
+            for (char& ch : key) if (ch == ' ' || ch == ',' || ch == '-') ch = '_';
+            fprintf(stderr, " %s=%.4f", key.c_str(), ms / 1e3);
+        }
+        fprintf(stderr, "\n");
+    }
     SnapCtx snap{s, snapshot_every, model, d1, d2, k, &U, &V, false};
     std::vector<pcr_iter_stats> hist((size_t)std::max(0, param.maxiter) + 1);
     if (pcr_train(s, snapshot_every > 0 ? snap_log : nullptr, &snap, hist.data()) != PCR_OK) return fail("train");

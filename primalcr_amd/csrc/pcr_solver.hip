@@ -143,6 +143,7 @@ struct pcr_solver {
     bool local_only = false;      // nranks > 1 without a communicator: entry points return this shard's partials
     int prof_period = 1;          // time every prof_period-th launch of each slot
     std::map<std::string, ProfSlot> prof;
+    std::vector<std::pair<std::string, double>> setup_ms;   // wall time of the phases of pcr_solver_create, in order (pcr_solver_counter "setup_ms/<i>", pcr_solver_setup_phase)
     virtual int prof_resolve() = 0;
     virtual void prof_prewarm(int n) = 0;
 };
@@ -709,14 +710,16 @@ struct Solver final : pcr_solver {
         const int64_t nu = n_users;
 
         // (pcr_tune("debug"): wall time of the set-up phases)
-        if (tune.debug) fprintf(stderr, "[pcr] set-up: %-28s %8.1f ms\n", "device, streams, events", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_init).count());
-        auto t_phase = std::chrono::steady_clock::now();
+        // wall time of the set-up phases: kept (pcr_solver_setup_phase; omp-pmf-train --timing prints them), printed with pcr_tune("debug")
+        auto t_phase = t_init;
         auto phase = [&](const char* what) {
-            if (!tune.debug) return;
             const auto now = std::chrono::steady_clock::now();
-            fprintf(stderr, "[pcr] set-up: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_phase).count());
+            const double ms = std::chrono::duration<double, std::milli>(now - t_phase).count();
+            setup_ms.emplace_back(what, ms);
+            if (tune.debug) fprintf(stderr, "[pcr] set-up: %-28s %8.1f ms\n", what, ms);
             t_phase = now;
         };
+        phase("device, streams, events");
         // ---- host-side shard preparation
         std::vector<int64_t> uptr(nu + 1);
         for (int64_t u = 0; u <= nu; ++u) uptr[u] = X.index[ds_u0 + u] - z0;
@@ -1586,18 +1589,6 @@ struct Solver final : pcr_solver {
         return sync_checked();
     }
 
-    // all-rank |U|^2 (cached until U changes)
-    int ensure_unorm() {
-        if (unorm_valid) return PCR_OK;
-        RC(norm2(d_U.p, (int64_t)n_users * geo.ld, 8));
-        RC(allreduce_f64(d_scal.p + 8, 1));
-        HIPCHK(hipMemcpyAsync(h_scal + 8, d_scal.p + 8, sizeof(double), hipMemcpyDeviceToHost, st));
-        RC(sync_checked());                                        // (an all-reduced value is only valid if its exchange completed)
-        unorm2 = h_scal[8];
-        unorm_valid = true;
-        return PCR_OK;
-    }
-
     // loss (all ranks) of the last prepare + lambda/2 (|U|^2 + |Vm|^2)   (pcrpp.cpp:410)
     // d_scal[0] = sum objx (all ranks), [1] = |Vm|^2, [2] = |U|^2 (all ranks; only if with_u): one pass + one finish
     // objx2 (optional): a second per-user sum -> [3].  after_ustep: the finishing kernel also moves the U step's counters to
@@ -2255,6 +2246,13 @@ int pcr_solver_comm_init_p2p(pcr_solver* s, const char* shm_name) {
     PCR_ABI("pcr_solver_comm_init_p2p", s->comm_init_p2p(shm_name));
 }
 int pcr_solver_comm_nranks(pcr_solver* s) { if (!s) return -1; return s->comm_nranks(); }
+int pcr_solver_setup_phase(const pcr_solver* s, int i, const char** name, double* ms) {
+    S_OR_ARG;
+    if (i < 0 || i >= (int)s->setup_ms.size()) return PCR_ERR_ARG;      // (the end of the list: no error text)
+    if (name) *name = s->setup_ms[(size_t)i].first.c_str();
+    if (ms) *ms = s->setup_ms[(size_t)i].second;
+    return PCR_OK;
+}
 int pcr_solver_counter(pcr_solver* s, const char* name, double* value) {
     S_OR_ARG;
     if (!name || !value) { pcr_set_error("pcr_solver_counter: bad argument"); return PCR_ERR_ARG; }

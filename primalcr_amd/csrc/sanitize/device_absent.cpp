@@ -35,6 +35,7 @@ NO_SOLVER(pcr_solver_comm_init_p2p, pcr_solver*, const char*)
 int pcr_solver_comm_nranks(pcr_solver*) { return -1; }
 NO_SOLVER(pcr_solver_counter, pcr_solver*, const char*, double*)
 NO_SOLVER(pcr_solver_ustep_classes, pcr_solver*, char*, int64_t)
+NO_SOLVER(pcr_solver_setup_phase, const pcr_solver*, int, const char**, double*)
 NO_SOLVER(pcr_solver_set_local_only, pcr_solver*, int)
 NO_SOLVER(pcr_solver_shard, const pcr_solver*, int64_t*, int64_t*, int64_t*)
 NO_SOLVER(pcr_solver_set_factors, pcr_solver*, const double*, const double*)

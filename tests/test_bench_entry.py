@@ -197,8 +197,10 @@ def test_under_the_drivers_launcher_a_job_without_gpus_says_so():
     if torch.cuda.is_available():
         pytest.skip("a GPU is visible: test_two_ranks_under_the_drivers_launcher runs the job itself")
     p = run_bench_under_torchrun(2, "--steps", "1", "--warmup", "0", "--no-cpu")
+    if "[rank " not in p.stderr:             # (the launcher itself failed -- its rendezvous port taken between our probe and its bind: once more)
+        p = run_bench_under_torchrun(2, "--steps", "1", "--warmup", "0", "--no-cpu")
     assert p.returncode != 0
-    assert "[rank 0]" in p.stderr and "[rank 1]" in p.stderr and "no GPU visible" in p.stderr and "starting 2 ranks" not in p.stderr
+    assert "[rank 0]" in p.stderr and "[rank 1]" in p.stderr and "no GPU visible" in p.stderr and "starting 2 ranks" not in p.stderr, p.stderr[-1500:]
     errs = [json.loads(l) for l in p.stdout.strip().split("\n") if l.startswith("{")]
     assert len(errs) == 1 and errs[0]["value"] is None and "no GPU visible" in errs[0]["error"]        # rank 0's line, nobody else's
 
@@ -370,12 +372,12 @@ def test_live_pmc_pass_is_summed_per_kernel_and_priced_per_launch(tmp_path):
     assert rf["traffic"] == bench.traffic_bytes(k[name]) and rf["traffic_source"].startswith("live")
     assert rf["traffic_over_algorithmic"] == pytest.approx(rf["traffic"] / rf["algorithmic_bytes_per_launch"], abs=0.01)
     h = an["hbm"]
-    assert h["achieved_GBs"] == pytest.approx(0.05 * 83.0, abs=0.06) and h["frac"] == pytest.approx(0.05 * 83.0 / 8000, abs=1e-5)
-    assert h["bytes_per_iteration"] == pytest.approx(0.05 * 83.0e9 * 1.05 / 700, rel=1e-6)
+    assert h["achieved_GBs"] == pytest.approx(0.05 * bench.HBM_GBS_PER_BUSY_PERCENT, abs=0.06) and h["frac"] == pytest.approx(0.05 * bench.HBM_GBS_PER_BUSY_PERCENT / 8000, abs=1e-5)
+    assert h["bytes_per_iteration"] == pytest.approx(0.05 * 1e9 * bench.HBM_GBS_PER_BUSY_PERCENT * 1.05 / 700, rel=1e-6)
     assert h["fabric_bytes_per_iteration"] == bench.traffic_bytes(k[name])               # 3 launches / 3 iterations; k_nop is no kernel of the step
     assert h["mall_served_frac"] == pytest.approx(1 - h["bytes_per_iteration"] / h["fabric_bytes_per_iteration"], abs=1e-4)
     assert rf["hbm_achieved_GBs"] == h["achieved_GBs"] and rf["mall_served_frac"] == h["mall_served_frac"]
-    assert rf["hbm_bytes"] == pytest.approx(0.05 * 83.0e9 * rf["avg_launch_us"] * 1e-6, rel=1e-3)
+    assert rf["hbm_bytes"] == pytest.approx(0.05 * 1e9 * bench.HBM_GBS_PER_BUSY_PERCENT * rf["avg_launch_us"] * 1e-6, rel=1e-3)
     line = bench.compact_line({"roofline": rf, "hbm": h, "config": {}})
     assert line["roofline"]["hbm_achieved_GBs"] == h["achieved_GBs"] and line["hbm"]["mall_served_frac"] == h["mall_served_frac"]
     # no sampler on the box (or --no-hbm): the fields are null, never zero
