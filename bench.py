@@ -428,14 +428,19 @@ class HbmSampler:
                 pass
             time.sleep(period)
 
-    def start(self, period=0.004):
+    def start(self, period=0.02):
+        # (only where the accumulating counter is not available: every read of the percentage is a query to the SMU, and 250 of
+        # them per second slowed the replay itself -- 2.63 instead of 1.50 ms per ml1m step in the first run of this code)
         import threading
-        self.samples, self.stop_flag = [], False
-        self.thread = threading.Thread(target=self._loop, args=(period,), daemon=True)
-        self.thread.start()
+        self.samples, self.stop_flag, self.thread = [], False, None
+        if self.smi is None:
+            self.thread = threading.Thread(target=self._loop, args=(period,), daemon=True)
+            self.thread.start()
 
     def stop(self):
         self.stop_flag = True
+        if self.thread is None:
+            return None, 0
         self.thread.join()
         xs = self.samples[len(self.samples) // 5:]        # (the firmware's average needs a moment to reach the replay's level)
         return (sum(xs) / len(xs), len(xs)) if xs else (None, 0)
@@ -696,8 +701,12 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False, live=No
         un = [k for k in kernels if k.startswith("ustep/")]
         if un and prof.get("wall:ustep", (0, 0))[1]:
             wm, wn = prof["wall:ustep"]
+            # pcr_tune("ustep_newton"): k_unewton runs on the solver's stream BEFORE the classes fork -- it is U-step time (round 5's
+            # line booked it under the V step, which is "the rest of the step")
+            nm, nn = prof.get("unewton", (0.0, 0))
+            newton_ms = (nm / nn) * run["launches"].get("unewton", 0) / steps if nn else 0.0
             u_gather = None if u_rows is None else u_rows / steps / N * r * esz     # this rank's share (the counter is the all-rank total)
-            roof_phase["u_step"] = dict(phase(un, wm / wn, u_gather, "ustep"), kernels=un,
+            roof_phase["u_step"] = dict(phase(un, wm / wn + newton_ms, u_gather, "ustep"), kernels=un, exact_newton_us_per_step=round(1e3 * newton_ms, 1) if nn else None,
                                         note="all length classes of k_ustep, launched side by side: sum of their algorithmic bytes / fork..join wall "
                                              "time on the solver's stream; gather_GBs = rows of V actually gathered (counted in the kernel: per user "
                                              "1 + 2 per CG iteration + 1 per line-search try, x its ratings) x row bytes / that wall time, against "
@@ -732,7 +741,7 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False, live=No
                "algorithmic_bytes_per_iteration": None,
                "method": "the SMU's average memory-controller activity of this GPU beside "
                          f"{hb['steps']} back-to-back iterations -- rocm_smi's accumulating 'Memory Activity' counter (percent x ms) read before and "
-                         "after the replay ('accumulated'), else /sys/class/drm/card*/device/mem_busy_percent sampled every 4 ms ('sampled', whole "
+                         "after the replay ('accumulated'), else /sys/class/drm/card*/device/mem_busy_percent sampled every 20 ms ('sampled', whole "
                          f"percent) -- x {HBM_GBS_PER_BUSY_PERCENT:g} GB/s per percent (calibrated on streamed "
                          "reads / writes / copies of 1 GiB and on Infinity-Cache-resident re-reads, which read 0 %: profiles/r06_umc_calib.md); "
                          "fabric_bytes = the L2s' requests to local memory per iteration from the live counter pass, Infinity-Cache hits "

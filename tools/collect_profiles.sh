@@ -1,7 +1,7 @@
 #!/bin/bash
 # Dev tool (GPU box): everything profiles/<tag>_<shape>_* is built from, in one gpurun call.
 #   bash tools/collect_profiles.sh <tag> <shape> <precision> [passes] [extra bench.py args...]
-#       e.g. r03_a ml1m f32 "trace fetch write l2 lds occ mix"        r03_a netflix f32 "trace fetch write l2 lds" --steps 3 --warmup 1
+#       e.g. r06_e ml1m f32 "trace dram l2 lds occ mix"   (dram = the byte-exact 32-byte-unit counters of round 6; fetch / write = FETCH_SIZE / WRITE_SIZE)        r03_a netflix f32 "trace fetch write l2 lds" --steps 3 --warmup 1
 # Writes gpurun_out/<tag>/<shape>_<precision>/: kernel-trace stats CSV and one rocprofv3 --pmc pass per counter group (separate runs,
 # no trace domain beside --kernel-trace; the program directly behind "--").
 set -o pipefail
@@ -13,8 +13,8 @@ REPO=$PWD
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-B="python3 $REPO/bench.py --no-live-traffic --full-line --full-record /tmp/bench_full_prof.json --shape $SHAPE --precision $PREC --no-cpu --no-cli --no-f64 --no-netflix --no-rows $EXTRA"
-declare -A PMC=( [fetch]="FETCH_SIZE" [write]="WRITE_SIZE" [l2]="TCC_HIT_sum TCC_MISS_sum" [lds]="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES"
+B="python3 $REPO/bench.py --no-live-traffic --no-hbm --full-line --full-record /tmp/bench_full_prof.json --shape $SHAPE --precision $PREC --no-cpu --no-cli --no-f64 --no-netflix --no-rows $EXTRA"
+declare -A PMC=( [dram]="TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_WRREQ_WRITE_DRAM_32B_sum" [fetch]="FETCH_SIZE" [write]="WRITE_SIZE" [l2]="TCC_HIT_sum TCC_MISS_sum" [lds]="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES"
                  [occ]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
                  [mix]="SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" )
 for P in $PASSES; do

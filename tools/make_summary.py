@@ -10,6 +10,12 @@ src, dst = f"gpurun_out/{tag}/{shape}_{prec}", "profiles"
 base = f"{dst}/{tag}_{shape}_{prec}"
 load = lambda n: json.load(open(f"{src}/pmc_{n}.json")) if os.path.exists(f"{src}/pmc_{n}.json") else {}
 fe, wr, l2, lds, occ, mix = (load(n) for n in ("fetch", "write", "l2", "lds", "occ", "mix"))
+dr = load("dram")        # round 6: TCC_EA0_RDREQ_DRAM_32B_sum / TCC_EA0_WRREQ_WRITE_DRAM_32B_sum, x 32 B, byte-exact (profiles/r06_dram_calib.md)
+if dr:                   # expressed in the units the table below expects: "FETCH_SIZE" KiB such that 2 x it = the read bytes
+    for k, v in dr.items():
+        n = v.get("launches", 1)
+        fe[k] = {"launches": n, "FETCH_SIZE": 32.0 * v.get("TCC_EA0_RDREQ_DRAM_32B_sum", 0.0) / 2.0 / 1024.0}
+        wr[k] = {"launches": n, "WRITE_SIZE": 32.0 * v.get("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", 0.0) / 1024.0}
 out = [f"# {tag} / {shape} / {prec}: rocprofv3 counters per kernel ({note})", "",
        f"Command of every pass: `rocprofv3 --pmc <counters> -- python3 bench.py --shape {shape} --precision {prec} --no-cpu --no-f64 --no-netflix --no-rows --no-profile [...]` "
        "(one pass per counter group; `--kernel-trace --stats` in a pass of its own -> the kernel_stats.csv beside this file). "
@@ -22,6 +28,10 @@ if os.path.exists(f"{src}/kernel_stats.csv"):
     out.append("")
 names = sorted(set(fe) | set(wr) | set(l2) | set(lds), key=lambda k: -(fe.get(k, {}).get("FETCH_SIZE", 0) + wr.get(k, {}).get("WRITE_SIZE", 0)))
 traffic = {}
+if dr:
+    out += ["Traffic columns: the byte-exact 32-byte-unit counters (`TCC_EA0_RDREQ_DRAM_32B_sum`, `TCC_EA0_WRREQ_WRITE_DRAM_32B_sum` x 32 B, one pass); "
+            "'FETCH raw' = read bytes / 2 (what FETCH_SIZE would have shown).  These are the L2s' requests to local memory: Infinity-Cache hits INCLUDED; "
+            "the HBM side of the same workload is the `hbm` block of the bench line (memory-controller activity).", ""]
 out += ["| kernel | launches | FETCH raw MB/launch | WRITE MB/launch | traffic = 2 x FETCH + WRITE MB/launch | L2 hit rate (TCC_HIT / (HIT + MISS)) | LDS bank-conflict cycles / LDS active cycles | LDS instructions per wave-kcycle |",
         "|---|---|---|---|---|---|---|---|"]
 for k in names:
