@@ -577,13 +577,22 @@ def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name
     if args.hbm and N == 1 and not count_rows and steps > 0:
         smp = HbmSampler(job.device)
         if smp.available():
-            n_rep = max(3, min(5000, int(1.0 / max(secs / steps, 1e-6)) + 1))
+            # The replay repeats THE SAME iterations as the measurement (warm-up + timed steps from pcr_initial, again and again for
+            # >= 1 s) -- not hundreds of further ones: past convergence an fp32 line search no longer finds a decrease and runs
+            # its 20 halvings, which is another workload (the first version of this replay ran 665 more ml1m iterations at 2.64 ms
+            # each instead of 1.50).  The reset is one upload of the initial factors per block (ml1m: 1 ms in 37).
+            U0, V0 = pcr.initial_rows(total, r, first, s.n_users), pcr.initial(d2, r)
+            blk = max(1, warmup + steps)
+            n_blk = max(1, int(1.0 / max(blk * secs / steps, 1e-6)) + 1)
+            n_rep = n_blk * blk
             barrier()
             time.sleep(0.05)                              # (the accumulator ticks in milliseconds: start from a quiet device)
             a0 = smp.mem_activity_acc()
             smp.start()
             t2 = time.perf_counter()
-            s.iterate(n_rep)
+            for _ in range(n_blk):
+                s.set_factors_local(U0, V0)
+                s.iterate(blk)
             barrier()
             dt = time.perf_counter() - t2
             bp, ns = smp.stop()
@@ -740,7 +749,7 @@ def analyse(run, rows_run, wl, prec_name, N, traffic_key, verbose=False, live=No
                "mall_served_frac": None if not fabric_it else round(max(0.0, 1.0 - per_it / fabric_it), 4),
                "algorithmic_bytes_per_iteration": None,
                "method": "the SMU's average memory-controller activity of this GPU beside "
-                         f"{hb['steps']} back-to-back iterations -- rocm_smi's accumulating 'Memory Activity' counter (percent x ms) read before and "
+                         f"{hb['steps']} iterations (the measurement's own warm-up + timed steps from the initial factors, repeated for >= 1 s) -- rocm_smi's accumulating 'Memory Activity' counter (percent x ms) read before and "
                          "after the replay ('accumulated'), else /sys/class/drm/card*/device/mem_busy_percent sampled every 20 ms ('sampled', whole "
                          f"percent) -- x {HBM_GBS_PER_BUSY_PERCENT:g} GB/s per percent (calibrated on streamed "
                          "reads / writes / copies of 1 GiB and on Infinity-Cache-resident re-reads, which read 0 %: profiles/r06_umc_calib.md); "

@@ -681,7 +681,19 @@ struct Solver final : pcr_solver {
             HIPCHK(hipStreamCreateWithPriority(&hi, hipStreamNonBlocking, greatest));
         }
         // (the side streams are created when pick_lanes probes them: a solver that needs three lanes creates four or five streams,
-        // not twelve -- a stream is 4-5 ms of set-up and a hardware queue of the device)
+        // not twelve -- a stream is 4-5 ms of set-up and a hardware queue of the device.  The first four, which every default
+        // layout ends up creating, come up on a helper thread while this one prepares and uploads the shard: 20 ms of the set-up's
+        // 80 on the ml1m shape, profiles/r06_cli_create.txt.)
+        std::thread side_maker;
+        struct JoinSide { std::thread& t; ~JoinSide() { if (t.joinable()) t.join(); } } join_side{side_maker};
+        if (tune.lanes != 1) {
+            const int want = tune.lanes > 0 ? std::min(MAXLANE, tune.lanes) : 4;
+            side_maker = std::thread([this, dev = prm.device, n = std::min(NSIDE, want)]() {
+                if (hipSetDevice(dev) != hipSuccess) return;
+                for (int c = 0; c < n; ++c)
+                    if (hipStreamCreateWithFlags(&side[c], hipStreamNonBlocking) != hipSuccess) { side[c] = nullptr; (void)hipGetLastError(); return; }
+            });
+        }
 
         const PcrCsr& X = ds->train;
         d1 = X.d1; d2 = X.d2; tnnz_file = ds->tnnz_file;
@@ -1154,6 +1166,7 @@ struct Solver final : pcr_solver {
         RC(set_lds_limits());
         HIPCHK(hipStreamSynchronize(st));
         phase("factors, scratch");
+        if (side_maker.joinable()) side_maker.join();
         RC(pick_lanes());
         phase("stream lanes");
         return PCR_OK;
@@ -1699,9 +1712,103 @@ struct Solver final : pcr_solver {
         RC(launch_vsweep(true, pvec, skip));
         return launch_spmm(out, pvec, rank == 0 ? prm.lambda : 0.0, skip, dots_rr);
     }
+#ifdef PCR_PIPE_PROBE
+    // Developer build only (make lib LIBDIR=build_next/probe PCR_EXTRA=-DPCR_PIPE_PROBE; tools/exp_pipe_probe.py): TIMING of one
+    // Hessian-vector product as it runs today (five kernels back to back on the solver's stream) against the two-stream form of
+    // VERDICT r5 item 7 -- each of the three tile-parallel kernels over HALF the ratings / users / workgroups on either stream,
+    // one device-side fork and one join per product, k_spmm_fin behind the join.  The halves are cut by position (the first and
+    // second half of the rating range, of both user lists, of the SpMM's workgroups), which is what a tile-wise split would launch;
+    // the second halves read what the first halves have not finished writing, so the VALUES are meaningless -- only the clock counts.
+    int pipe_probe() {
+        if (sbins[0].users.empty() || sbins[1].users.empty() || n_rng != 1 || nnz_local < 4096) return PCR_OK;
+        hipStream_t sd = nullptr;
+        HIPCHK(hipStreamCreateWithFlags(&sd, hipStreamNonBlocking));
+        hipEvent_t e0, e1, ef, ej;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+        const int tile = sddmm_tile ? sddmm_tile : 64, ngrp = 256 / geo.G, span = ngrp * tile;
+        Bin &ba = sbins[0], &bb = sbins[1];
+        const int na = (int)ba.users.size(), nb = (int)bb.users.size(), rsa = ba.max_lev + 2, rsb = bb.max_lev + 2;
+        const bool two = !sh.ws;
+        const size_t wb = (vsweep_wave_bytes<T>(ba.cap, rsa, two) + 15) & ~(size_t)15;
+        const size_t lds = std::max(wb * 8, small_common(512) + vsweep_bytes<T>(bb.cap, rsb, two));
+        const bool dense = lds <= (size_t)40 * 1024;
+        const int bc = sweep_pf4 ? 2 : 0;
+        auto sddmm = [&](hipStream_t q, int64_t z0, int64_t z1) {
+            hipLaunchKernelGGL((k_sddmm<T, 256>), dim3((unsigned)cdiv(z1 - z0, span)), dim3(256), (size_t)span * 8, q, d_U.p, d_p.p, d_ruser.p + z0, d_sitem.p + z0, z1 - z0,
+                               d_b.p + z0, geo, tile, (const int*)nullptr, (const int32_t*)nullptr, (const int2*)nullptr, (const int32_t*)nullptr);
+        };
+        auto sweep = [&](hipStream_t q, int a0, int a1, int b0, int b1) {
+            const int grid = (b1 - b0) + cdiv(a1 - a0, 8);
+            if (dense) hipLaunchKernelGGL((k_vsweep_all<T, true, 512, 8>), dim3(grid), dim3(512), lds, q, sh, ba.d_users.p + a0, a1 - a0, ba.cap, rsa, wb, bb.d_users.p + b0, b1 - b0, bb.cap, rsb, b1 - b0, d_b.p, d_c.p, strict(), (const int*)nullptr, bc);
+            else hipLaunchKernelGGL((k_vsweep_all<T, true, 512, 1>), dim3(grid), dim3(512), lds, q, sh, ba.d_users.p + a0, a1 - a0, ba.cap, rsa, wb, bb.d_users.p + b0, b1 - b0, bb.cap, rsb, b1 - b0, d_b.p, d_c.p, strict(), (const int*)nullptr, bc);
+        };
+        auto spmm = [&](hipStream_t q, int w0, int w1) {
+            hipLaunchKernelGGL((k_spmm<T, 256>), dim3(w1 - w0), dim3(256), 0, q, d_c.p, d_c2r.p, d_cuf.p, d_chunk_ptr.p, d_slot_base.p, d_slot_id.p, d_blk_chunks.p + w0, d_U.p, d_slab.p, geo, (const int*)nullptr);
+        };
+        auto fin = [&](hipStream_t q) {
+            hipLaunchKernelGGL((k_spmm_fin<T, 256, false>), dim3(fin_blocks()), dim3(256), 0, q, d_slab.p, d_item_slot.p, d_p.p, 0.0, (int)d2, d_Hp.p, geo, (const int*)nullptr, (const T*)nullptr, (double*)nullptr, 0);
+        };
+        const int64_t zh = nnz_local / 2;
+        const int wh = (spmm_blocks / 2) & ~7;
+        const int R = 60;
+        auto timed = [&](const char* what, auto body) -> int {
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipStreamSynchronize(sd));
+                HIPCHK(hipEventRecord(e0, st));
+                for (int i = 0; i < R; ++i) body();
+                HIPCHK(hipEventRecord(e1, st));
+                HIPCHK(hipEventSynchronize(e1));
+                HIPCHK(hipStreamSynchronize(sd));
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+                best = std::min(best, ms);
+            }
+            fprintf(stderr, "[pipe-probe] %-74s %7.2f us per product\n", what, 1e3 * best / R);
+            return PCR_OK;
+        };
+        RC(timed("today: sddmm, sweep, spmm, fin on one stream", [&]() { sddmm(st, 0, nnz_local); sweep(st, 0, na, 0, nb); spmm(st, 0, spmm_blocks); fin(st); }));
+        RC(timed("  sddmm alone", [&]() { sddmm(st, 0, nnz_local); }));
+        RC(timed("  sddmm, first half of the ratings alone", [&]() { sddmm(st, 0, zh); }));
+        RC(timed("  sweep alone", [&]() { sweep(st, 0, na, 0, nb); }));
+        RC(timed("  sweep, first half of both user lists (the longest users) alone", [&]() { sweep(st, 0, na / 2, 0, nb / 2); }));
+        RC(timed("  spmm alone", [&]() { spmm(st, 0, spmm_blocks); }));
+        RC(timed("  spmm, first half of the workgroups alone", [&]() { spmm(st, 0, wh); }));
+        RC(timed("  fin alone", [&]() { fin(st); }));
+        RC(timed("halves back to back on ONE stream (what the split itself costs)", [&]() {
+            sddmm(st, 0, zh); sddmm(st, zh, nnz_local); sweep(st, 0, na / 2, 0, nb / 2); sweep(st, na / 2, na, nb / 2, nb); spmm(st, 0, wh); spmm(st, wh, spmm_blocks); fin(st); }));
+        RC(timed("two streams: halves side by side, fork + join per product, fin behind the join", [&]() {
+            (void)hipEventRecord(ef, st); (void)hipStreamWaitEvent(sd, ef, 0);
+            sddmm(st, 0, zh); sddmm(sd, zh, nnz_local); sweep(st, 0, na / 2, 0, nb / 2); sweep(sd, na / 2, na, nb / 2, nb); spmm(st, 0, wh); spmm(sd, wh, spmm_blocks);
+            (void)hipEventRecord(ej, sd); (void)hipStreamWaitEvent(st, ej, 0);
+            fin(st); }));
+        RC(timed("two streams, the side stream one kernel behind (its sddmm starts with the other half's sweep)", [&]() {
+            sddmm(st, 0, zh);
+            (void)hipEventRecord(ef, st); (void)hipStreamWaitEvent(sd, ef, 0);
+            sweep(st, 0, na / 2, 0, nb / 2); sddmm(sd, zh, nnz_local); spmm(st, 0, wh); sweep(sd, na / 2, na, nb / 2, nb); spmm(sd, wh, spmm_blocks);
+            (void)hipEventRecord(ej, sd); (void)hipStreamWaitEvent(st, ej, 0);
+            fin(st); }));
+        RC(timed("full-size sweep on the side stream beside the full-size sddmm (latency-bound beside bandwidth-bound)", [&]() {
+            (void)hipEventRecord(ef, st); (void)hipStreamWaitEvent(sd, ef, 0);
+            sddmm(st, 0, nnz_local); sweep(sd, 0, na, 0, nb);
+            (void)hipEventRecord(ej, sd); (void)hipStreamWaitEvent(st, ej, 0); }));
+        RC(timed("full-size spmm on the side stream beside the full-size sddmm (two bandwidth-bound kernels)", [&]() {
+            (void)hipEventRecord(ef, st); (void)hipStreamWaitEvent(sd, ef, 0);
+            sddmm(st, 0, nnz_local); spmm(sd, 0, spmm_blocks);
+            (void)hipEventRecord(ej, sd); (void)hipStreamWaitEvent(st, ej, 0); }));
+        HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipStreamSynchronize(sd));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(ef); (void)hipEventDestroy(ej); (void)hipStreamDestroy(sd);
+        return PCR_OK;
+    }
+#endif
     int compute_Ha(const double* a, double* Ha) override {
         RC(need_sorted());
         RC(upload_mat(a, d2, d_p.p));
+#ifdef PCR_PIPE_PROBE
+        RC(pipe_probe());
+        RC(need_sorted());
+#endif
         RC(device_hv(d_p.p, d_Hp.p));
         return download_mat(d_Hp.p, d2, Ha);
     }
