@@ -1927,9 +1927,9 @@ struct Solver final : pcr_solver {
             if (newton_n > 0) {
                 const int ldp = (geo.ld + 15) & ~15;
                 ProfScope ps(this, "unewton", st, -1, newton_n);
-                size_t lds = newton_bytes<T>(newton_cap, newton_rs, geo.ld, ldp);
-                const int wbcap = lds + newton_wb_bytes(newton_cap) <= (size_t)160 * 1024 ? newton_cap : 0;
-                if (wbcap) lds += newton_wb_bytes(newton_cap);
+                // (the window bounds ride along where the workgroup still fits half a CU's LDS: two workgroups per CU matter more)
+                const int wbcap = newton_bytes<T>(newton_cap, newton_rs, geo.ld, ldp, newton_cap) <= (size_t)80 * 1024 ? newton_cap : 0;
+                const size_t lds = newton_bytes<T>(newton_cap, newton_rs, geo.ld, ldp, wbcap);
                 hipLaunchKernelGGL((k_unewton<T>), dim3(newton_grid), dim3(256), lds, st, sh, geo,
                                    d_newton_users.p, newton_n, d_U.p, d_V.p, prm.lambda, strict(), newton_cap, newton_rs, ldp, d_newton_scratch.p, newton_stride, d_dir.p, wbcap);
                 HIPCHK(hipGetLastError());
