@@ -10,17 +10,19 @@
 // scores within 1 above / below, pcrpp.cpp:218,224), so w_p is a handful of differences of a prefix table P of the user's rows in
 // sorted order.  One workgroup per user (256 threads):
 //     1. gradient coefficients c_p and degrees by the same window searches as the sweeps (sweep_coeff, pcr_prims.h);
-//     2. one pass over the user's rows of V: the prefix table P (global scratch, L2-resident) and g = lambda u + X^T c;
-//     3. a second pass in chunks of 16 rows: X chunk and Y chunk staged in LDS (fp64), H += X^T Y on the matrix cores
-//        (v_mfma_f64_16x16x4_f64; the upper triangle of 16 x 16 tiles dealt to the four waves, accumulated in registers);
+//     2. one pass over the user's rows of V (eight segments of the positions side by side, 16-byte loads): the prefix table P
+//        (global scratch, served by the L2s / the Infinity Cache) and g = lambda u + X^T c; the prefix rows at the run boundaries are
+//        summed once per level (Bnd), so that a rating needs ONE table row per other level, not two;
+//     3. a second pass in chunks of 16 rows: X chunk and Y chunk staged in LDS (fp64) -- the next chunk's loads in flight meanwhile --
+//        H += X^T Y on the matrix cores (v_mfma_f64_16x16x4_f64; the upper triangle of 16 x 16 tiles dealt to the four waves,
+//        accumulated in registers, one k-step of all of a wave's tile pairs at a time: independent MFMAs back to back);
 //     4. BLOCKED Cholesky of H in LDS (round 6): H as 16 x 16 tiles of its lower triangle, laid OVER the per-rating arrays and staging
 //        chunks of steps 1-3 (the workgroup needs max(build, factor) of LDS, not the sum: two workgroups per CU); per tile column k
 //        the diagonal tile by one wave, the panel below it by row-parallel substitution in registers, the trailing update on the
 //        matrix cores -- 3 barriers per tile column (21 at r = 100) where the column-by-column form had 300; then the two
 //        triangular solves by one wave with the vector in registers (v_readlane hand-offs, reciprocal diagonal): delta = H^-1 g -> dir[u];
 // k_ustep then takes delta instead of running its CG (line search, re-sorts, objective and the state hand-over are its own).
-// Covered: users of at most NEWTON_MAX_N ratings at ranks of at most 112 (H, the per-rating arrays and the staging chunks share the
-// 160 KB of LDS); every other user keeps k_ustep's CG, run to convergence (r iterations, tolerance 1e-12) -- the same Newton step by
+// Covered: users of at most NEWTON_MAX_N ratings at ranks of at most 112 (78.5 KB of LDS per workgroup at 1024 ratings and r = 100); every other user keeps k_ustep's CG, run to convergence (r iterations, tolerance 1e-12) -- the same Newton step by
 // another route.  A Hessian that is not positive definite to rounding leaves NaN in dir[u][0], at which k_ustep falls back likewise.
 #pragma once
 #include "pcr_kernels.h"

@@ -994,7 +994,9 @@ struct Solver final : pcr_solver {
             newton_grid = std::max(1, std::min(newton_n, 2 * ncu));
             newton_stride = (((size_t)newton_cap + 1) * ldp * sizeof(double) + 255) & ~(size_t)255;
             RC(d_newton_scratch.alloc(newton_stride * (size_t)newton_grid));
+#ifndef PCR_NO_OPTIONAL_KERNELS
             HIPCHK(hipFuncSetAttribute((const void*)k_unewton<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
             if (tune.debug) fprintf(stderr, "[pcr] exact-Newton U step: %d of %lld users through the explicit Hessian (<= %d ratings)\n", newton_n, (long long)nu, NEWTON_MAX_N);
         }
         {
@@ -1193,8 +1195,10 @@ struct Solver final : pcr_solver {
         else UL(512, false, 1, false, 4);
         UL(512, true, 1, true, 8); UL(512, true, 1, false, 4); UL(512, true, 4, true, 8);
 #undef UL
+#ifndef PCR_NO_OPTIONAL_KERNELS      // (a measurement build without the three optional kernel families: profiles/r06_cli_create.txt)
         HIPCHK(hipFuncSetAttribute((const void*)k_ustep_gram<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_ustep_gram<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+#endif
         HIPCHK(hipFuncSetAttribute((const void*)k_eval<T, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHK(hipFuncSetAttribute((const void*)k_eval2<T, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         return PCR_OK;
@@ -1443,7 +1447,9 @@ struct Solver final : pcr_solver {
         if (hv && vblock_nbp) {                                   // the block's share of b = U A^T on the matrix cores (pcr_vblock.h)
             ProfScope ps(this, "vblock_b");
             const int64_t tiles = (int64_t)(vblock_nbp / GramMfma<T>::TS) * cdiv(d2, GramMfma<T>::TS);
+#ifndef PCR_NO_OPTIONAL_KERNELS
             hipLaunchKernelGGL((k_vblock_b<T>), dim3((unsigned)cdiv(tiles, 4)), dim3(256), 0, st, d_U.p, A, d_blk_user.p, vblock_nbp, d_cpos_dense.p, d2, geo, d_b.p, skip);
+#endif
             HIPCHK(hipGetLastError());
         }
         return launch_sweeps(hv, skip, hv && sddmm_by_tiles());
@@ -1524,7 +1530,9 @@ struct Solver final : pcr_solver {
             if (vblock_nbp) {                                     // + the block's share, C_B^T U_B on the matrix cores, before the exchange
                 ProfScope ps(this, "vblock_hp");
                 const int64_t tiles = (int64_t)cdiv(d2, GramMfma<T>::TS) * cdiv(geo.ld, GramMfma<T>::TS);
+#ifndef PCR_NO_OPTIONAL_KERNELS
                 hipLaunchKernelGGL((k_vblock_hp<T>), dim3((unsigned)cdiv(tiles, 4)), dim3(256), 0, st, d_U.p, d_c.p, d_blk_user.p, vblock_nbp, d_cpos_dense.p, d2, geo, out, skip);
+#endif
             }
             HIPCHK(hipGetLastError());
             return allreduce_T(out, n);
@@ -1930,8 +1938,12 @@ struct Solver final : pcr_solver {
                 // (the window bounds ride along where the workgroup still fits half a CU's LDS: two workgroups per CU matter more)
                 const int wbcap = newton_bytes<T>(newton_cap, newton_rs, geo.ld, ldp, newton_cap) <= (size_t)80 * 1024 ? newton_cap : 0;
                 const size_t lds = newton_bytes<T>(newton_cap, newton_rs, geo.ld, ldp, wbcap);
+#ifndef PCR_NO_OPTIONAL_KERNELS
                 hipLaunchKernelGGL((k_unewton<T>), dim3(newton_grid), dim3(256), lds, st, sh, geo,
                                    d_newton_users.p, newton_n, d_U.p, d_V.p, prm.lambda, strict(), newton_cap, newton_rs, ldp, d_newton_scratch.p, newton_stride, d_dir.p, wbcap);
+#else
+                (void)lds;
+#endif
                 HIPCHK(hipGetLastError());
             }
             dirp = d_dir.p;
@@ -1952,6 +1964,7 @@ struct Solver final : pcr_solver {
 #define LUS(BL, BG, KK, RS, UN, SY) hipLaunchKernelGGL((k_ustep<T, BL, BG, KK, RS, UN, SY>), dim3(grid), dim3(BL), lds, q, sh, geo, b.d_users.p, nus, d_U.p, d_V.p, prm.lambda, prm.stepsize, cg_max_u, cg_tol_u, strict(), strict(), b.cap, cap_pad, rsc, b.rcap, nchp, scr, scratch_stride, d_counters.p, cb, (tune.fault_cluster_member ? 1 : 0) | (tune.count_rows ? 2 : 0) | (state_of_rejected_V ? 4 : 0), b.wcap, dirp)
 #define LU(BL, BG, KK, RS, UN) LUS(BL, BG, KK, RS, UN, 0)
 #define LU2(BL) do { if (b.sym) LUS(BL, false, 1, false, 4, 1); else LUS(BL, false, 1, false, 4, 0); } while (0)
+#ifndef PCR_NO_OPTIONAL_KERNELS
             if (b.gram) {
                 const size_t gl = gram_bytes<T>(b.cap, cap_pad, rsc, geo.ld, nchp, b.block);
                 if (b.block == 64)
@@ -1962,6 +1975,7 @@ struct Solver final : pcr_solver {
                                        prm.cg_max_iter, prm.cg_tol, strict(), strict(), b.cap, cap_pad, rsc, nchp, d_counters.p, tune.count_rows);
                 return;
             }
+#endif
             if (b.big) { if (b.K == 4) LU(512, true, 4, true, 8); else if (b.unr == 8) LU(512, true, 1, true, 8); else LU(512, true, 1, false, 4); }
             else if (b.block == 64) { if (b.rcap > 0) LU(64, false, 1, true, 4); else LU2(64); }
             else if (b.block == 256) LU2(256);

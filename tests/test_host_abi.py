@@ -394,7 +394,7 @@ def test_loader_blank_lines_crlf_and_missing_final_newline(tmp_path):
         (d / "meta").write_text(f"{R.d1} {R.d2}\n{len(lines)} training.ratings\n")
         assert len(body) > (1 << 20)
         n = ctypes.c_int64(-1)
-        assert pcr.lib().pcr_rating_file_count(str(d / "training.ratings").encode(), ctypes.byref(n)) == pcr.PCR_OK and n.value == len(lines), style
+        assert pcr.lib().pcr_rating_file_count(str(d / "training.ratings").encode(), ctypes.byref(n)) == 0 and n.value == len(lines), style
         for threads in (1, 5):
             got = pcr.Dataset.load(str(d), threads=threads).csr(0)
             assert all(np.array_equal(a, b) for a, b in zip(got, want)), (style, threads)
