@@ -320,7 +320,7 @@ def traffic_bytes(t):
     return int(2 * t["fetch_bytes_per_launch_raw"] + t["write_bytes_per_launch"])
 
 
-def live_traffic(shape, prec, r, steps=10, warmup=5, timeout_s=170):
+def live_traffic(shape, prec, r, steps=10, warmup=5, timeout_s=170, users=None):
     """Memory-side traffic of THIS box, now: ONE rocprofv3 --pmc pass (both 32-byte-unit DRAM counters, no trace domain beside them,
     the program directly behind "--": MI355X_MICROARCH.md) of a short replay of the same workload in a child process (warmup +
     steps + 1 outer iterations from pcr_initial, no event timing).  Returns ({kernel name: {"launches", "read_bytes_per_launch",
@@ -336,7 +336,7 @@ def live_traffic(shape, prec, r, steps=10, warmup=5, timeout_s=170):
         out = os.path.join(tmp, "pmc")
         cmd = [exe, "--pmc", PMC_READ, PMC_WRITE, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--shape", shape,
                "--precision", prec, "--rank-k", str(r), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu", "--no-cli", "--no-f64", "--no-netflix", "--no-rows",
-               "--no-profile", "--no-live-traffic", "--no-hbm", "--full-record", os.path.join(tmp, "child.json")]
+               "--no-profile", "--no-live-traffic", "--no-hbm", "--full-record", os.path.join(tmp, "child.json")] + (["--users", str(users)] if users else [])
         p = subprocess.Popen(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
                              text=True, start_new_session=True)
         try:
@@ -505,13 +505,30 @@ def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name
     with pcr.tuned(**({"count_rows": 1} if count_rows else {})):
         s = pcr.Solver(ds, p, rank, N, shard=shard)
     t_create = time.perf_counter() - t_create          # pcr_solver_create(_shard): uploads + the set-up built on the device
+    comm_used = None
     if N > 1:
+        p2p_name = shm_name + ("_64" if prec == pcr.PCR_F64 else "_32") + ("c" if count_rows else "")
+        comm_used = args.comm
         if args.comm == "p2p":
-            s.comm_init_p2p(shm_name + ("_64" if prec == pcr.PCR_F64 else "_32") + ("c" if count_rows else ""))
+            s.comm_init_p2p(p2p_name)
         else:
-            s.comm_init(job.bcast(pcr.comm_unique_id() if rank == 0 else None))
+            # RCCL -- and if ANY rank cannot join its communicator (an error code from ncclCommInitRank: a layout RCCL refuses, a
+            # transport it cannot set up), the WHOLE job takes the direct peer-to-peer exchange instead of ending without a
+            # measurement: the ranks agree through the launcher's process group, every rank starts over with a fresh solver.
+            err = None
+            try:
+                s.comm_init(job.bcast(pcr.comm_unique_id() if rank == 0 else None))
+            except Exception as e:
+                err = f"{type(e).__name__}: {e}"[:200]
+            if job.allsum(1.0 if err else 0.0) > 0:
+                log(f"[rank {rank}] the RCCL communicator could not be set up on every rank ({err or 'a peer failed'}): the job takes the peer-to-peer exchange")
+                s.close()
+                with pcr.tuned(**({"count_rows": 1} if count_rows else {})):
+                    s = pcr.Solver(ds, p, rank, N, shard=shard)
+                s.comm_init_p2p(p2p_name + "_fb")
+                comm_used = "p2p (fallback: the RCCL communicator could not be set up)"
         if s.comm_nranks() != N:                 # "RCCL saw N ranks": nothing is timed on a communicator of another size
-            raise RuntimeError(f"the {args.comm} communicator reports {s.comm_nranks()} ranks, the job has {N}")
+            raise RuntimeError(f"the {comm_used} communicator reports {s.comm_nranks()} ranks, the job has {N}")
     # the reference's init stream (util.cpp:80): this rank's rows of initial(d1, k), and V = initial(d2, k)
     s.set_factors_local(pcr.initial_rows(total, r, first, s.n_users), pcr.initial(d2, r))
 
@@ -604,7 +621,7 @@ def timed_run(job, ds, shard, d2, r, lam, prec, steps, warmup, profile, shm_name
             hb = dict(busy_percent=bp, samples=ns, steps=n_rep, secs=dt, source=src)
     out = dict(secs=secs, secs_noevents=noev, create_s=t_create, objs=objs, inner=inner, prof=prof, launches=launches, scope=scope, prof_period=prof_period, cold=cold, hbm=hb,
                u_rows=s.counter("ustep_row_gathers") - rows0, rows_by_class=rows_by_class, steps=steps,
-               te=(te_err, te_ndcg), tr=(tr_err, tr_ndcg), comm_nranks=comm_n, shard=shard_now)
+               te=(te_err, te_ndcg), tr=(tr_err, tr_ndcg), comm_nranks=comm_n, shard=shard_now, comm_used=comm_used)
     s.close()
     return out
 
@@ -859,11 +876,14 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
     main_p = precisions[0]
     run = runs[main_p]
     secs, objs, inner = run["secs"], run["objs"], run["inner"]
-    tkey = f"{shape}:{main_p}" if (users is None and nnz is None and N == 1 and r == (200 if shape == "yahoo" else 100)) else None
+    whole_yahoo = shape == "yahoo" and users == synth.SHAPES["yahoo"][0] and nnz is None          # configs[4] itself on one GPU
+    tkey = (f"{shape}{'-whole' if whole_yahoo else ''}:{main_p}"
+            if ((users is None or whole_yahoo) and nnz is None and N == 1 and r == (200 if shape == "yahoo" else 100)) else None)
     live, live_iters = None, 0
     if args.live_traffic and N == 1 and profile and tkey:
         lt_steps, lt_warm = (10, 5) if shape == "ml1m" else (3, 1)
-        live, live_iters, took = live_traffic(shape, main_p, r, lt_steps, lt_warm, timeout_s=170 if shape == "ml1m" else 600)
+        live, live_iters, took = live_traffic(shape, main_p, r, lt_steps, lt_warm, timeout_s=170 if shape == "ml1m" else (1500 if whole_yahoo else 600),
+                                              users=users if whole_yahoo else None)
         log("[traffic] live rocprofv3 --pmc pass: " + (f"{took:.0f} s, {live_iters} iterations replayed" if live else f"not available ({took}): stored passes used"))
     an = analyse(run, run["rows"], wl, main_p, N, tkey, verbose, live, live_iters)
     value = n_pairs * steps / secs
@@ -882,7 +902,7 @@ def measure(job, shape, r, lam, steps, warmup, users=None, nnz=None, precisions=
         # SURVEY 8d, kernel-level figure: ordered pairs swept per second over the EXECUTED sweep passes of a step
         # (V side: gradient + Hessian-vector products + line-search objectives; U side the same per user, averaged)
         "passes_per_step": an["passes_per_step"], "sweep_pairs_per_s": value * an["passes_per_step"],
-        "comm_nranks": run["comm_nranks"], "shards": bounds, "exchange_profile": an["exchange"],
+        "comm_nranks": run["comm_nranks"], "comm_used": run.get("comm_used"), "shards": bounds, "exchange_profile": an["exchange"],
         "cold_start": run["cold"], "ms_per_step_first5": run["cold"]["ms_per_step"] if run["cold"] and run["cold"]["iterations"] == 5 else None,
         "roofline": an["roofline"], "roofline_phase": an["roofline_phase"], "roofline_iteration": an["roofline_iteration"],
         "gather": an["gather"], "kernels": an["kernels"], "hbm": an["hbm"],
@@ -1396,7 +1416,7 @@ def main():
                "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic",
                "config": {"workload": rec["workload"], "solver": "PrimalCR++", "rank": r, "lambda": lam,
                           "parallelism": f"user-sharded x{N}", "accumulation": "f64", "storage": rec["dtype"],
-                          "exchange": None if N == 1 else args.comm}}
+                          "exchange": None if N == 1 else (rec.get("comm_used") or args.comm)}}
         for k, v in rec.items():
             if k not in out and k not in ("workload", "scaling", "dtype", "steps", "warmup"):
                 out[k] = v

@@ -136,6 +136,22 @@ def test_two_ranks_on_one_gpu_equal_one_rank():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
+def test_a_layout_rccl_refuses_falls_back_to_the_peer_to_peer_exchange():
+    """`--comm rccl` is the default of an N > 1 run, and RCCL has never met a second rank here.  If any rank cannot join its
+    communicator -- two ranks on ONE device is a layout ncclCommInitRank refuses with an error code -- the ranks agree through the
+    launcher's process group and the whole job takes the direct peer-to-peer exchange: a measurement with `config.exchange` saying
+    so instead of an {"error": ...} line."""
+    p = run_bench("--gpus", "2", "--comm", "rccl", "--devices", "0,0", "--rendezvous", "gloo", "--steps", "2", "--warmup", "1", "--users", "800",
+                  "--nnz", "100000", "--no-cpu", "--no-f64", "--no-rows", "--no-netflix")
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.strip().split("\n") if l.startswith("{")][-1])
+    assert "error" not in line and line["value"] > 0 and line["n_gpus"] == 2 and line["comm_nranks"] == 2
+    assert line["config"]["exchange"].startswith("p2p (fallback") and "peer-to-peer exchange" in p.stderr
+    assert line["shards"] == [[0, 800, 100000], [800, 800, 100000]]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
 def test_a_failing_netflix_leg_never_costs_the_headline():
     """the second leg of an N > 1 run is wrapped -- a rank that fails inside it (the hook raises on rank 1, so
     rank 0 is left waiting in the leg's first collective) yields netflix = {"error": ...} in the ONE line, with the ml1m record
