@@ -53,7 +53,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 GATHER_CEILING_GBS = {"l2-gather": 18800.0,     # table shared by every workgroup, in each XCD's 4 MiB L2: 16.8-18.8 TB/s
                       "mall-gather": 8600.0,    # 38 MB table, uniformly random rows (Infinity Cache): 8.6 TB/s; 151 MB: 7.4-7.9
                       "hbm-gather": 6100.0}     # tables beyond the 256 MiB Infinity Cache: 6.0-6.1 TB/s
-TRAFFIC_FILE = "r05_traffic.json"   # stored PMC passes of this command (tools/collect_profiles.sh): the fall-back when the live passes are off
+TRAFFIC_FILE = "r06_traffic.json"   # stored PMC passes of this command (tools/collect_profiles.sh): the fall-back when the live passes are off
 USERS_PER_GPU = 6040
 D2, NNZ_PER_GPU = 3952, 939809
 YAHOO_USERS_PER_GPU = 225000
