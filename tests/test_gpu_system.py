@@ -199,3 +199,21 @@ def test_half_steps_match_oracle_on_a_long_tailed_shape(oracle):
         gU, giu = s.update_U()
         assert abs(gU / objU - 1) < 1e-11 and (giu["cg"], giu["ls"]) == (iu["cg"], iu["ls"])
         assert rel(s.get_factors()[0], U) < 1e-10
+
+
+def test_setup_phases_of_solver_creation_are_kept():
+    """pcr_solver_setup_phase (the split `omp-pmf-train --timing` prints as [timing-create]): the phases of pcr_solver_create in
+    order, each with its wall time; their sum is the creation's own time, the list ends with PCR_ERR_ARG and no error text."""
+    import time
+    import primalcr_amd as pcr
+    from primalcr_amd import synth
+    R = synth.generate("small", seed=4)
+    ds = pcr.Dataset.from_ratings(R)
+    t0 = time.perf_counter()
+    s = pcr.Solver(ds, pcr.Parameter(k=8, **{"lambda": 10.0}))
+    wall_ms = 1e3 * (time.perf_counter() - t0)
+    ph = s.setup_phases()
+    names = [n for n, _ in ph]
+    assert names[0] == "device, streams, events" and names[-1] == "stream lanes" and "tile-major CSC, slab plan" in names and len(names) >= 8
+    assert all(ms >= 0.0 for _, ms in ph) and 0.5 * wall_ms < sum(ms for _, ms in ph) <= wall_ms + 1.0
+    s.close()

@@ -8,7 +8,7 @@ that the Infinity Cache serves).
 Samples /sys/class/drm/card*/device/mem_busy_percent (the SMU's average UMC activity, what `rocm-smi --showmemuse` prints as "GPU
 Memory Read/Write Activity") and gpu_busy_percent of every card while the command runs, and reports, per card that was busy, the
 mean / median / maximum over the middle 80 % of the run.  The figure is a firmware average in whole percent: calibrate it on
-known patterns first (tools/ubench/dram_calib loop read|reread|..., tools/r06_b.sh) before reading a workload with it."""
+known patterns first (tools/ubench/dram_calib loop read|reread|..., tools/archive/r06_b.sh) before reading a workload with it."""
 import glob, json, os, statistics, subprocess, sys, time
 
 args = sys.argv[1:]
