@@ -327,7 +327,7 @@ class Solver:
         """[(phase, ms)] of pcr_solver_create, in order."""
         out, i = [], 0
         name, ms = C.c_char_p(), C.c_double()
-        while lib().pcr_solver_setup_phase(self._h, i, C.byref(name), C.byref(ms)) == PCR_OK:
+        while lib().pcr_solver_setup_phase(self._h, i, C.byref(name), C.byref(ms)) == 0:
             out.append((name.value.decode(), ms.value)); i += 1
         return out
 
