@@ -447,3 +447,55 @@ def test_every_ustep_class_is_one_kernel_symbol_in_the_committed_profiles():
         dom = rec["roofline"]["kernel"]
         if dom.startswith("ustep/"):
             assert rec["roofline"]["traffic"] and rec["roofline"]["traffic_over_algorithmic"] > 1, (shape, rec["roofline"])
+
+
+_SECOND_LEG_DRIVER = r"""
+import json, os, sys, time
+sys.path.insert(0, {root!r})
+import bench
+rank, flag, mode = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+held = {{"metric": "pairwise-comparisons/sec", "value": 123.0}}
+def emit(netflix):
+    print(json.dumps(dict(held, netflix=netflix)), flush=True)
+leg = bench.SecondLeg(rank, flag, 4.0 if mode == "deadline" else 60.0, emit)
+def fn():
+    if mode == "raise" and rank == 1:
+        raise RuntimeError("boom in the second leg")
+    if mode == "ok":
+        return {{"ms_per_step": 1.0}}
+    time.sleep(120)            # a collective whose peer is gone: never returns by itself
+out = leg.run(fn)
+if rank == 0:
+    emit(out)
+"""
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("mode", ["raise", "deadline", "sigterm", "ok"])
+def test_second_leg_guard_always_lets_the_held_record_out(mode, tmp_path):
+    """bench.SecondLeg, the guard round the Netflix-shaped leg of an N > 1 run, without a GPU: two "ranks" as processes.  A rank that
+    raises leaves a note and every watchdog ends its process -- rank 0 printing the held record with netflix = {"error": ...} first;
+    so does the deadline, and SIGTERM while the main thread sits in a call that never returns; a leg that succeeds prints its result.
+    ONE line on rank 0, exit code 0, within seconds."""
+    import signal, time
+    drv = tmp_path / "drv.py"
+    drv.write_text(_SECOND_LEG_DRIVER.format(root=ROOT))
+    flag = str(tmp_path / "leg.failed")
+    t0 = time.time()
+    ps = [subprocess.Popen([sys.executable, str(drv), str(q), flag, mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for q in (0, 1)]
+    if mode == "sigterm":
+        time.sleep(2.5)
+        ps[0].send_signal(signal.SIGTERM)
+        time.sleep(0.5)
+        ps[1].send_signal(signal.SIGTERM)
+    outs = [p.communicate(timeout=60) for p in ps]
+    assert time.time() - t0 < 40 and [p.returncode for p in ps] == [0, 0], [o[1][-500:] for o in outs]
+    lines = [l for l in outs[0][0].strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1 and outs[1][0].strip() == ""                     # rank 0 speaks, once; rank 1 prints nothing
+    line = json.loads(lines[0])
+    assert line["value"] == 123.0
+    if mode == "ok":
+        assert line["netflix"] == {"ms_per_step": 1.0}
+    else:
+        want = {"raise": "rank 1: RuntimeError: boom in the second leg", "deadline": "time budget", "sigterm": "SIGTERM"}[mode]
+        assert want in line["netflix"]["error"], line
