@@ -1394,7 +1394,7 @@ def main():
             log("[bench] several ranks share a device: one stream per rank (--tune lanes=1)")
     job = Job(args, torch, dist, rank, N, device)
     r, lam = args.rank_k or (200 if args.shape == "yahoo" else 100), args.lam
-    # N > 1: ONE timed run, one communicator (the scaling record needs `value`; the fp64 leg and the row-counting replay are three
+    # N > 1: ONE timed run and one communicator per shape (the scaling record needs `value`; the fp64 leg and the row-counting replay are three
     # more solvers and communicators per rank on a path that has never met a peer over xGMI -- ask for them with --all-legs)
     if N > 1 and not args.all_legs:
         args.no_f64 = True
