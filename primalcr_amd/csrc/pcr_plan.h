@@ -4,6 +4,7 @@
 // incidences with their static item-major slab rows) is built ON THE DEVICE from the uploaded CSR: pcr_plan_dev.h.  No GPU calls here.
 // Replaces the scatter of pcrpp.cpp:240-243 / :323-327 (one `omp atomic` per scalar) by a static plan built once per data set.
 #pragma once
+#include <cmath>
 #include <algorithm>
 #include <cstdint>
 #include <vector>
@@ -28,6 +29,27 @@ struct SpmmPlan {
 };
 
 // ---- the plan in three host steps around the device build (pcr_plan_dev.h) -------------------------------------------------------
+
+// chunk = ratings one lane group of k_spmm walks (one slab row per item it meets).  A shard whose lane groups all fit on the chip at
+// once (6 workgroups per CU at 80 VGPRs) gets the smallest chunk that still fits in ONE round -- more, shorter chains (ml1m fp32: 96
+// instead of 128, k_spmm 32.3 -> 30.3 us; 64: 33.3 us, a second round; 192: 40.3 us).  A shard that needs between one and four rounds
+// at 128 AND whose lane groups are whole waves (G = 64: fp64 at k = 100, wide ranks) takes, of 128 / 96 / 64, the chunk whose LAST round
+// is fullest (round 6: ml1m in fp64 needs 1.19 rounds at 128 -- a second round for a fifth of the work: k_spmm 50.8 us -- against 1.59
+// at 96: 47.0 us, the fp64 step 2.40 -> 2.345 ms).  Everything else: 128 (large shards: the tail is one round in dozens).
+static inline int plan_pick_chunk(int64_t nnz_local, int ncu, int G) {
+    const int64_t groups_at_once = (int64_t)ncu * 6 * (256 / G);
+    const int64_t fit = (std::max<int64_t>(nnz_local, 1) + groups_at_once - 1) / groups_at_once;
+    if (fit <= 128) return (int)std::max<int64_t>(64, (fit + 31) / 32 * 32);
+    if (fit >= 4 * 128 || G < 64) return 128;                    // (32-lane groups: a 2 M-rating fp32 shard measured 1.2 % SLOWER under the rule below)
+    int best = 128;
+    double best_idle = 2.0;
+    for (int c : {128, 96, 64}) {
+        const double rounds = (double)fit / c, full = std::ceil(rounds);
+        const double idle = (full - rounds) / full;               // share of the slots the last round leaves empty
+        if (idle < best_idle - 1e-9) { best_idle = idle; best = c; }      // (ties: the larger chunk, fewer slab rows)
+    }
+    return best;
+}
 // 1. plan_tiles: chunk length, user tiles (tile_u), item ranges -- from the row pointers alone
 static inline void plan_tiles(const SpmmPlanIn& in, SpmmPlan& P, std::vector<int64_t>& tile_u) {
     const std::vector<int64_t>& uptr = in.uptr;
@@ -43,15 +65,7 @@ static inline void plan_tiles(const SpmmPlanIn& in, SpmmPlan& P, std::vector<int
     // untiled, 0.6 MB tiles 411 us: the tile shares the XCD's 4 MB L2 with the streamed ids, c and the slab stores);
     // inside a tile the entries are ordered by item, then user.
     {
-        // chunk = ratings one lane group walks (one slab row per item it meets).  128 on large shards; a shard whose
-        // workgroups all fit on the chip at once (6 per CU at 80 VGPRs) gets the smallest chunk that still fits in one
-        // round -- more, shorter chains: ml1m 96 instead of 128, k_spmm 32.3 -> 30.3 us, 1.69 -> 1.66 ms per iteration
-        // (64: 33.3 us, a second round; 192: 40.3 us)
-        {
-            const int64_t groups_at_once = (int64_t)ncu * 6 * (256 / geo.G);
-            const int64_t fit = cdiv(std::max<int64_t>(nnz_local, 1), groups_at_once);
-            spmm_chunk = (int)std::min<int64_t>(128, std::max<int64_t>(64, (fit + 31) / 32 * 32));
-        }
+        spmm_chunk = plan_pick_chunk(nnz_local, ncu, geo.G);     // ratings one lane group walks
         if (tune.spmm_chunk > 0) spmm_chunk = std::max(8, tune.spmm_chunk);
         const size_t row_bytes = (size_t)geo.ld * in.esz;
         int64_t tile_users_max = std::max<int64_t>(64, (int64_t)((5u << 18) / row_bytes));
@@ -183,15 +197,7 @@ static inline void build_spmm_plan_host(const SpmmPlanIn& in, SpmmPlan& P) {
             for (int64_t z = uptr[u]; z < uptr[u + 1]; ++z) ruser[z] = (int32_t)u;
     });
     {
-        // chunk = ratings one lane group walks (one slab row per item it meets).  128 on large shards; a shard whose
-        // workgroups all fit on the chip at once (6 per CU at 80 VGPRs) gets the smallest chunk that still fits in one
-        // round -- more, shorter chains: ml1m 96 instead of 128, k_spmm 32.3 -> 30.3 us, 1.69 -> 1.66 ms per iteration
-        // (64: 33.3 us, a second round; 192: 40.3 us)
-        {
-            const int64_t groups_at_once = (int64_t)ncu * 6 * (256 / geo.G);
-            const int64_t fit = cdiv(std::max<int64_t>(nnz_local, 1), groups_at_once);
-            spmm_chunk = (int)std::min<int64_t>(128, std::max<int64_t>(64, (fit + 31) / 32 * 32));
-        }
+        spmm_chunk = plan_pick_chunk(nnz_local, ncu, geo.G);     // ratings one lane group walks
         if (tune.spmm_chunk > 0) spmm_chunk = std::max(8, tune.spmm_chunk);
         const size_t row_bytes = (size_t)geo.ld * in.esz;
         int64_t tile_users_max = std::max<int64_t>(64, (int64_t)((5u << 18) / row_bytes));
